@@ -1,0 +1,323 @@
+"""Generate golden input/output vectors by RUNNING THE REFERENCE on CPU in this container.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+
+The reference (read-only at /root/reference, pure Python) is imported under the
+sys.modules stubs of tools/ref_import.py; only DATA (inputs + the reference's outputs)
+is written to tests/golden/.  Inputs come from numpy seeded generators or closed-form
+recipes and are stored alongside the outputs, so the fixtures are self-contained.
+This script never runs on the GPU box (the reference does not travel).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_import  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+# ---------------------------------------------------------------------------
+def make_cfg(ref, **over):
+    """Reference-style cfg (AttrDict tree) with the reference defaults."""
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "creid_cfg", os.path.join(ROOT, "centroids-reid_amd", "config.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    c = m.get_cfg_defaults()
+
+    def conv(d):
+        a = ref_import.AttrDict()
+        for k, v in d.items():
+            a[k] = conv(v) if isinstance(v, dict) else v
+        return a
+    c = conv(c)
+    c.MODEL.PRETRAINED = False
+    c.SOLVER.OPTIMIZER_NAME = "Adam"
+    for k, v in over.items():
+        node = c
+        parts = k.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return c
+
+
+def gapped_features(nq, ng, D, seed, min_gap, iters=20000):
+    """Unit-norm features whose per-query sorted distances have adjacent gaps >= min_gap
+    (so that rank order is implementation-independent: SURVEY.md §7 'hard parts')."""
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((nq + ng, D)).astype(np.float32)
+    for it in range(iters):
+        fn = f / np.maximum(np.linalg.norm(f.astype(np.float64), axis=1, keepdims=True), 1e-12)
+        q, g = fn[:nq], fn[nq:]
+        d = ((q * q).sum(1)[:, None] + (g * g).sum(1)[None, :] - 2 * q @ g.T)
+        order = np.argsort(d, axis=1)
+        ds = np.take_along_axis(d, order, 1)
+        gaps = np.diff(ds, axis=1)
+        bad = np.argwhere(gaps < min_gap)
+        if len(bad) == 0:
+            return f, it
+        qi, k = bad[0]
+        j = order[qi, k + 1]
+        f[nq + j] += (rng.standard_normal(D) * 0.05).astype(np.float32)
+    raise RuntimeError("could not build a gapped fixture")
+
+
+def gen_eval(ref, name, nq, ng, D, seed, n_pid, n_cam, min_gap, force_invalid=0, split_cams=False, slim=False):
+    f, it = gapped_features(nq, ng, D, seed, min_gap)
+    rng = np.random.default_rng(seed + 1)
+    pids = rng.integers(0, n_pid, nq + ng).astype(np.int64)
+    cams = rng.integers(0, n_cam, nq + ng).astype(np.int64)
+    if split_cams:                           # no same-camera removals (kept length == ng)
+        cams[:nq] = 0; cams[nq:] = 1
+    for k in range(force_invalid):           # queries whose pid never appears in the gallery
+        pids[k] = n_pid + 100 + k
+    feats = torch.from_numpy(f)
+    # --- the reference path: utils/reid_metric.py:112-135 then utils/eval_reid.py:25-92
+    fn = torch.nn.functional.normalize(feats, dim=1, p=2)
+    distmat = ref.reid_metric.get_euclidean(x=fn[:nq], y=fn[nq:])
+    indices = np.argsort(distmat.numpy(), axis=1)
+    cmc, mAP, topk, single = ref.eval_reid.eval_func(
+        indices, pids[:nq], pids[nq:], cams[:nq], cams[nq:], 50, False)
+    ds = np.take_along_axis(distmat.numpy().astype(np.float64), indices, 1)
+    big = {} if slim else dict(feats_norm=fn.numpy(), distmat=distmat.numpy())
+    np.savez_compressed(
+        os.path.join(OUT, name), feats=f, pids=pids, camids=cams, num_query=np.int64(nq),
+        indices=indices.astype(np.int64), **big,
+        cmc=np.asarray(cmc, np.float32), mAP=np.float64(mAP), topk=np.asarray(topk, np.float64),
+        single=np.asarray(single, np.float64), min_gap=np.float64(np.diff(ds, axis=1).min()))
+    print(f"[{name}] nq={nq} ng={ng} D={D} repair_iters={it} min_gap={np.diff(ds, axis=1).min():.3e} "
+          f"mAP={mAP:.6f} valid={len(single)}")
+
+
+def gen_eval_centroids(ref, name, nq, ng, D, seed, n_pid):
+    """modelling/bases.py:179-262 validation_create_centroids(respect_camids=False) + metric."""
+    f, it = gapped_features(nq, ng, D, seed, 0.0)
+    rng = np.random.default_rng(seed + 1)
+    pids = np.concatenate([rng.integers(0, n_pid, nq), rng.integers(0, n_pid, ng)]).astype(np.int64)
+    cams = np.concatenate([np.zeros(nq), np.ones(ng)]).astype(np.int64)
+    cfg = make_cfg(ref)
+    fake = types.SimpleNamespace(hparams=ref_import.AttrDict(num_query=nq))
+    fake._calculate_centroids = ref.bases.ModelBase._calculate_centroids
+    emb, labels, camids = ref.bases.ModelBase.validation_create_centroids(
+        fake, torch.from_numpy(f), pids, cams, respect_camids=False)
+    fn = torch.nn.functional.normalize(emb.float(), dim=1, p=2)
+    distmat = ref.reid_metric.get_euclidean(x=fn[:nq], y=fn[nq:])
+    indices = np.argsort(distmat.numpy(), axis=1)
+    cmc, mAP, topk, single = ref.eval_reid.eval_func(
+        indices, labels[:nq], labels[nq:], camids[:nq], camids[nq:], 50, False)
+    np.savez_compressed(
+        os.path.join(OUT, name), feats=f, pids=pids, camids=cams, num_query=np.int64(nq),
+        cent_emb=emb.numpy(), cent_labels=np.asarray(labels, np.int64),
+        cent_camids=np.asarray(camids, np.int64), cmc=np.asarray(cmc, np.float32),
+        mAP=np.float64(mAP), topk=np.asarray(topk, np.float64))
+    print(f"[{name}] centroids={emb.shape[0] - nq} mAP={mAP:.6f}")
+
+
+# ---------------------------------------------------------------------------
+class FeatStub(torch.nn.Module):
+    """Stands in for Baseline: returns preset features so the reference's head arithmetic
+    (train_ctl_model.py:59-179) runs on known inputs and exposes d(loss)/d(features)."""
+
+    def __init__(self, feats):
+        super().__init__()
+        self.feats = torch.nn.Parameter(feats.clone())
+
+    def forward(self, x):
+        return None, self.feats * 1.0
+
+
+def build_ref_model(ref, cfg, num_classes, D):
+    cfg.MODEL.BACKBONE_EMB_SIZE = D
+    model = ref.train_ctl_model.CTLModel(cfg, num_classes=num_classes, num_query=0)
+    return model
+
+
+def gen_heads(ref, name, P, K, D, C, seed, fakes=(), margin=0.5, steps=1):
+    rng = np.random.default_rng(seed)
+    # same-pid features share a base vector; scales chosen so that BOTH hinge branches
+    # (active / inactive) occur in the query triplet and in the centroid rounds
+    sc = float(np.sqrt(128.0 / D))
+    base = (rng.standard_normal((P, D))).astype(np.float32)
+    feats = ((rng.standard_normal((P * K, D)) * (0.3 * sc)).astype(np.float32)
+             + np.repeat(base, K, 0) * np.float32(0.2 * sc))
+    pid_vals = (np.arange(P) * 7) % C
+    labels = np.repeat(pid_vals, K).astype(np.int64)
+    is_real = np.ones(P * K, bool)
+    for j in fakes:
+        is_real[j] = False
+        # the reference pads with a zero IMAGE; its feature is whatever the backbone gives
+        feats[j] = (rng.standard_normal(D) * 0.25 * sc).astype(np.float32)
+    centers0 = rng.standard_normal((C, D)).astype(np.float32)
+    fc0 = (rng.standard_normal((C, D)) * 0.001).astype(np.float32)
+    bn_w0 = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    bn_b0 = np.zeros(D, np.float32)
+
+    cfg = make_cfg(ref)
+    cfg.SOLVER.MARGIN = margin
+    cfg.DATALOADER.NUM_INSTANCE = K
+    model = build_ref_model(ref, cfg, C, D)
+    model.backbone = FeatStub(torch.from_numpy(feats))
+    with torch.no_grad():
+        model.center_loss.centers.copy_(torch.from_numpy(centers0))
+        model.fc_query.weight.copy_(torch.from_numpy(fc0))
+        model.bn.weight.copy_(torch.from_numpy(bn_w0))
+    opts = ref.solver.build_optimizer(model.named_parameters(), model.hparams)
+    model.optimizers = lambda use_pl_optimizer=True: opts
+    model.manual_backward = lambda loss, optimizer=None: loss.backward()
+    model.trainer = types.SimpleNamespace(current_epoch=0)
+    model.train()
+    batch = (torch.zeros(P * K, 3, 8, 4), torch.from_numpy(labels),
+             torch.zeros(P * K, dtype=torch.int64), torch.from_numpy(is_real))
+    rec = {}
+    for s in range(steps):
+        out = model.training_step(batch, s)
+        rec[f"s{s}_loss_total"] = np.float32(out["loss"].item())
+        for n in model.losses_names:
+            rec[f"s{s}_{n}"] = np.float32(model.losses_dict[n][-1])
+        for k, v in out["other"].items():
+            rec[f"s{s}_{k}"] = np.float32(v)
+        if s == 0:
+            rec["s0_grad_features"] = model.backbone.feats.grad.detach().numpy().copy()
+            # NB: centers.grad was rescaled in place by 1/CENTER_LOSS_WEIGHT (train_ctl_model.py:157-158)
+            rec["s0_grad_centers_scaled"] = model.center_loss.centers.grad.detach().numpy().copy()
+            rec["s0_grad_fc"] = model.fc_query.weight.grad.detach().numpy().copy()
+            rec["s0_grad_bn_w"] = model.bn.weight.grad.detach().numpy().copy()
+        rec[f"s{s}_centers_after"] = model.center_loss.centers.detach().numpy().copy()
+        rec[f"s{s}_fc_after"] = model.fc_query.weight.detach().numpy().copy()
+        rec[f"s{s}_bn_w_after"] = model.bn.weight.detach().numpy().copy()
+        rec[f"s{s}_bn_rm_after"] = model.bn.running_mean.numpy().copy()
+        rec[f"s{s}_bn_rv_after"] = model.bn.running_var.numpy().copy()
+        rec[f"s{s}_feats_after"] = model.backbone.feats.detach().numpy().copy()
+    masks, _ = ref.bases.ModelBase.create_masks_train(torch.from_numpy(labels))
+    rec["masks"] = masks.numpy()
+    np.savez_compressed(os.path.join(OUT, name), feats=feats, labels=labels, is_real=is_real,
+                        centers0=centers0, fc0=fc0, bn_w0=bn_w0, bn_b0=bn_b0, P=np.int64(P),
+                        K=np.int64(K), C=np.int64(C), margin=np.float32(margin),
+                        base_lr=np.float64(cfg.SOLVER.BASE_LR), **rec)
+    print(f"[{name}] total={rec['s0_loss_total']:.6f} xent={rec['s0_query_xent']:.6f} "
+          f"trip={rec['s0_query_triplet']:.6f} center={rec['s0_query_center']:.6f} "
+          f"ctl={rec['s0_centroid_triplet']:.6f}")
+
+
+def gen_losses(ref, name, N, D, C, seed):
+    """Stand-alone TripletLoss (margin / soft-margin / mask), CenterLoss, CrossEntropyLabelSmooth."""
+    rng = np.random.default_rng(seed)
+    K = 4
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    labels = np.repeat((np.arange(N // K) * 5) % C, K).astype(np.int64)
+    mask = np.ones(N, bool); mask[[1, 6]] = False
+    rec = dict(x=x, labels=labels, mask=mask)
+    for tag, margin, m in (("m05", 0.5, None), ("soft", None, None), ("m05_mask", 0.5, mask)):
+        xt = torch.from_numpy(x).requires_grad_(True)
+        tl = ref.triplet_loss.TripletLoss(margin, "euclidean")
+        loss, ap, an = tl(xt, torch.from_numpy(labels), mask=None if m is None else torch.from_numpy(m))
+        loss.backward()
+        rec[f"trip_{tag}_loss"] = np.float32(loss.item())
+        rec[f"trip_{tag}_ap"] = ap.detach().numpy(); rec[f"trip_{tag}_an"] = an.detach().numpy()
+        rec[f"trip_{tag}_grad"] = xt.grad.numpy().copy()
+    dist = ref.triplet_loss.euclidean_dist(torch.from_numpy(x), torch.from_numpy(x))
+    ap, an, pi, ni = ref.triplet_loss.hard_example_mining(dist, torch.from_numpy(labels), return_inds=True)
+    rec["dist"] = dist.numpy(); rec["p_inds"] = pi.numpy(); rec["n_inds"] = ni.numpy()
+    # center loss
+    centers = rng.standard_normal((C, D)).astype(np.float32)
+    cl = ref.center_loss.CenterLoss(C, D, use_gpu=False)
+    with torch.no_grad():
+        cl.centers.copy_(torch.from_numpy(centers))
+    xt = torch.from_numpy(x).requires_grad_(True)
+    l = cl(xt, torch.from_numpy(labels)); l.backward()
+    rec.update(centers=centers, center_loss=np.float32(l.item()), center_grad_x=xt.grad.numpy().copy(),
+               center_grad_c=cl.centers.grad.numpy().copy())
+    # label-smoothed xent
+    logits = (rng.standard_normal((N, C)) * 2).astype(np.float32)
+    lt = torch.from_numpy(logits).requires_grad_(True)
+    xe = ref.triplet_loss.CrossEntropyLabelSmooth(C, use_gpu=False)
+    l = xe(lt, torch.from_numpy(labels)); l.backward()
+    rec.update(logits=logits, xent_loss=np.float32(l.item()), xent_grad=lt.grad.numpy().copy())
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(f"[{name}] trip={rec['trip_m05_loss']:.6f} soft={rec['trip_soft_loss']:.6f} "
+          f"center={rec['center_loss']:.4f} xent={rec['xent_loss']:.6f}")
+
+
+# ---------------------------------------------------------------------------
+def gen_backbone(ref, name, arch, B, H, W):
+    from oracle import backbone_oracle as bo
+    sd = bo.make_state_dict(arch, 1, seed=1234)
+    if arch == "resnet50":
+        net = ref.resnet.ResNet(last_stride=1, block=ref.resnet.Bottleneck, layers=[3, 4, 6, 3])
+    else:
+        net = ref.resnet_ibn_a.resnet50_ibn_a(1)
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    assert all(k.startswith("fc.") for k in missing.missing_keys), missing.missing_keys
+    x = bo.synthetic_images(B, H, W, seed=7)
+    coef = torch.from_numpy(np.random.default_rng(99).standard_normal((B, 2048)).astype(np.float32))
+    rec = {}
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+        rec["eval_feat"] = y.mean(dim=(2, 3)).numpy()
+        rec["eval_base_checksum"] = np.float64(y.double().sum().item())
+    net.train()
+    y = net(x)
+    feat = y.mean(dim=(2, 3))
+    rec["train_feat"] = feat.detach().numpy()
+    (feat * coef).sum().backward()
+    rec["bn1_rm"] = net.bn1.running_mean.numpy().copy(); rec["bn1_rv"] = net.bn1.running_var.numpy().copy()
+    last = net.layer4[2].bn3
+    rec["l4_bn3_rm"] = last.running_mean.numpy().copy(); rec["l4_bn3_rv"] = last.running_var.numpy().copy()
+    rec["grad_conv1"] = net.conv1.weight.grad.numpy().copy()
+    rec["grad_l4_conv3_slice"] = net.layer4[2].conv3.weight.grad[:16, :, 0, 0].numpy().copy()
+    rec["grad_l1_conv2_slice"] = net.layer1[0].conv2.weight.grad[:8].numpy().copy()
+    rec["grad_l2_ds_slice"] = net.layer2[0].downsample[0].weight.grad[:8, :, 0, 0].numpy().copy()
+    rec["grad_bn1_w"] = net.bn1.weight.grad.numpy().copy(); rec["grad_bn1_b"] = net.bn1.bias.grad.numpy().copy()
+    rec["grad_l3_bn2_w"] = net.layer3[1].bn2.weight.grad.numpy().copy()
+    if arch != "resnet50":
+        rec["grad_l1_in_w"] = net.layer1[0].bn1.IN.weight.grad.numpy().copy()
+    gsum = 0.0
+    for p in net.parameters():
+        if p.grad is not None:
+            gsum += p.grad.double().abs().sum().item()
+    rec["grad_abs_sum"] = np.float64(gsum)
+    np.savez_compressed(os.path.join(OUT, name), arch=np.array(arch), B=np.int64(B), H=np.int64(H),
+                        W=np.int64(W), **rec)
+    print(f"[{name}] eval_feat mean={rec['eval_feat'].mean():.5f} std={rec['eval_feat'].std():.5f} "
+          f"train_feat std={rec['train_feat'].std():.5f} grad_abs_sum={gsum:.4e}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_import.load()
+    which = sys.argv[1:] or ["eval", "losses", "heads", "backbone"]
+    if "eval" in which:
+        gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
+        gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
+        gen_eval(ref, "eval_tiny_gallery", 8, 40, 32, 13, n_pid=5, n_cam=3, min_gap=1e-4, split_cams=True)
+        gen_eval_centroids(ref, "eval_centroids", 40, 300, 128, 14, n_pid=30)
+    if "losses" in which:
+        gen_losses(ref, "losses_n64_d128", 64, 128, 751, 21)
+        gen_losses(ref, "losses_n32_d2048", 32, 2048, 40, 22)
+    if "heads" in which:
+        gen_heads(ref, "heads_p16k4_d128", 16, 4, 128, 200, 31, steps=2)
+        gen_heads(ref, "heads_p16k4_d128_fake1", 16, 4, 128, 60, 32, fakes=(5,))
+        gen_heads(ref, "heads_p16k4_d128_fake2", 16, 4, 128, 60, 33, fakes=(8, 9, 30))
+        gen_heads(ref, "heads_p8k4_d2048", 8, 4, 2048, 24, 34)
+    if "backbone" in which:
+        gen_backbone(ref, "backbone_r50_2x256x128", "resnet50", 2, 256, 128)
+        gen_backbone(ref, "backbone_r50ibn_2x64x64", "resnet50_ibn_a", 2, 64, 64)
+
+
+if __name__ == "__main__":
+    main()
