@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- hot-path benchmark (contract: see the task statement / DESIGN.md "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|eval]
+
+One "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+  train: one CTLModel.training_step (ResNet50 256x128 bf16, P=16 x K=4 = 64 images, all four
+         losses, backward, Adam + center-SGD) -> metric train_images_per_sec  (BASELINE configs[1])
+  eval : normalise + squared-L2 matrix + rank + CMC/mAP over 2228 x 17661 x 2048 fp32
+         (DukeMTMC-shaped, BASELINE configs[4]) -> metric eval_dist_pairs_per_sec
+Rank 0 prints ONE JSON line.  For N>1 launch with torch.distributed.run (one rank per GPU, RCCL).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_TFLOPS = 157.3        # f32-input MFMA dense peak
+MFMA_BF16_TFLOPS = 2500.0      # bf16 MFMA dense peak
+
+
+def ddp_setup(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
+    return rank, world
+
+
+def barrier_sync(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def time_kernel(fn, iters):
+    """Average device time (ms) of fn() measured with HIP events on the launch stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+# ----------------------------------------------------------------------------- eval workload
+def eval_inputs(nq, ng, D, rank, world):
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    feats = torch.randn((nq + ng, D), generator=gen, device="cuda", dtype=torch.float32)
+    rng = np.random.default_rng(0)
+    pids = rng.integers(0, 702, nq + ng)
+    cams = rng.integers(0, 8, nq + ng)
+    return feats, pids, cams
+
+
+def run_eval(args, rank, world):
+    from centroids_reid_amd import reid_metric as rm
+    nq, ng, D = 2228, 17661, 2048
+    feats, pids, cams = eval_inputs(nq, ng, D, rank, world)
+    # weak scaling: every rank ranks its own nq queries against the (all-gathered) gallery
+    q_pids = torch.as_tensor(pids[:nq], device="cuda"); g_pids = torch.as_tensor(pids[nq:], device="cuda")
+    q_cams = torch.as_tensor(cams[:nq], device="cuda"); g_cams = torch.as_tensor(cams[nq:], device="cuda")
+    gal_shard = feats[nq:].chunk(world)[rank].contiguous() if world > 1 else None
+
+    def step():
+        if world > 1:  # node-level all-gather of (gallery) embeddings before the distance matrix
+            parts = [torch.empty_like(c) for c in feats[nq:].chunk(world)]
+            dist.all_gather(parts, gal_shard)
+            f = torch.cat([feats[:nq]] + parts)
+        else:
+            f = feats
+        fn, sq = rm.l2_normalize(f, return_sqnorm=True)
+        d = rm.get_euclidean(fn[:nq], fn[nq:], sq[:nq].contiguous(), sq[nq:].contiguous())
+        idx = rm.rank_rows(d)
+        return rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50)
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    pairs = float(nq) * ng * world * args.steps
+    mAP = float(out[1].item())
+
+    # ---- per-kernel roofline (rank 0): dominant kernel = distance GEMM (MFMA-bound)
+    res = {}
+    if rank == 0:
+        fn, sq = rm.l2_normalize(feats, return_sqnorm=True)
+        q, g = fn[:nq], fn[nq:]
+        qq, gg = sq[:nq].contiguous(), sq[nq:].contiguous()
+        t_dist = time_kernel(lambda: rm.get_euclidean(q, g, qq, gg), 10)
+        d = rm.get_euclidean(q, g, qq, gg)
+        t_rank = time_kernel(lambda: rm.rank_rows(d), 5)
+        idx = rm.rank_rows(d)
+        t_norm = time_kernel(lambda: rm.l2_normalize(feats, return_sqnorm=True), 10)
+        t_cmc = time_kernel(lambda: rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50), 10)
+        flops = 2.0 * nq * ng * D
+        res["roofline"] = {"kernel": "sqdist_f32_kernel", "bound": "mfma", "achieved": flops / (t_dist * 1e-3) / 1e12,
+                           "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flops / (t_dist * 1e-3) / 1e12 / MFMA_F32_TFLOPS, "traffic": None,
+                           "ms": t_dist}
+        rank_bytes = nq * ng * (4 + 8)
+        res["stages_ms"] = {"l2norm": t_norm, "sqdist": t_dist, "rank_rows": t_rank, "cmc_ap": t_cmc}
+        res["roofline_hbm_stages"] = {
+            "l2norm_GBs": (nq + ng) * D * 8 / (t_norm * 1e-3) / 1e9,
+            "rank_rows_GBs": rank_bytes / (t_rank * 1e-3) / 1e9,
+            "peak_GBs": HBM_PEAK_GBS}
+        res["cpu_baseline"] = cpu_baseline_eval(feats, pids, cams, nq, ng)
+        res["mAP"] = mAP
+    return {
+        "metric": "eval_dist_pairs_per_sec", "value": pairs / dt, "unit": "pairs/s",
+        "ms_per_step": dt / args.steps * 1e3, "dtype": "f32",
+        "config": {"workload": "DukeMTMC-shaped eval 2228x17661x2048: normalise+sqdist+rank+CMC/mAP (BASELINE configs[4])",
+                   "queries_per_rank": nq, "gallery": ng, "D": D,
+                   "parallelism": f"query-shard x{world}, gallery all-gather" if world > 1 else "single"},
+        **res}
+
+
+def cpu_baseline_eval(feats, pids, cams, nq, ng):
+    """The CPU oracle (kind 'port') on a bounded sample of the same workload, all host cores."""
+    from oracle import reid_oracle as ro
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    nqs = min(nq, 512)
+    f = torch.cat([feats[:nqs], feats[nq:]]).cpu()
+    p = np.concatenate([pids[:nqs], pids[nq:]]); c = np.concatenate([cams[:nqs], cams[nq:]])
+    t0 = time.perf_counter()
+    ro.r1_map(f, p, c, nqs)
+    dt = time.perf_counter() - t0
+    return {"value": nqs * ng / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{nqs} of {nq} queries x {ng} gallery, vectorised numpy/torch-CPU restatement "
+                      f"(the reference's own per-query Python loop is ~50x slower, BASELINE.md)", "seconds": dt}
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["train", "eval"], default=None)
+    args = ap.parse_args()
+    rank, world = ddp_setup(args.gpus)
+    workload = args.workload
+    if workload is None:
+        try:
+            from centroids_reid_amd import bench_train  # noqa: F401
+            workload = "train"
+        except ImportError:
+            workload = "eval"
+    if workload == "train":
+        from centroids_reid_amd import bench_train
+        args.steps = args.steps or 30
+        args.warmup = args.warmup if args.warmup is not None else 5
+        out = bench_train.run(args, rank, world, barrier_sync, time_kernel)
+    else:
+        args.steps = args.steps or 5
+        args.warmup = args.warmup if args.warmup is not None else 2
+        out = run_eval(args, rank, world)
+    if rank == 0:
+        line = {"metric": out.pop("metric"), "value": out.pop("value"), "unit": out.pop("unit"),
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": out.pop("dtype"), "data": "synthetic", **out}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

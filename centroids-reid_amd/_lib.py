@@ -1,0 +1,88 @@
+"""ctypes binding of libcreid_hip.so (the C ABI declared in include/creid.h).
+
+The product path has NO CPU fallback: if the shared library is missing this module raises,
+and every op raises if its tensors are not on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcreid_hip.so")
+
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+_lib = None
+
+_p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/creid.h declares
+SIGNATURES = {
+    "creid_abi_version": (C.c_int, []),
+    "creid_l2norm_rows": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _f32, _p]),
+    "creid_row_sqnorm": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
+    "creid_sqdist_matrix": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, C.c_int, _p, _i64, _p]),
+    "creid_rank_rows_workspace_bytes": (_sz, [_i64, _i64]),
+    "creid_rank_rows": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
+    "creid_cmc_ap_ranked": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_eval_reduce": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+}
+
+
+class CreidError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CreidError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        if h.creid_abi_version() != 1:
+            raise CreidError("libcreid_hip.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise CreidError(f"unsupported dtype {t.dtype}") from None
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CreidError("centroids-reid_amd ops need HIP device tensors (no CPU fallback); got a CPU tensor")
+        if t is not None and not t.is_contiguous():
+            raise CreidError("centroids-reid_amd ops need contiguous tensors")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported dtype", -3: "workspace too small", -4: "unsupported shape"}.get(
+            rc, f"hipError_t {rc}")
+        raise CreidError(f"{what} failed: {kind}")

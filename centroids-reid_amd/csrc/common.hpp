@@ -1,0 +1,61 @@
+// Shared device/host helpers for libcreid_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/creid.h"
+
+#define CREID_CHECK_ARG(cond) do { if (!(cond)) return CREID_E_ARG; } while (0)
+#define CREID_LAUNCH_RET() do { hipError_t e_ = hipGetLastError(); return (int)e_; } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+typedef float  f32x4  __attribute__((ext_vector_type(4)));
+typedef float  f32x16 __attribute__((ext_vector_type(16)));
+typedef short  s16x8  __attribute__((ext_vector_type(8)));
+typedef short  s16x4  __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// lanes strictly below this lane
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  const int lane = threadIdx.x & 63;
+  return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// bf16 <-> f32 (round-to-nearest-even), bit-level so they work in any context
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned)b) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}

@@ -1,0 +1,169 @@
+"""Stage D/E host side: the reference's metric surface on top of the HIP kernels.
+
+Mirrors utils/reid_metric.py (get_euclidean :25-33, get_dist_func :62-68, R1_mAP :71-151)
+and utils/eval_reid.py (eval_func :25-92) -- same names, argument meaning and return
+values -- but every step runs on the GPU: rows are normalised, the squared-L2 matrix comes
+from the MFMA distance kernel, ranking is a device radix sort, and CMC/AP are scanned on the
+device; only the final few scalars come back to the host.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+K_LIST = [1, 5, 10, 20, 50]
+
+
+# --------------------------------------------------------------------------- primitives
+def l2_normalize(x: torch.Tensor, out_dtype=torch.float32, eps: float = 1e-12, return_sqnorm=False):
+    L.require_gpu(x)
+    assert x.dtype == torch.float32 and x.dim() == 2
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    sq = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if return_sqnorm else None
+    L.check(L.lib().creid_l2norm_rows(L.ptr(x), L.ptr(y), L.ptr(sq), x.shape[0], x.shape[1],
+                                      L._DT[out_dtype], eps, L.stream()), "creid_l2norm_rows")
+    return (y, sq) if return_sqnorm else y
+
+
+def row_sqnorm(x: torch.Tensor) -> torch.Tensor:
+    L.require_gpu(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    L.check(L.lib().creid_row_sqnorm(L.ptr(x), L.ptr(out), x.shape[0], x.shape[1], L.dtype_code(x), L.stream()),
+            "creid_row_sqnorm")
+    return out
+
+
+def get_euclidean(x: torch.Tensor, y: torch.Tensor, xx=None, yy=None, **kwargs) -> torch.Tensor:
+    """Squared L2 matrix [m, n] fp32 (utils/reid_metric.py:25-33)."""
+    L.require_gpu(x, y)
+    assert x.dtype == y.dtype and x.shape[1] == y.shape[1]
+    xx = row_sqnorm(x) if xx is None else xx
+    yy = row_sqnorm(y) if yy is None else yy
+    m, n, D = x.shape[0], y.shape[0], x.shape[1]
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    L.check(L.lib().creid_sqdist_matrix(L.ptr(x), L.ptr(y), L.ptr(xx), L.ptr(yy), m, n, D, L.dtype_code(x),
+                                        L.ptr(out), n, L.stream()), "creid_sqdist_matrix")
+    return out
+
+
+def get_cosine(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """utils/reid_metric.py:51-59: clamp(|1 - cos|, eps).  With unit rows |x-y|^2 = 2 - 2cos, so the
+    cosine matrix is derived from the same MFMA kernel: cos = 1 - d/2 on re-normalised rows."""
+    xn, xs = l2_normalize(x.float(), eps=eps, return_sqnorm=True)
+    yn, ys = l2_normalize(y.float(), eps=eps, return_sqnorm=True)
+    d = get_euclidean(xn, yn, xs, ys)
+    cos = (xs[:, None] + ys[None, :] - d) * 0.5
+    return torch.abs(1 - cos).clamp(min=eps)
+
+
+def get_dist_func(func_name="euclidean"):
+    if func_name == "cosine":
+        return get_cosine
+    if func_name == "euclidean":
+        return get_euclidean
+    raise KeyError(func_name)
+
+
+def rank_rows(distmat: torch.Tensor) -> torch.Tensor:
+    """np.argsort(distmat, axis=1) (utils/reid_metric.py:129,132) with (distance, index) order."""
+    L.require_gpu(distmat)
+    assert distmat.dtype == torch.float32 and distmat.dim() == 2
+    m, n = distmat.shape
+    out = torch.empty((m, n), dtype=torch.int64, device=distmat.device)
+    nbytes = L.lib().creid_rank_rows_workspace_bytes(m, n)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=distmat.device)
+    L.check(L.lib().creid_rank_rows(L.ptr(distmat), m, n, n, L.ptr(out), L.ptr(ws), nbytes, L.stream()),
+            "creid_rank_rows")
+    return out
+
+
+def _dev_i64(a, device):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.int64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.int64), device=device)
+
+
+def eval_func_device(indices: torch.Tensor, q_pids, g_pids, q_camids, g_camids, max_rank=50):
+    """Device half of eval_func: returns device tensors (cmc f32[max_rank], mAP f64[1], topk f64[5],
+    nvalid i64[1], valid u8[m], ap f64[m], first i32[m])."""
+    L.require_gpu(indices)
+    dev = indices.device
+    m, n = indices.shape
+    if n < max_rank:  # utils/eval_reid.py:33-35
+        max_rank = n
+        print("Note: number of gallery samples is quite small, got {}".format(n))
+    qp, gp, qc, gc = (_dev_i64(a, dev) for a in (q_pids, g_pids, q_camids, g_camids))
+    valid = torch.empty(m, dtype=torch.uint8, device=dev)
+    ap = torch.empty(m, dtype=torch.float64, device=dev)
+    first = torch.empty(m, dtype=torch.int32, device=dev)
+    lib = L.lib()
+    L.check(lib.creid_cmc_ap_ranked(L.ptr(indices), m, n, L.ptr(qp), L.ptr(gp), L.ptr(qc), L.ptr(gc),
+                                    L.ptr(valid), L.ptr(ap), L.ptr(first), L.stream()), "creid_cmc_ap_ranked")
+    cmc = torch.empty(max_rank, dtype=torch.float32, device=dev)
+    mAP = torch.empty(1, dtype=torch.float64, device=dev)
+    topk = torch.empty(5, dtype=torch.float64, device=dev)
+    nvalid = torch.empty(1, dtype=torch.int64, device=dev)
+    L.check(lib.creid_eval_reduce(L.ptr(valid), L.ptr(ap), L.ptr(first), m, max_rank, L.ptr(cmc), L.ptr(mAP),
+                                  L.ptr(topk), L.ptr(nvalid), L.stream()), "creid_eval_reduce")
+    return cmc, mAP, topk, nvalid, valid, ap, first
+
+
+def eval_func(indices, q_pids, g_pids, q_camids, g_camids, max_rank=50, respect_camids=False):
+    """utils/eval_reid.py:25-92: returns (all_cmc float32[max_rank], mAP float, all_topk float64[5],
+    single_performance float64[n_valid, 3] = rows [q_idx, q_pid, AP])."""
+    if respect_camids:
+        raise NotImplementedError("respect_camids=True (camera-set centroids) is a SURVEY §8f 'next' row")
+    if not isinstance(indices, torch.Tensor):
+        raise L.CreidError("eval_func needs a device tensor of ranked indices (no CPU fallback)")
+    cmc, mAP, topk, nvalid, valid, ap, first = eval_func_device(indices, q_pids, g_pids, q_camids, g_camids, max_rank)
+    valid_h = valid.cpu().numpy().astype(bool)
+    vi = np.nonzero(valid_h)[0]
+    qp = np.asarray(q_pids.cpu() if isinstance(q_pids, torch.Tensor) else q_pids)
+    single = np.stack([vi.astype(np.float64), qp[vi].astype(np.float64), ap.cpu().numpy()[vi]], axis=1)
+    return cmc.cpu().numpy(), float(mAP.item()), topk.cpu().numpy(), single
+
+
+class R1_mAP:
+    """utils/reid_metric.py:71-151.  `pl_module` only needs `.hparams` (SOLVER.DISTANCE_FUNC,
+    MODEL.USE_CENTROIDS); trainer/logger lookups of the reference are optional here."""
+
+    def __init__(self, pl_module=None, num_query=0, max_rank=50, feat_norm=True, dist_func="euclidean",
+                 compute_dtype=torch.float32):
+        self.num_query = num_query
+        self.max_rank = max_rank
+        self.feat_norm = feat_norm
+        self.pl_module = pl_module
+        self.compute_dtype = compute_dtype
+        if pl_module is not None and hasattr(pl_module, "hparams"):
+            try:
+                dist_func = pl_module.hparams.SOLVER.DISTANCE_FUNC
+            except (AttributeError, KeyError):
+                pass
+        self.dist_name = dist_func
+        self.dist_func = get_dist_func(dist_func)
+        self.last = {}
+
+    def compute(self, feats, pids, camids, respect_camids=False):
+        if not isinstance(feats, torch.Tensor) or not feats.is_cuda:
+            raise L.CreidError("R1_mAP.compute needs device features (no CPU fallback)")
+        feats = feats.float().contiguous()
+        nq = self.num_query
+        if self.dist_name == "euclidean":
+            if self.feat_norm:
+                print("The test feature is normalized")
+                f, sq = l2_normalize(feats, out_dtype=self.compute_dtype, return_sqnorm=True)
+            else:
+                f = feats if self.compute_dtype == torch.float32 else feats.to(self.compute_dtype)
+                sq = row_sqnorm(f)
+            distmat = get_euclidean(f[:nq], f[nq:], sq[:nq].contiguous(), sq[nq:].contiguous())
+        else:
+            f = l2_normalize(feats) if self.feat_norm else feats
+            distmat = self.dist_func(f[:nq].contiguous(), f[nq:].contiguous())
+        indices = rank_rows(distmat)
+        pids = np.asarray(pids); camids = np.asarray(camids)
+        cmc, mAP, all_topk, single = eval_func(indices, pids[:nq], pids[nq:], camids[:nq], camids[nq:],
+                                               self.max_rank, respect_camids)
+        self.last = dict(distmat=distmat, indices=indices, single_performance=single)
+        return cmc, mAP, all_topk
