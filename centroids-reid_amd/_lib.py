@@ -30,6 +30,18 @@ SIGNATURES = {
     "creid_rank_rows": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "creid_cmc_ap_ranked": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_eval_reduce": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "creid_loo_centroids_fwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "creid_loo_centroids_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
+    "creid_triplet_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_triplet_bwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _f32, _p, _p]),
+    "creid_center_loss_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "creid_center_loss_bwd": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _f32, _p, _p, _p]),
+    "creid_xent_ls": (C.c_int, [_p, _p, _i64, _i64, _f32, _f32, _p, _p, _p, _p]),
+    "creid_bn1d_fwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, C.c_int, _f32, _f32, _p, _p, _p, _p]),
+    "creid_bn1d_bwd": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p]),
+    "creid_sgd_scaled_step": (C.c_int, [_p, _p, _i64, _f32, _f32, _p]),
+    "creid_gemm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _f32, _f32, _i32, _p]),
 }
 
 

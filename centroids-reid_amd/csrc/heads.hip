@@ -1,0 +1,536 @@
+// Stages B/C: leave-one-out per-PID centroids, pairwise-distance + batch-hard mining triplet,
+// center loss, label-smoothed cross-entropy, BNNeck (BatchNorm1d), optimiser steps.
+//
+// Reference arithmetic: train_ctl_model.py:79-104 (centroids), losses/triplet_loss.py:27-173,
+// losses/center_loss.py:26-46, losses/triplet_loss.py:194-205 (xent), modelling/bases.py:83-84
+// (BNNeck), solver/build.py:36-44 + train_ctl_model.py:154-159 (Adam / center SGD).
+// All tensors here are tiny (B = 64..512 rows x 2048): every kernel is latency-bound, so the
+// design goal is few launches, wave-level reductions (no atomics -> deterministic) and
+// features streamed once per workgroup with 16-byte loads.
+#include "common.hpp"
+
+// ======================================================================================
+// B2: leave-one-out centroids.  grid (P, K); centroid[i,p,:] = sum_{s!=i, real} f[p,s,:]/max(cnt,1)
+// if slot i of pid p is real, else 0.
+// ======================================================================================
+__global__ __launch_bounds__(256) void loo_centroids_fwd_kernel(const float* __restrict__ feat,
+                                                                const uint8_t* __restrict__ is_real, int P, int K,
+                                                                int D, float* __restrict__ cent,
+                                                                int32_t* __restrict__ valid) {
+  const int p = blockIdx.x, i = blockIdx.y;
+  const bool qreal = is_real[p * K + i] != 0;
+  int cnt = 0;
+  if (qreal)
+    for (int s = 0; s < K; ++s) cnt += (s != i && is_real[p * K + s]) ? 1 : 0;
+  if (threadIdx.x == 0) valid[i * P + p] = cnt;
+  const float inv_den = (float)max(cnt, 1);
+  float* out = cent + ((int64_t)i * P + p) * D;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    if (qreal)
+      for (int s = 0; s < K; ++s)   // same s-order as the reference's sum(-2)
+        if (s != i && is_real[p * K + s]) acc += feat[((int64_t)p * K + s) * D + d];
+    out[d] = acc / inv_den;
+  }
+}
+
+// dfeat[p,s,:] += sum_{i != s, real(i), real(s)} dcent[i,p,:] / max(cnt_i,1).  grid (P, K=s)
+__global__ __launch_bounds__(256) void loo_centroids_bwd_kernel(const float* __restrict__ dcent,
+                                                                const uint8_t* __restrict__ is_real, int P, int K,
+                                                                int D, float* __restrict__ dfeat) {
+  const int p = blockIdx.x, s = blockIdx.y;
+  if (!is_real[p * K + s]) return;
+  float* out = dfeat + ((int64_t)p * K + s) * D;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    for (int i = 0; i < K; ++i) {
+      if (i == s || !is_real[p * K + i]) continue;
+      int cnt = 0;
+      for (int t = 0; t < K; ++t) cnt += (t != i && is_real[p * K + t]) ? 1 : 0;
+      acc += dcent[((int64_t)i * P + p) * D + d] / (float)max(cnt, 1);
+    }
+    out[d] += acc;
+  }
+}
+
+// ======================================================================================
+// C1-C3: triplet.  One workgroup per anchor: distances to all N rows (wave per row, 16-B
+// loads, wave reduction), then hardest-positive / hardest-negative mining by wave 0.
+// ======================================================================================
+__global__ __launch_bounds__(256) void triplet_mine_kernel(const float* __restrict__ x,
+                                                           const int64_t* __restrict__ labels, int N, int D,
+                                                           float* __restrict__ dist_ap, float* __restrict__ dist_an,
+                                                           int32_t* __restrict__ p_idx, int32_t* __restrict__ n_idx,
+                                                           float* __restrict__ dist_row_out /* nullable [N,N] */) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [D] anchor row, then [N] distances
+  float* xa = sm;
+  float* drow = sm + D;
+  const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xap = x + (int64_t)a * D;
+  float saa = 0.f;
+  for (int d = tid; d < D; d += 256) { float v = xap[d]; xa[d] = v; }
+  __syncthreads();
+  for (int d = lane; d < D; d += 64) saa = fmaf(xa[d], xa[d], saa);
+  saa = wave_sum(saa);
+  for (int j = wave; j < N; j += 4) {
+    const float* xj = x + (int64_t)j * D;
+    float dot = 0.f, sjj = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      float4 v = *reinterpret_cast<const float4*>(xj + d);
+      float4 u = *reinterpret_cast<const float4*>(xa + d);
+      dot = fmaf(u.x, v.x, dot); dot = fmaf(u.y, v.y, dot); dot = fmaf(u.z, v.z, dot); dot = fmaf(u.w, v.w, dot);
+      sjj = fmaf(v.x, v.x, sjj); sjj = fmaf(v.y, v.y, sjj); sjj = fmaf(v.z, v.z, sjj); sjj = fmaf(v.w, v.w, sjj);
+    }
+    dot = wave_sum(dot); sjj = wave_sum(sjj);
+    if (lane == 0) {
+      const float sq = fmaf(-2.0f, dot, saa + sjj);         // xx + yy - 2 x.y   (triplet_loss.py:35-39)
+      drow[j] = sqrtf(fmaxf(sq, 1e-12f));                    // clamp(min=1e-12).sqrt() (:40)
+    }
+  }
+  __syncthreads();
+  if (dist_row_out)
+    for (int j = tid; j < N; j += 256) dist_row_out[(int64_t)a * N + j] = drow[j];
+  if (wave == 0) {
+    const int64_t la = labels[a];
+    float bp = -INFINITY, bn = INFINITY;
+    int ip = 0x7fffffff, in_ = 0x7fffffff;
+    for (int j = lane; j < N; j += 64) {
+      const float d = drow[j];
+      if (labels[j] == la) { if (d > bp) { bp = d; ip = j; } }
+      else { if (d < bn) { bn = d; in_ = j; } }
+    }
+    // wave arg-max / arg-min with first-index tie-break (torch.max/min return the first)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float obp = __shfl_xor(bp, o, 64); int oip = __shfl_xor(ip, o, 64);
+      if (obp > bp || (obp == bp && oip < ip)) { bp = obp; ip = oip; }
+      float obn = __shfl_xor(bn, o, 64); int oin = __shfl_xor(in_, o, 64);
+      if (obn < bn || (obn == bn && oin < in_)) { bn = obn; in_ = oin; }
+    }
+    if (lane == 0) { dist_ap[a] = bp; dist_an[a] = bn; p_idx[a] = ip; n_idx[a] = in_; }
+  }
+}
+
+// loss over (masked) anchors; coef[a] = d loss / d dist_ap[a] ( = - d loss / d dist_an[a]).
+// margin >= 0: MarginRankingLoss mean(max(0, ap - an + margin)); margin < 0: SoftMarginLoss.
+// out[0]=loss, out[1]=mean ap, out[2]=mean an, out[3]=#anchors.
+__global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restrict__ dist_ap,
+                                                           const float* __restrict__ dist_an,
+                                                           const uint8_t* __restrict__ mask, int N, float margin,
+                                                           float* __restrict__ out, float* __restrict__ coef) {
+  __shared__ float s[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float cnt = 0.f;
+  for (int a = tid; a < N; a += 256) cnt += (!mask || mask[a]) ? 1.f : 0.f;
+  cnt = wave_sum(cnt);
+  if (lane == 0) s[wave][3] = cnt;
+  __syncthreads();
+  const float nm = s[0][3] + s[1][3] + s[2][3] + s[3][3];
+  __syncthreads();
+  float l = 0.f, sap = 0.f, san = 0.f;
+  for (int a = tid; a < N; a += 256) {
+    const bool on = !mask || mask[a];
+    float c = 0.f;
+    if (on) {
+      const float ap = dist_ap[a], an = dist_an[a];
+      sap += ap; san += an;
+      if (margin >= 0.f) {
+        const float v = ap - an + margin;           // -(an - ap) + margin
+        if (v > 0.f) { l += v; c = 1.f / nm; }
+      } else {
+        const float z = ap - an;                    // log(1 + exp(-(an - ap)))
+        l += (z > 0.f) ? z + log1pf(expf(-z)) : log1pf(expf(z));
+        c = (1.f / (1.f + expf(-z))) / nm;
+      }
+    }
+    if (coef) coef[a] = c;
+  }
+  l = wave_sum(l); sap = wave_sum(sap); san = wave_sum(san);
+  if (lane == 0) { s[wave][0] = l; s[wave][1] = sap; s[wave][2] = san; }
+  __syncthreads();
+  if (tid == 0) {
+    out[0] = ((s[0][0] + s[1][0]) + (s[2][0] + s[3][0])) / nm;
+    out[1] = ((s[0][1] + s[1][1]) + (s[2][1] + s[3][1])) / nm;
+    out[2] = ((s[0][2] + s[1][2]) + (s[2][2] + s[3][2])) / nm;
+    out[3] = nm;
+  }
+}
+
+// dx[r,:] += g * sum_a coef[a] * ( [a==r]((xa-xp)/dap - (xa-xn)/dan) + [p_a==r](xp-xa)/dap - [n_a==r](xn-xa)/dan )
+// (gradient of sqrt(clamp(.)) is zero where the clamp was active: dist <= 1e-6).  One workgroup per row.
+__global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ x, int N, int D,
+                                                          const float* __restrict__ dist_ap,
+                                                          const float* __restrict__ dist_an,
+                                                          const int32_t* __restrict__ p_idx,
+                                                          const int32_t* __restrict__ n_idx,
+                                                          const float* __restrict__ coef,
+                                                          const float* __restrict__ gscale_ptr, float gscale,
+                                                          float* __restrict__ dx) {
+  const int r = blockIdx.x;
+  const float g = gscale * (gscale_ptr ? *gscale_ptr : 1.f);
+  const float* xr = x + (int64_t)r * D;
+  float* out = dx + (int64_t)r * D;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float xv = xr[d];
+    float acc = 0.f;
+    for (int a = 0; a < N; ++a) {
+      const float c = coef[a];
+      if (c == 0.f) continue;
+      const int p = p_idx[a], n = n_idx[a];
+      if (a != r && p != r && n != r) continue;
+      const float dap = dist_ap[a], dan = dist_an[a];
+      const float ip = dap > 1e-6f ? c / dap : 0.f, in_ = dan > 1e-6f ? c / dan : 0.f;
+      if (a == r) acc += ip * (xv - x[(int64_t)p * D + d]) - in_ * (xv - x[(int64_t)n * D + d]);
+      if (p == r) acc += ip * (xv - x[(int64_t)a * D + d]);
+      if (n == r) acc -= in_ * (xv - x[(int64_t)a * D + d]);
+    }
+    out[d] += g * acc;
+  }
+}
+
+// ======================================================================================
+// C4: center loss.  row_loss[b] = clamp(|x_b|^2 + |c_y|^2 - 2 x_b.c_y, 1e-12, 1e12) (expanded form
+// like the reference); loss = (sum_b row_loss + B*(C-1)*1e-12)/B.
+// ======================================================================================
+__global__ __launch_bounds__(256) void center_row_kernel(const float* __restrict__ x,
+                                                         const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ centers, int D,
+                                                         float* __restrict__ row_loss) {
+  __shared__ float s[4][3];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xb = x + (int64_t)b * D;
+  const float* c = centers + labels[b] * D;
+  float xx = 0.f, cc = 0.f, xc = 0.f;
+  for (int d = tid; d < D; d += 256) {
+    const float u = xb[d], v = c[d];
+    xx = fmaf(u, u, xx); cc = fmaf(v, v, cc); xc = fmaf(u, v, xc);
+  }
+  xx = wave_sum(xx); cc = wave_sum(cc); xc = wave_sum(xc);
+  if (lane == 0) { s[wave][0] = xx; s[wave][1] = cc; s[wave][2] = xc; }
+  __syncthreads();
+  if (tid == 0) {
+    xx = (s[0][0] + s[1][0]) + (s[2][0] + s[3][0]);
+    cc = (s[0][1] + s[1][1]) + (s[2][1] + s[3][1]);
+    xc = (s[0][2] + s[1][2]) + (s[2][2] + s[3][2]);
+    const float dv = fmaf(-2.0f, xc, xx + cc);
+    row_loss[b] = dv;   // unclamped; the reduce kernel clamps (and bwd needs the clamp state)
+  }
+}
+
+__global__ __launch_bounds__(256) void center_reduce_kernel(const float* __restrict__ row_loss, int B, int C,
+                                                            float* __restrict__ out) {
+  __shared__ float s[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float l = 0.f;
+  for (int b = tid; b < B; b += 256) l += fminf(fmaxf(row_loss[b], 1e-12f), 1e12f);
+  l = wave_sum(l);
+  if (lane == 0) s[wave] = l;
+  __syncthreads();
+  if (tid == 0) out[0] = (((s[0] + s[1]) + (s[2] + s[3])) + (float)B * (float)(C - 1) * 1e-12f) / (float)B;
+}
+
+// dx[b] += g*(2/B)(x_b - c_y) ; dcenters[y] (+)= g*(2/B) sum_{b:y_b=y}(c_y - x_b), written once per
+// distinct label by the workgroup of its FIRST occurrence (deterministic, no atomics).
+__global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict__ x,
+                                                         const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ centers,
+                                                         const float* __restrict__ row_loss, int B, int D,
+                                                         const float* __restrict__ gscale_ptr, float gscale,
+                                                         float* __restrict__ dx, float* __restrict__ dcenters) {
+  const int b = blockIdx.x;
+  const int64_t y = labels[b];
+  const float g = gscale * (gscale_ptr ? *gscale_ptr : 1.f) * 2.0f / (float)B;
+  const bool on = row_loss[b] >= 1e-12f && row_loss[b] <= 1e12f;
+  const float* c = centers + y * D;
+  const float* xb = x + (int64_t)b * D;
+  bool first = true;
+  for (int t = 0; t < b; ++t) first = first && (labels[t] != y);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float cv = c[d];
+    if (dx) dx[(int64_t)b * D + d] += on ? g * (xb[d] - cv) : 0.f;
+    if (first && dcenters) {
+      float acc = 0.f;
+      for (int t = b; t < B; ++t)
+        if (labels[t] == y && row_loss[t] >= 1e-12f && row_loss[t] <= 1e12f) acc += cv - x[(int64_t)t * D + d];
+      dcenters[y * D + d] += g * acc;
+    }
+  }
+}
+
+// ======================================================================================
+// C6: label-smoothed cross entropy, fwd + bwd in one pass.  One workgroup per row.
+// row_loss[b] = -sum_c t_c logp_c, t = (1-eps) onehot + eps/C ; dlogits = (softmax - t) * g / B.
+// ======================================================================================
+__global__ __launch_bounds__(256) void xent_ls_kernel(const float* __restrict__ logits,
+                                                      const int64_t* __restrict__ targets, int B, int C, float eps,
+                                                      float* __restrict__ row_loss, float* __restrict__ dlogits,
+                                                      float gscale) {
+  __shared__ float s[4];
+  __shared__ float bc;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* z = logits + (int64_t)b * C;
+  float mx = -INFINITY;
+  for (int c = tid; c < C; c += 256) mx = fmaxf(mx, z[c]);
+  mx = wave_max(mx);
+  if (lane == 0) s[wave] = mx;
+  __syncthreads();
+  if (tid == 0) bc = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+  __syncthreads();
+  mx = bc;
+  float se = 0.f, sz = 0.f;
+  for (int c = tid; c < C; c += 256) { se += expf(z[c] - mx); sz += z[c] - mx; }
+  se = wave_sum(se);
+  __syncthreads();
+  if (lane == 0) s[wave] = se;
+  __syncthreads();
+  if (tid == 0) bc = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  se = bc;
+  const float lse = logf(se);
+  sz = wave_sum(sz);
+  __syncthreads();
+  if (lane == 0) s[wave] = sz;
+  __syncthreads();
+  const int64_t y = targets[b];
+  if (tid == 0) {
+    const float sum_logp = ((s[0] + s[1]) + (s[2] + s[3])) - (float)C * lse;   // sum_c (z_c - mx - lse)
+    const float logp_y = z[y] - mx - lse;
+    row_loss[b] = -((1.f - eps) * logp_y + (eps / (float)C) * sum_logp);
+  }
+  if (dlogits) {
+    const float gb = gscale / (float)B;
+    for (int c = tid; c < C; c += 256) {
+      const float p = expf(z[c] - mx) / se;
+      const float t = (c == y ? (1.f - eps) : 0.f) + eps / (float)C;
+      dlogits[(int64_t)b * C + c] = (p - t) * gb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ v, int n, float scale,
+                                                        float* __restrict__ out) {
+  __shared__ float s[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float l = 0.f;
+  for (int i = tid; i < n; i += 256) l += v[i];
+  l = wave_sum(l);
+  if (lane == 0) s[wave] = l;
+  __syncthreads();
+  if (tid == 0) out[0] = ((s[0] + s[1]) + (s[2] + s[3])) * scale;
+}
+
+// ======================================================================================
+// A4: BNNeck = BatchNorm1d over [B, D] (B small): thread per feature, loop over rows (coalesced).
+// ======================================================================================
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int B, int D,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       int training, float momentum, float eps,
+                                                       float* __restrict__ y, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_invstd) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float mean, invstd;
+  if (training) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += x[(int64_t)b * D + d];
+    mean = s / (float)B;
+    float m2 = 0.f;
+    for (int b = 0; b < B; ++b) { const float t = x[(int64_t)b * D + d] - mean; m2 = fmaf(t, t, m2); }
+    const float var = m2 / (float)B;
+    invstd = 1.0f / sqrtf(var + eps);
+    if (rmean) rmean[d] = (1.f - momentum) * rmean[d] + momentum * mean;
+    if (rvar) rvar[d] = (1.f - momentum) * rvar[d] + momentum * (B > 1 ? m2 / (float)(B - 1) : var);
+    if (save_mean) { save_mean[d] = mean; save_invstd[d] = invstd; }
+  } else {
+    mean = rmean[d];
+    invstd = 1.0f / sqrtf(rvar[d] + eps);
+  }
+  const float g = w ? w[d] : 1.f, be = bias ? bias[d] : 0.f;
+  for (int b = 0; b < B; ++b) y[(int64_t)b * D + d] = (x[(int64_t)b * D + d] - mean) * invstd * g + be;
+}
+
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       int B, int D, const float* __restrict__ w,
+                                                       const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_invstd,
+                                                       float* __restrict__ dx, float* __restrict__ dw,
+                                                       float* __restrict__ dbias) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float mean = save_mean[d], invstd = save_invstd[d], g = w ? w[d] : 1.f;
+  float sdy = 0.f, sdyx = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float t = dy[(int64_t)b * D + d];
+    sdy += t; sdyx = fmaf(t, (x[(int64_t)b * D + d] - mean) * invstd, sdyx);
+  }
+  if (dw) dw[d] += sdyx;
+  if (dbias) dbias[d] += sdy;
+  const float k = g * invstd / (float)B;
+  for (int b = 0; b < B; ++b) {
+    const float xh = (x[(int64_t)b * D + d] - mean) * invstd;
+    dx[(int64_t)b * D + d] += k * ((float)B * dy[(int64_t)b * D + d] - sdy - xh * sdyx);
+  }
+}
+
+// ======================================================================================
+// C5 + optimiser: Adam with L2 weight decay (torch.optim.Adam) over a flat fp32 buffer; center SGD.
+// ======================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                                                   float gscale) {
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  for (int64_t i = i0; i < n; i += stride) {
+    if (i + 3 < n) {
+      float4 pv = *reinterpret_cast<float4*>(p + i), gv = *reinterpret_cast<const float4*>(g + i);
+      float4 mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+      float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gg = fmaf(wd, pp[k], gp[k] * gscale);
+        mp[k] = b1 * mp[k] + (1.f - b1) * gg;
+        vp[k] = b2 * vp[k] + (1.f - b2) * gg * gg;
+        const float denom = sqrtf(vp[k]) / bc2s + eps;
+        pp[k] = pp[k] - (lr / bc1) * (mp[k] / denom);
+      }
+      *reinterpret_cast<float4*>(p + i) = pv; *reinterpret_cast<float4*>(m + i) = mv;
+      *reinterpret_cast<float4*>(v + i) = vv;
+    } else {
+      for (int64_t j = i; j < n; ++j) {
+        const float gg = fmaf(wd, p[j], g[j] * gscale);
+        m[j] = b1 * m[j] + (1.f - b1) * gg;
+        v[j] = b2 * v[j] + (1.f - b2) * gg * gg;
+        p[j] = p[j] - (lr / bc1) * (m[j] / (sqrtf(v[j]) / bc2s + eps));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_scaled_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n,
+                                                         float lr, float gmul) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float gv = g[i] * gmul;     // train_ctl_model.py:157-158 rescale (kept in .grad like the reference)
+    g[i] = gv;
+    p[i] = p[i] - lr * gv;
+  }
+}
+
+// ======================================================================================
+extern "C" {
+
+int creid_loo_centroids_fwd(const float* feat, const uint8_t* is_real, int64_t P, int64_t K, int64_t D,
+                            float* centroids, int32_t* valid, void* stream) {
+  CREID_CHECK_ARG(feat && is_real && centroids && valid && P > 0 && K > 0 && D > 0);
+  hipLaunchKernelGGL(loo_centroids_fwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream), feat,
+                     is_real, (int)P, (int)K, (int)D, centroids, valid);
+  CREID_LAUNCH_RET();
+}
+
+int creid_loo_centroids_bwd(const float* dcentroids, const uint8_t* is_real, int64_t P, int64_t K, int64_t D,
+                            float* dfeat_accum, void* stream) {
+  CREID_CHECK_ARG(dcentroids && is_real && dfeat_accum && P > 0 && K > 0 && D > 0);
+  hipLaunchKernelGGL(loo_centroids_bwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream),
+                     dcentroids, is_real, (int)P, (int)K, (int)D, dfeat_accum);
+  CREID_LAUNCH_RET();
+}
+
+int creid_triplet_fwd(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t N, int64_t D,
+                      float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx, float* coef,
+                      float* out4, float* dist_mat, void* stream) {
+  CREID_CHECK_ARG(x && labels && dist_ap && dist_an && p_idx && n_idx && out4 && N > 0 && D > 0);
+  if (D % 4 != 0) return CREID_E_SHAPE;
+  const size_t smem = (size_t)(D + N) * sizeof(float);
+  if (smem > 64 * 1024) return CREID_E_SHAPE;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(triplet_mine_kernel, dim3((unsigned)N), dim3(256), smem, s, x, labels, (int)N, (int)D, dist_ap,
+                     dist_an, p_idx, n_idx, dist_mat);
+  hipLaunchKernelGGL(triplet_loss_kernel, dim3(1), dim3(256), 0, s, dist_ap, dist_an, anchor_mask, (int)N, margin,
+                     out4, coef);
+  CREID_LAUNCH_RET();
+}
+
+int creid_triplet_bwd(const float* x, int64_t N, int64_t D, const float* dist_ap, const float* dist_an,
+                      const int32_t* p_idx, const int32_t* n_idx, const float* coef, const float* gscale_dev,
+                      float gscale, float* dx_accum, void* stream) {
+  CREID_CHECK_ARG(x && dist_ap && dist_an && p_idx && n_idx && coef && dx_accum && N > 0 && D > 0);
+  hipLaunchKernelGGL(triplet_bwd_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), x, (int)N, (int)D,
+                     dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum);
+  CREID_LAUNCH_RET();
+}
+
+int creid_center_loss_fwd(const float* x, const int64_t* labels, const float* centers, int64_t B, int64_t C,
+                          int64_t D, float* row_sq, float* loss, void* stream) {
+  CREID_CHECK_ARG(x && labels && centers && row_sq && loss && B > 0 && C > 0 && D > 0);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(center_row_kernel, dim3((unsigned)B), dim3(256), 0, s, x, labels, centers, (int)D, row_sq);
+  hipLaunchKernelGGL(center_reduce_kernel, dim3(1), dim3(256), 0, s, row_sq, (int)B, (int)C, loss);
+  CREID_LAUNCH_RET();
+}
+
+int creid_center_loss_bwd(const float* x, const int64_t* labels, const float* centers, const float* row_sq,
+                          int64_t B, int64_t D, const float* gscale_dev, float gscale, float* dx_accum,
+                          float* dcenters_accum, void* stream) {
+  CREID_CHECK_ARG(x && labels && centers && row_sq && B > 0 && D > 0 && (dx_accum || dcenters_accum));
+  hipLaunchKernelGGL(center_bwd_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), x, labels, centers,
+                     row_sq, (int)B, (int)D, gscale_dev, gscale, dx_accum, dcenters_accum);
+  CREID_LAUNCH_RET();
+}
+
+int creid_xent_ls(const float* logits, const int64_t* targets, int64_t B, int64_t C, float eps, float gscale,
+                  float* row_loss, float* loss, float* dlogits, void* stream) {
+  CREID_CHECK_ARG(logits && targets && row_loss && loss && B > 0 && C > 0);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(xent_ls_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, targets, (int)B, (int)C, eps,
+                     row_loss, dlogits, gscale);
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, s, row_loss, (int)B, 1.0f / (float)B, loss);
+  CREID_LAUNCH_RET();
+}
+
+int creid_bn1d_fwd(const float* x, int64_t B, int64_t D, const float* weight, const float* bias, float* running_mean,
+                   float* running_var, int training, float momentum, float eps, float* y, float* save_mean,
+                   float* save_invstd, void* stream) {
+  CREID_CHECK_ARG(x && y && B > 0 && D > 0);
+  CREID_CHECK_ARG(training || (running_mean && running_var));
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, as_stream(stream), x, (int)B,
+                     (int)D, weight, bias, running_mean, running_var, training, momentum, eps, y, save_mean,
+                     save_invstd);
+  CREID_LAUNCH_RET();
+}
+
+int creid_bn1d_bwd(const float* x, const float* dy, int64_t B, int64_t D, const float* weight, const float* save_mean,
+                   const float* save_invstd, float* dx_accum, float* dweight_accum, float* dbias_accum,
+                   void* stream) {
+  CREID_CHECK_ARG(x && dy && save_mean && save_invstd && dx_accum && B > 0 && D > 0);
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, as_stream(stream), x, dy,
+                     (int)B, (int)D, weight, save_mean, save_invstd, dx_accum, dweight_accum, dbias_accum);
+  CREID_LAUNCH_RET();
+}
+
+int creid_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+  CREID_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1);
+  if (n == 0) return 0;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  CREID_LAUNCH_RET();
+}
+
+int creid_sgd_scaled_step(float* p, float* g, int64_t n, float lr, float grad_mul, void* stream) {
+  CREID_CHECK_ARG(p && g && n >= 0);
+  if (n == 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sgd_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, n, lr,
+                     grad_mul);
+  CREID_LAUNCH_RET();
+}
+
+}  // extern "C"

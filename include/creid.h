@@ -80,6 +80,78 @@ int creid_eval_reduce(const uint8_t* valid, const double* ap, const int32_t* fir
                       int32_t max_rank, float* out_cmc, double* out_map, double* out_topk,
                       int64_t* out_nvalid, void* stream);
 
+
+/* ------------------------------------------------------------------ stage B: centroids */
+
+/* train_ctl_model.py:79-104: leave-one-out per-PID centroids of a PID-contiguous [P,K] batch.
+ * centroids[i,p,:] = sum_{s != i, is_real[p,s]} feat[p*K+s,:] / max(cnt,1) if is_real[p,i] else 0;
+ * valid[i,p] = cnt.  feat fp32 [P*K, D]; is_real uint8 [P*K]; centroids fp32 [K,P,D]; valid int32 [K,P]. */
+int creid_loo_centroids_fwd(const float* feat, const uint8_t* is_real, int64_t P, int64_t K, int64_t D,
+                            float* centroids, int32_t* valid, void* stream);
+/* adjoint of the above: dfeat_accum[P*K, D] += J^T dcentroids. */
+int creid_loo_centroids_bwd(const float* dcentroids, const uint8_t* is_real, int64_t P, int64_t K,
+                            int64_t D, float* dfeat_accum, void* stream);
+
+/* ------------------------------------------------------------------ stage C: losses */
+
+/* losses/triplet_loss.py:27-41 (euclidean_dist), :68-119 (hard_example_mining), :139-173
+ * (TripletLoss.__call__).  x fp32 [N,D]; labels int64 [N]; anchor_mask uint8 [N] or NULL (applied
+ * AFTER mining, :148-151).  margin >= 0 -> MarginRankingLoss(margin); margin < 0 -> SoftMarginLoss.
+ * Outputs: dist_ap/dist_an fp32 [N] (all anchors, unmasked), p_idx/n_idx int32 [N] (first index wins
+ * ties), coef fp32 [N] (= dloss/d dist_ap, nullable), out4 = {loss, mean ap, mean an, #anchors} over
+ * masked anchors, dist_mat fp32 [N,N] (nullable; the sqrt(clamp(.,1e-12)) matrix). */
+int creid_triplet_fwd(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t N,
+                      int64_t D, float margin, float* dist_ap, float* dist_an, int32_t* p_idx,
+                      int32_t* n_idx, float* coef, float* out4, float* dist_mat, void* stream);
+/* dx_accum[N,D] += gscale * (*gscale_dev if non-NULL) * dloss/dx (zero through an active clamp). */
+int creid_triplet_bwd(const float* x, int64_t N, int64_t D, const float* dist_ap, const float* dist_an,
+                      const int32_t* p_idx, const int32_t* n_idx, const float* coef,
+                      const float* gscale_dev, float gscale, float* dx_accum, void* stream);
+
+/* losses/center_loss.py:26-46.  row_sq[b] = |x_b|^2 + |c_y|^2 - 2 x_b.c_y (unclamped, saved for bwd);
+ * loss[0] = (sum_b clamp(row_sq[b],1e-12,1e12) + B*(C-1)*1e-12) / B. */
+int creid_center_loss_fwd(const float* x, const int64_t* labels, const float* centers, int64_t B,
+                          int64_t C, int64_t D, float* row_sq, float* loss, void* stream);
+/* dx_accum[B,D] += g*(2/B)(x_b - c_y); dcenters_accum[C,D] += g*(2/B) sum_{b:y_b=y}(c_y - x_b) on the
+ * touched rows only (either output may be NULL). */
+int creid_center_loss_bwd(const float* x, const int64_t* labels, const float* centers,
+                          const float* row_sq, int64_t B, int64_t D, const float* gscale_dev,
+                          float gscale, float* dx_accum, float* dcenters_accum, void* stream);
+
+/* losses/triplet_loss.py:194-205 CrossEntropyLabelSmooth: loss[0] = mean_b(-sum_c t_c logp_c),
+ * t = (1-eps)*onehot + eps/C; dlogits (nullable) = gscale * (softmax - t) / B. */
+int creid_xent_ls(const float* logits, const int64_t* targets, int64_t B, int64_t C, float eps,
+                  float gscale, float* row_loss, float* loss, float* dlogits, void* stream);
+
+/* modelling/bases.py:83-84 BNNeck = nn.BatchNorm1d(D) on [B,D] (momentum 0.1, eps 1e-5):
+ * training: batch stats (biased var for y, unbiased into running_var); eval: running stats. */
+int creid_bn1d_fwd(const float* x, int64_t B, int64_t D, const float* weight, const float* bias,
+                   float* running_mean, float* running_var, int training, float momentum, float eps,
+                   float* y, float* save_mean, float* save_invstd, void* stream);
+int creid_bn1d_bwd(const float* x, const float* dy, int64_t B, int64_t D, const float* weight,
+                   const float* save_mean, const float* save_invstd, float* dx_accum,
+                   float* dweight_accum, float* dbias_accum, void* stream);
+
+/* ------------------------------------------------------------------ optimiser steps */
+
+/* solver/build.py:36-39 torch.optim.Adam (L2 weight decay added to the gradient, bias correction,
+ * eps outside the sqrt) over a flat fp32 buffer; the gradient is multiplied by grad_scale first. */
+int creid_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                    void* stream);
+/* train_ctl_model.py:157-159 + solver/build.py:44: g *= grad_mul (in place); p -= lr * g. */
+int creid_sgd_scaled_step(float* p, float* g, int64_t n, float lr, float grad_mul, void* stream);
+
+/* ------------------------------------------------------------------ small fp32 GEMM */
+
+/* Classifier of the BNNeck head (modelling/bases.py:86-87 fc_query = Linear(D -> C, bias=False);
+ * used at train_ctl_model.py:75): C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
+ * + beta * C[m*ldc + n], exact-f32 MFMA.  split_k > 1 combines K-slices with fp32 atomics
+ * (non-deterministic order); split_k == 1 is deterministic. */
+int creid_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                   float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, float beta,
+                   int32_t split_k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

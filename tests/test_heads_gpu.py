@@ -1,0 +1,124 @@
+"""GPU parity: stages B/C (centroids, triplet, center, xent, BNNeck, classifier, optimiser steps)
+through the C ABI against golden vectors from the reference and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available()
+    from centroids_reid_amd import losses, ops
+    return losses, ops
+
+
+@pytest.mark.parametrize("name", ["losses_n64_d128", "losses_n32_d2048"])
+def test_losses_golden(golden, mods, name):
+    losses, ops = mods
+    g = golden(name)
+    x = torch.from_numpy(g["x"]).cuda(); labels = torch.from_numpy(g["labels"]).cuda()
+    dm, dap, dan, pi, ni = ops.pairwise_dist_mine(x, labels)
+    off = ~np.eye(len(g["x"]), dtype=bool)
+    np.testing.assert_allclose(dm.cpu().numpy()[off], g["dist"][off], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(pi.cpu().numpy(), g["p_inds"])
+    np.testing.assert_array_equal(ni.cpu().numpy(), g["n_inds"])
+    for tag, margin, m in (("m05", 0.5, None), ("soft", None, None), ("m05_mask", 0.5, g["mask"])):
+        xt = x.clone().requires_grad_(True)
+        mask = None if m is None else torch.from_numpy(m).cuda()
+        loss, ap, an = losses.TripletLoss(margin)(xt, labels, mask=mask)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"trip_{tag}_loss"])) < 1e-5
+        np.testing.assert_allclose(ap.cpu().numpy(), g[f"trip_{tag}_ap"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(an.cpu().numpy(), g[f"trip_{tag}_an"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), g[f"trip_{tag}_grad"], rtol=1e-4, atol=1e-6)
+    C, D = g["centers"].shape
+    cl = losses.CenterLoss(C, D).cuda()
+    with torch.no_grad():
+        cl.centers.copy_(torch.from_numpy(g["centers"]))
+    xt = x.clone().requires_grad_(True)
+    l = cl(xt, labels); l.backward()
+    assert abs(l.item() - float(g["center_loss"])) < 1e-5 * abs(float(g["center_loss"]))
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), g["center_grad_x"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(cl.centers.grad.cpu().numpy(), g["center_grad_c"], rtol=1e-4, atol=1e-6)
+    lt = torch.from_numpy(g["logits"]).cuda().requires_grad_(True)
+    l = losses.CrossEntropyLabelSmooth(lt.shape[1])(lt, labels); l.backward()
+    assert abs(l.item() - float(g["xent_loss"])) < 1e-5
+    np.testing.assert_allclose(lt.grad.cpu().numpy(), g["xent_grad"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("P,K,D,fakes", [(16, 4, 128, ()), (16, 4, 2048, (5,)), (8, 4, 64, (8, 9, 30)), (4, 2, 32, (1,)),
+                                          (6, 3, 36, (0, 1, 2))])
+def test_loo_centroids_vs_oracle(mods, P, K, D, fakes):
+    from oracle import reid_oracle as ro
+    _, ops = mods
+    rng = np.random.default_rng(P * K + D)
+    f = torch.from_numpy(rng.standard_normal((P * K, D)).astype(np.float32))
+    ir = torch.ones(P * K, dtype=torch.bool)
+    for j in fakes:
+        ir[j] = False
+    ft = f.clone().requires_grad_(True)
+    co, vo = ro.loo_centroids(ft, ir, P, K)
+    w = torch.from_numpy(rng.standard_normal(tuple(co.shape)).astype(np.float32))
+    (co * w).sum().backward()
+    fg = f.cuda().requires_grad_(True)
+    cg, vg = ops.LooCentroids.apply(fg, ir.cuda(), P, K)
+    (cg * w.cuda()).sum().backward()
+    np.testing.assert_array_equal(cg.detach().cpu().numpy(), co.detach().numpy())   # same s-order -> bit-exact
+    np.testing.assert_array_equal(vg.cpu().numpy(), vo.numpy())
+    np.testing.assert_allclose(fg.grad.cpu().numpy(), ft.grad.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_bnneck_and_classifier_vs_oracle(mods):
+    losses, ops = mods
+    rng = np.random.default_rng(2)
+    B, D, C = 61, 2048, 751
+    x = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32) * 2 + 0.5)
+    w = torch.from_numpy((1 + 0.1 * rng.standard_normal(D)).astype(np.float32))
+    fc = torch.from_numpy((rng.standard_normal((C, D)) * 0.01).astype(np.float32))
+    coef = torch.from_numpy(rng.standard_normal((B, C)).astype(np.float32))
+    # oracle
+    xt, wt, fct = x.clone().requires_grad_(True), w.clone().requires_grad_(True), fc.clone().requires_grad_(True)
+    rm, rv = torch.zeros(D), torch.ones(D)
+    y = torch.nn.functional.batch_norm(xt, rm, rv, wt, torch.zeros(D), True, 0.1, 1e-5)
+    (y @ fct.t() * coef).sum().backward()
+    # HIP
+    bn = losses.BatchNorm1d(D).cuda(); lin = losses.Linear(D, C).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(w); lin.weight.copy_(fc)
+    xg = x.cuda().requires_grad_(True)
+    yg = bn(xg)
+    lg = lin(yg)
+    (lg * coef.cuda()).sum().backward()
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), y.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lg.detach().cpu().numpy(), (y @ fct.t()).detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), rv.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), fct.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xt.grad.numpy(), rtol=1e-3, atol=1e-5)
+    # eval mode
+    bn.eval()
+    ye = bn(x.cuda())
+    yo = torch.nn.functional.batch_norm(x, rm, rv, w, torch.zeros(D), False, 0.1, 1e-5)
+    np.testing.assert_allclose(ye.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_optimizer_steps_vs_oracle(mods):
+    from oracle import reid_oracle as ro
+    from centroids_reid_amd import _lib as L
+    rng = np.random.default_rng(4)
+    n = 100003
+    p = torch.from_numpy(rng.standard_normal(n).astype(np.float32)); g = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+    m = torch.zeros(n); v = torch.zeros(n)
+    pg, gg, mg, vg = p.cuda(), g.cuda(), m.cuda(), v.cuda()
+    for step in (1, 2, 3):
+        p, m, v = ro.adam_step(p, g, m, v, step, 3.5e-5)
+        L.check(L.lib().creid_adam_step(L.ptr(pg), L.ptr(gg), L.ptr(mg), L.ptr(vg), n, 3.5e-5, 0.9, 0.999, 1e-8, 5e-4,
+                                        step, 1.0, L.stream()), "adam")
+    np.testing.assert_allclose(pg.cpu().numpy(), p.numpy(), rtol=1e-5, atol=1e-7)
+    c = torch.from_numpy(rng.standard_normal(5000).astype(np.float32)); gc = torch.from_numpy(rng.standard_normal(5000).astype(np.float32) * 1e-4)
+    cg, gcg = c.cuda(), gc.cuda()
+    L.check(L.lib().creid_sgd_scaled_step(L.ptr(cg), L.ptr(gcg), 5000, 0.5, 1.0 / 5e-4, L.stream()), "sgd")
+    np.testing.assert_allclose(cg.cpu().numpy(), ro.center_sgd_step(c, gc).numpy(), rtol=1e-6, atol=1e-7)
