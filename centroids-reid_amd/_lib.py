@@ -39,10 +39,39 @@ SIGNATURES = {
     "creid_xent_ls": (C.c_int, [_p, _p, _i64, _i64, _f32, _f32, _p, _p, _p, _p]),
     "creid_bn1d_fwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, C.c_int, _f32, _f32, _p, _p, _p, _p]),
     "creid_bn1d_bwd": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_gather_mean_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "creid_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p]),
     "creid_sgd_scaled_step": (C.c_int, [_p, _p, _i64, _f32, _f32, _p]),
+    "creid_conv2d_bn_partial_rows": (_i64, [_p]),
+    "creid_conv2d_fwd_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p]),
+    "creid_conv2d_dgrad_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p]),
+    "creid_conv2d_wgrad_workspace_bytes": (_sz, [_p, C.c_int]),
+    "creid_conv2d_wgrad_nhwc": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _sz, C.c_int, _p]),
+    "creid_stem_conv_fwd": (C.c_int, [_i64, _i64, _i64, _p, _p, _p, _p, C.c_int, _p]),
+    "creid_stem_conv_wgrad_workspace_bytes": (_sz, [_i64, _i64, _i64, C.c_int]),
+    "creid_stem_conv_wgrad": (C.c_int, [_i64, _i64, _i64, _p, _p, _p, C.c_int, _p, _sz, C.c_int, _p]),
+    "creid_image_to_nhwc4_pad": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
+    "creid_weight_prep": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),
+    "creid_stem_weight_prep": (C.c_int, [_p, C.c_int, _p, _p]),
+    "creid_bn2d_finalize": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, C.c_int, _f32, _f32, _p, _p, _p]),
+    "creid_col_stats_rows": (_i64, [_i64]),
+    "creid_col_stats": (C.c_int, [_p, _i64, _i64, C.c_int, _p, _p]),
+    "creid_bn2d_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _i64, _i64, C.c_int, _p, _p]),
+    "creid_bn2d_bwd_rows": (_i64, [_i64]),
+    "creid_bn2d_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_maxpool3x3s2_fwd": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),
+    "creid_maxpool3x3s2_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, C.c_int, _p, _p]),
+    "creid_gap_fwd": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
+    "creid_gap_bwd": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
+    "creid_nhwc_to_nchw_f32": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
     "creid_gemm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _f32, _f32, _i32, _p]),
 }
+
+
+class ConvDesc(C.Structure):
+    """creid_conv_desc of include/creid.h."""
+    _fields_ = [("batch", _i64), ("in_h", _i64), ("in_w", _i64), ("in_c", _i64), ("out_h", _i64), ("out_w", _i64),
+                ("out_c", _i64), ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32)]
 
 
 class CreidError(RuntimeError):

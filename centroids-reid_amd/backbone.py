@@ -1,0 +1,356 @@
+"""Stage A host side: ResNet50 / ResNet50-IBN-a on the HIP layer kernels.
+
+`ResNet` / `ResNet_IBN` mirror the module tree of modelling/backbones/resnet.py:90-133 and
+resnet_ibn_a.py:77-141 as pure PARAMETER HOLDERS (same attribute names -> same state_dict keys:
+conv1.weight, bn1.running_mean, layer1.0.downsample.0.weight, ...; master weights stay fp32 OIHW
+like the reference's checkpoints).  The arithmetic is done by `BackboneEngine`, an explicit
+forward/backward schedule over NHWC activations that calls the C ABI (implicit-GEMM convs on the
+MFMA pipe with BN statistics fused into the epilogue, fused BN+residual+ReLU, transposing-LDS
+wgrad); torch only provides memory, the stream and the autograd hook at the module boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+
+LAYERS = (3, 4, 6, 3)
+PLANES = (64, 128, 256, 512)
+
+
+# ----------------------------------------------------------------------------- holders
+class Conv2d(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding = cin, cout, k, stride, padding
+        w = torch.empty(cout, cin, k, k)
+        w.normal_(0, math.sqrt(2.0 / (k * k * cout)))           # resnet.py:156-160 random_init
+        self.weight = nn.Parameter(w)
+
+
+class BatchNorm2d(nn.Module):
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3, stride, 1)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, planes * 4, 1)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet(nn.Module):
+    """Parameter tree of modelling/backbones/resnet.py:90-120 (Bottleneck, layers [3,4,6,3])."""
+    arch = "resnet50"
+    stem_relu = False            # resnet.py:97,125 -- the stem ReLU is commented out upstream
+
+    def __init__(self, last_stride=2, block=Bottleneck, layers=LAYERS):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = Conv2d(3, 64, 7, 2, 3)
+        self.bn1 = BatchNorm2d(64)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=last_stride)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(Conv2d(self.inplanes, planes * block.expansion, 1, stride, 0),
+                                       BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def load_param(self, model_path):
+        """resnet.py:135-154: strip 'backbone.base.' / 'base.' prefixes, skip fc/bottleneck/classifier."""
+        param_dict = torch.load(model_path, map_location="cpu")
+        if "state_dict" in param_dict:
+            param_dict = param_dict["state_dict"]
+        own = self.state_dict()
+        for i in param_dict:
+            if "backbone" in i:
+                name = i[14:]
+            elif "base" in i:
+                name = i[5:]
+            else:
+                name = i
+            if any(t in i for t in ("fc", "bottleneck", "classifier", "transformer")):
+                continue
+            own[name].copy_(param_dict[i])
+
+
+# ----------------------------------------------------------------------------- engine
+def _desc(B, H, W, cin, cout, k, stride, pad):
+    oh = (H + 2 * pad - k) // stride + 1
+    ow = (W + 2 * pad - k) // stride + 1
+    return L.ConvDesc(B, H, W, cin, oh, ow, cout, k, k, stride, pad), oh, ow
+
+
+class _ConvUnit:
+    """conv + BN bookkeeping for one (holder conv, holder bn) pair."""
+    __slots__ = ("conv", "bn", "w_krsc", "w_crsk", "k", "stride", "pad", "cin", "cout")
+
+    def __init__(self, conv, bn):
+        self.conv, self.bn = conv, bn
+        self.k, self.stride, self.pad = conv.kernel_size, conv.stride, conv.padding
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.w_krsc = self.w_crsk = None
+
+
+class BackboneEngine:
+    """Explicit forward / backward schedule for one backbone instance."""
+
+    def __init__(self, net: ResNet, dtype=torch.bfloat16):
+        self.net = net
+        self.dtype = dtype
+        self.dt = L._DT[dtype]
+        self.units = []
+        self.stem = _ConvUnit(net.conv1, net.bn1)
+        self.blocks = []
+        for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+            for blk in layer:
+                u = dict(c1=_ConvUnit(blk.conv1, blk.bn1), c2=_ConvUnit(blk.conv2, blk.bn2),
+                         c3=_ConvUnit(blk.conv3, blk.bn3),
+                         ds=_ConvUnit(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None)
+                self.blocks.append(u)
+        self.weights_dirty = True
+        self._ws = None
+        self.saved = None
+
+    # ---- helpers
+    @property
+    def device(self):
+        return self.net.conv1.weight.device
+
+    def _empty(self, *shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def all_units(self):
+        yield self.stem
+        for b in self.blocks:
+            for k in ("c1", "c2", "c3", "ds"):
+                if b[k] is not None:
+                    yield b[k]
+
+    def prep_weights(self):
+        """fp32 OIHW master weights -> compute-dtype [O][r][s][I] and [I][r][s][O] copies."""
+        lib, st = L.lib(), L.stream()
+        for u in self.all_units():
+            w = u.conv.weight
+            if u is self.stem:
+                if u.w_krsc is None:
+                    u.w_krsc = self._empty(64, 8, 32)
+                L.check(lib.creid_stem_weight_prep(L.ptr(w), self.dt, L.ptr(u.w_krsc), st), "stem_weight_prep")
+                continue
+            if u.w_krsc is None:
+                u.w_krsc = self._empty(u.cout, u.k, u.k, u.cin)
+                u.w_crsk = self._empty(u.cin, u.k, u.k, u.cout)
+            L.check(lib.creid_weight_prep(L.ptr(w), u.cout, u.cin, u.k, u.k, self.dt, L.ptr(u.w_krsc),
+                                          L.ptr(u.w_crsk), st), "weight_prep")
+        self.weights_dirty = False
+
+    # ---- layer steps
+    def _conv_bn(self, u, a_in, B, H, W, training, relu, residual=None):
+        """conv -> BN(batch or running stats) -> (+residual) -> (ReLU).  Returns (x_raw, a_out, mean, invstd, oh, ow)."""
+        lib, st = L.lib(), L.stream()
+        d, oh, ow = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
+        M = B * oh * ow
+        x = self._empty(M, u.cout)
+        rows = lib.creid_conv2d_bn_partial_rows(C.byref(d)) if training else 0
+        part = self._empty(rows * 2, u.cout, dtype=torch.float32) if training else None
+        L.check(lib.creid_conv2d_fwd_nhwc(C.byref(d), L.ptr(a_in), L.ptr(u.w_krsc), L.ptr(x), L.ptr(part), self.dt, st),
+                "conv2d_fwd")
+        return (x,) + self._bn_tail(u, x, part, rows, M, training, relu, residual) + (oh, ow)
+
+    def _bn_tail(self, u, x, part, rows, M, training, relu, residual):
+        lib, st = L.lib(), L.stream()
+        bn = u.bn
+        mean = self._empty(u.cout, dtype=torch.float32)
+        invstd = self._empty(u.cout, dtype=torch.float32)
+        L.check(lib.creid_bn2d_finalize(L.ptr(part), rows, u.cout, M, L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                        1 if training else 0, bn.momentum, bn.eps, L.ptr(mean), L.ptr(invstd), st),
+                "bn2d_finalize")
+        if training:
+            bn.num_batches_tracked += 1
+        a = self._empty(M, u.cout)
+        L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(mean), L.ptr(invstd), L.ptr(bn.weight), L.ptr(bn.bias),
+                                     L.ptr(residual), 1 if relu else 0, M, u.cout, self.dt, L.ptr(a), st), "bn2d_apply")
+        return a, mean, invstd
+
+    # ---- forward
+    def forward(self, x_nchw: torch.Tensor, training: bool, want_base_out: bool = False):
+        L.require_gpu(x_nchw)
+        assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3
+        if self.weights_dirty:
+            self.prep_weights()
+        lib, st = L.lib(), L.stream()
+        B, _, H, W = x_nchw.shape
+        sv = {"B": B, "H": H, "W": W, "training": training}
+        # stem
+        xpad = self._empty(B, H + 8, W + 6, 4)
+        L.check(lib.creid_image_to_nhwc4_pad(L.ptr(x_nchw), B, H, W, self.dt, L.ptr(xpad), st), "image_pad")
+        H1, W1 = H // 2, W // 2
+        M0 = B * H1 * W1
+        x0 = self._empty(M0, 64)
+        rows = (M0 + 127) // 128 if training else 0
+        part = self._empty(rows * 2, 64, dtype=torch.float32) if training else None
+        L.check(lib.creid_stem_conv_fwd(B, H, W, L.ptr(xpad), L.ptr(self.stem.w_krsc), L.ptr(x0), L.ptr(part), self.dt, st),
+                "stem_conv_fwd")
+        y0, mean0, invstd0 = self._bn_tail(self.stem, x0, part, rows, M0, training, self.net.stem_relu, None)
+        H2, W2 = H1 // 2, W1 // 2
+        p0 = self._empty(B * H2 * W2, 64)
+        idx0 = self._empty(B * H2 * W2, 64, dtype=torch.uint8)
+        L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, self.dt, L.ptr(p0), L.ptr(idx0), st), "maxpool_fwd")
+        sv["stem"] = (xpad, x0, y0, mean0, invstd0, idx0)
+        a, h, w = p0, H2, W2
+        sv["blocks"] = []
+        for b in self.blocks:
+            a_in, hin, win = a, h, w
+            x1, a1, m1, i1, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, training, True)
+            x2, a2, m2, i2, h2, w2 = self._conv_bn(b["c2"], a1, B, h1, w1, training, True)
+            if b["ds"] is not None:
+                xd, r, md, idd, _, _ = self._conv_bn(b["ds"], a_in, B, hin, win, training, False)
+            else:
+                xd, r, md, idd = None, a_in, None, None
+            x3, a3, m3, i3, h3, w3 = self._conv_bn(b["c3"], a2, B, h2, w2, training, True, residual=r)
+            if training:
+                sv["blocks"].append(dict(a_in=a_in, hin=hin, win=win, x1=x1, a1=a1, m1=m1, i1=i1, h1=h1, w1=w1,
+                                         x2=x2, a2=a2, m2=m2, i2=i2, h2=h2, w2=w2, xd=xd, md=md, idd=idd,
+                                         x3=x3, a3=a3, m3=m3, i3=i3))
+            a, h, w = a3, h3, w3
+        feat = self._empty(B, 2048, dtype=torch.float32)
+        L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), st), "gap_fwd")
+        sv["final"] = (h, w)
+        self.saved = sv if training else None
+        base_out = None
+        if want_base_out:
+            base_out = self._empty(B, 2048, h, w, dtype=torch.float32)
+            L.check(lib.creid_nhwc_to_nchw_f32(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(base_out), st), "nhwc_to_nchw")
+        return base_out, feat
+
+    # ---- backward
+    def _grad_of(self, p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        return p.grad
+
+    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False):
+        lib, st = L.lib(), L.stream()
+        rows = lib.creid_bn2d_bwd_rows(M)
+        part = self._empty(rows * 2, u.cout, dtype=torch.float32)
+        sums = self._empty(2, u.cout, dtype=torch.float32)
+        dx = self._empty(M, u.cout)
+        gm = self._empty(M, u.cout) if want_gm else None
+        bn = u.bn
+        dgam = self._grad_of(bn.weight) if bn.weight.requires_grad else None
+        dbet = self._grad_of(bn.bias) if bn.bias.requires_grad else None
+        L.check(lib.creid_bn2d_bwd(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(bn.weight), M, u.cout,
+                                   self.dt, L.ptr(part), L.ptr(sums), L.ptr(dgam), L.ptr(dbet), L.ptr(dx), L.ptr(gm), st),
+                "bn2d_bwd")
+        return dx, gm
+
+    def _wgrad(self, u, a_in, dy, B, H, W):
+        lib, st = L.lib(), L.stream()
+        if not u.conv.weight.requires_grad:
+            return
+        d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
+        nbytes = lib.creid_conv2d_wgrad_workspace_bytes(C.byref(d), self.dt)
+        ws = self._workspace(nbytes)
+        L.check(lib.creid_conv2d_wgrad_nhwc(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(self._grad_of(u.conv.weight)), 1,
+                                            L.ptr(ws), nbytes, self.dt, st), "conv2d_wgrad")
+
+    def _dgrad(self, u, dy, B, H, W, add_src=None):
+        lib, st = L.lib(), L.stream()
+        d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
+        dx = self._empty(B * H * W, u.cin)
+        L.check(lib.creid_conv2d_dgrad_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src), self.dt, st),
+                "conv2d_dgrad")
+        return dx
+
+    def backward(self, dfeat: torch.Tensor):
+        """Accumulates parameter gradients into `.grad` (fp32, reference layouts)."""
+        sv = self.saved
+        assert sv is not None and sv["training"], "backward() needs a training-mode forward first"
+        lib, st = L.lib(), L.stream()
+        B = sv["B"]
+        h, w = sv["final"]
+        dfeat = dfeat.contiguous().float()
+        g = self._empty(B * h * w, 2048)
+        L.check(lib.creid_gap_bwd(L.ptr(dfeat), B, h * w, 2048, self.dt, L.ptr(g), st), "gap_bwd")
+        for b, s in zip(reversed(self.blocks), reversed(sv["blocks"])):
+            M3 = B * s["h2"] * s["w2"]
+            dx3, gm = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, want_gm=True)
+            self._wgrad(b["c3"], s["a2"], dx3, B, s["h2"], s["w2"])
+            da2 = self._dgrad(b["c3"], dx3, B, s["h2"], s["w2"])
+            dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3)
+            self._wgrad(b["c2"], s["a1"], dx2, B, s["h1"], s["w1"])
+            da1 = self._dgrad(b["c2"], dx2, B, s["h1"], s["w1"])
+            M1 = B * s["h1"] * s["w1"]
+            dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1)
+            self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"])
+            if b["ds"] is not None:
+                dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3)
+                self._wgrad(b["ds"], s["a_in"], dxd, B, s["hin"], s["win"])
+                tmp = self._dgrad(b["ds"], dxd, B, s["hin"], s["win"])
+                g = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp)
+            else:
+                g = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm)
+        # stem
+        xpad, x0, y0, mean0, invstd0, idx0 = sv["stem"]
+        H, W = sv["H"], sv["W"]
+        H1, W1 = H // 2, W // 2
+        dy0 = self._empty(B * H1 * W1, 64)
+        L.check(lib.creid_maxpool3x3s2_bwd(L.ptr(g), L.ptr(idx0), B, H1, W1, 64, self.dt, L.ptr(dy0), st), "maxpool_bwd")
+        dx0, _ = self._bn_bwd(self.stem, x0, dy0, y0 if self.net.stem_relu else None, mean0, invstd0, B * H1 * W1)
+        if self.stem.conv.weight.requires_grad:
+            nbytes = lib.creid_stem_conv_wgrad_workspace_bytes(B, H, W, self.dt)
+            ws = self._workspace(nbytes)
+            L.check(lib.creid_stem_conv_wgrad(B, H, W, L.ptr(xpad), L.ptr(dx0), L.ptr(self._grad_of(self.stem.conv.weight)),
+                                              1, L.ptr(ws), nbytes, self.dt, st), "stem_conv_wgrad")
+        self.saved = None
+
+
+class _BackboneFn(torch.autograd.Function):
+    """Autograd boundary: the engine's backward writes parameter .grad directly."""
+
+    @staticmethod
+    def forward(ctx, x, trigger, engine, want_base_out):
+        ctx.engine = engine
+        base_out, feat = engine.forward(x, True, want_base_out)
+        if base_out is None:
+            base_out = feat.new_empty(0)
+        ctx.mark_non_differentiable(base_out)
+        return base_out, feat
+
+    @staticmethod
+    def backward(ctx, _g_base, g_feat):
+        ctx.engine.backward(g_feat)
+        return None, None, None, None

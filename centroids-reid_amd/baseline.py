@@ -1,0 +1,64 @@
+"""modelling/baseline.py:44-107 Baseline on the HIP backbone engine.
+
+`Baseline(cfg).forward(x) -> (base_out, global_feat)`; `self.base` holds the backbone parameters
+under the reference's names (state_dict keys `base.conv1.weight`, ...).  `compute_dtype` selects the
+activation / MFMA input type: torch.bfloat16 (throughput mode; the reference's AMP analogue when
+cfg.USE_MIXED_PRECISION) or torch.float32 (parity mode, exact-f32 MFMA)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import backbone as bb
+
+
+class Baseline(nn.Module):
+    in_planes = 2048
+
+    def __init__(self, cfg, compute_dtype=None):
+        super().__init__()
+        last_stride = cfg.MODEL.LAST_STRIDE
+        model_name = cfg.MODEL.NAME
+        self.use_mixed_precision = cfg.USE_MIXED_PRECISION
+        if model_name == "resnet50":
+            self.base = bb.ResNet(last_stride=last_stride)
+        elif model_name == "resnet50_ibn_a":
+            self.base = bb.resnet50_ibn_a(last_stride)
+        else:
+            raise NotImplementedError(f"MODEL.NAME={model_name!r}: only resnet50 / resnet50_ibn_a are on the accelerated path")
+        self.model_name = model_name
+        if cfg.MODEL.PRETRAINED and not cfg.MODEL.RESUME_TRAINING and not cfg.TEST.ONLY_TEST:
+            self.base.load_param(cfg.MODEL.PRETRAIN_PATH)      # modelling/baseline.py:84-87
+            print("Loading pretrained ImageNet model......")
+        self.compute_dtype = compute_dtype or (torch.bfloat16 if cfg.USE_MIXED_PRECISION else torch.float32)
+        self.return_base_out = False      # base_out (NCHW fp32 copy) is materialised only on request
+        self._engine = None
+
+    @property
+    def engine(self):
+        if self._engine is None or self._engine.dtype != self.compute_dtype:
+            self._engine = bb.BackboneEngine(self.base, self.compute_dtype)
+        return self._engine
+
+    def forward(self, x):
+        eng = self.engine
+        x = x.contiguous().float()
+        if self.training and torch.is_grad_enabled():
+            base_out, feat = bb._BackboneFn.apply(x, self.base.conv1.weight, eng, self.return_base_out)
+            if base_out.numel() == 0:
+                base_out = None
+        else:
+            base_out, feat = eng.forward(x, self.training, self.return_base_out)
+        return base_out, feat
+
+    def load_param(self, trained_path, load_specific=None):
+        param_dict = torch.load(trained_path, map_location="cpu")
+        for i in param_dict:
+            if load_specific is not None:
+                if load_specific in i:
+                    self.state_dict()[i].copy_(param_dict[i])
+            else:
+                if "classifier" in i:
+                    continue
+                self.state_dict()[i].copy_(param_dict[i])
+        self.engine.weights_dirty = True

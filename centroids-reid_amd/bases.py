@@ -1,0 +1,226 @@
+"""modelling/bases.py:52-393 ModelBase -- the LightningModule surface of the reference, kept as the
+drop-in boundary (same constructor, attribute names, hook names and return values) with every
+arithmetic step routed to the HIP kernels.  pytorch-lightning is optional: when it is importable the
+class derives from pl.LightningModule, otherwise from nn.Module with a minimal trainer stand-in
+(`self.trainer.current_epoch`, `optimizers()`, `manual_backward()`), which is all the hot path uses.
+"""
+from __future__ import annotations
+
+import copy
+from collections import defaultdict
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from .baseline import Baseline
+from .config import CfgNode
+from .losses import BatchNorm1d, CenterLoss, CrossEntropyLabelSmooth, Linear, TripletLoss
+from .reid_metric import R1_mAP
+from .solver import build_optimizer, build_scheduler
+
+try:  # optional
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    pl = None
+    _Base = nn.Module
+
+
+class AttributeDict(CfgNode):
+    pass
+
+
+def _to_attr(d):
+    if isinstance(d, dict):
+        out = AttributeDict()
+        for k, v in d.items():
+            out[k] = _to_attr(v)
+        return out
+    return d
+
+
+class ModelBase(_Base):
+    def __init__(self, cfg=None, test_dataloader=None, compute_dtype=None, **kwargs):
+        super().__init__()
+        if cfg is None:
+            hparams = {**kwargs}
+        elif isinstance(cfg, dict):
+            hparams = {**cfg, **kwargs}
+            if cfg["TEST"]["ONLY_TEST"]:
+                hparams = {**kwargs, **cfg}            # modelling/bases.py:59-62
+        else:
+            raise TypeError("cfg must be a dict-like config tree")
+        hp = _to_attr(hparams)
+        if pl is not None:
+            self.save_hyperparameters(hp)
+        else:
+            self.hparams = hp
+        if test_dataloader is not None:
+            self.test_dataloader = test_dataloader
+
+        self.backbone = Baseline(self.hparams, compute_dtype=compute_dtype)
+        self.contrastive_loss = TripletLoss(self.hparams.SOLVER.MARGIN, self.hparams.SOLVER.DISTANCE_FUNC)
+        d_model = self.hparams.MODEL.BACKBONE_EMB_SIZE
+        self.xent = CrossEntropyLabelSmooth(num_classes=self.hparams.num_classes)
+        self.center_loss = CenterLoss(num_classes=self.hparams.num_classes, feat_dim=d_model)
+        self.center_loss_weight = self.hparams.SOLVER.CENTER_LOSS_WEIGHT
+        self.bn = BatchNorm1d(d_model)
+        self.bn.bias.requires_grad_(False)               # modelling/bases.py:84
+        self.fc_query = Linear(d_model, self.hparams.num_classes, bias=False)
+        self.losses_names = ["query_xent", "query_triplet", "query_center"]
+        self.losses_dict = {n: [] for n in self.losses_names}
+        if pl is None:
+            self.trainer = SimpleNamespace(current_epoch=0, global_rank=0, local_rank=0, logger=None,
+                                           train_dataloader=None)
+            self._optimizers = None
+
+    # ------------------------------------------------------------------ optimiser plumbing
+    @staticmethod
+    def _calculate_centroids(vecs, dim=1):
+        length = vecs.shape[dim]
+        return torch.sum(vecs, dim) / length
+
+    def configure_optimizers(self):
+        optimizers_list = build_optimizer(self.named_parameters(), self.hparams)
+        self.lr_scheduler = build_scheduler(optimizers_list[0], self.hparams)
+        if pl is None:
+            self._optimizers = optimizers_list
+        return optimizers_list, self.lr_scheduler
+
+    if pl is None:
+        def optimizers(self, use_pl_optimizer=True):
+            if self._optimizers is None:
+                self.configure_optimizers()
+            return self._optimizers
+
+        def manual_backward(self, loss, optimizer=None):
+            loss.backward()
+
+        @property
+        def current_epoch(self):
+            return self.trainer.current_epoch
+
+    def training_step(self, batch, batch_idx, opt_idx=None):
+        raise NotImplementedError("A used model should have its own training_step method implemented")
+
+    def training_epoch_end(self, outputs):
+        """modelling/bases.py:140-167 (logging; the barrier is the trainer's business)."""
+        sampler = getattr(getattr(self.trainer, "train_dataloader", None), "sampler", None)
+        if sampler is not None and hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(self.current_epoch + 1)
+        lr = self.lr_scheduler.get_last_lr()[0]
+        loss = torch.stack([x.pop("loss").detach().float() for x in outputs]).mean().cpu()
+        log_data = {"epoch_train_loss": float(loss), "lr": lr}
+        for k_out, k_in in (("epoch_dist_ap", "step_dist_ap"), ("epoch_dist_an", "step_dist_an"),
+                            ("l2_mean_centroid", "l2_mean_centroid")):
+            log_data[k_out] = float(np.mean([float(x["other"].pop(k_in)) for x in outputs]))
+        if hasattr(self, "losses_dict"):
+            for name, vals in self.losses_dict.items():
+                log_data[name] = float(np.mean([float(v) for v in vals])) if vals else float("nan")
+                self.losses_dict[name] = []
+        logger = getattr(self.trainer, "logger", None)
+        if logger is not None:
+            logger.log_metrics(log_data, step=self.trainer.current_epoch)
+        return log_data
+
+    # ------------------------------------------------------------------ validation
+    def validation_step(self, batch, batch_idx):
+        """modelling/bases.py:169-177: eval-mode backbone + BNNeck embedding."""
+        self.backbone.eval()
+        self.bn.eval()
+        x, class_labels, camid, idx = batch
+        with torch.no_grad():
+            _, emb = self.backbone(x)
+            emb = self.bn(emb)
+        return {"emb": emb, "labels": class_labels, "camid": camid, "idx": idx}
+
+    def validation_create_centroids(self, embeddings, labels, camids, respect_camids=False):
+        """modelling/bases.py:179-262 (respect_camids=False): gallery -> per-PID mean (device kernel);
+        returns (embeddings [nq + n_centroids, D], labels, camids) with the reference's dummy camids
+        (including its nq-longer-than-needed camid vector, bases.py:255-260)."""
+        if respect_camids:
+            raise NotImplementedError("camera-set centroids (KEEP_CAMID_CENTROIDS) are a SURVEY §8f 'next' row")
+        num_query = self.hparams.num_query
+        labels = np.asarray(labels)
+        emb = embeddings.float().contiguous()
+        L.require_gpu(emb)
+        lq, lg = labels[:num_query], labels[num_query:]
+        uniq, inverse = np.unique(lg, return_inverse=True)
+        order = np.argsort(inverse, kind="stable")            # gallery rows grouped by PID, original order kept
+        counts = np.bincount(inverse, minlength=len(uniq))
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        dev = emb.device
+        order_t = torch.as_tensor(order.astype(np.int64) + num_query, device=dev)
+        off_t = torch.as_tensor(offsets, device=dev)
+        cents = torch.empty((len(uniq), emb.shape[1]), dtype=torch.float32, device=dev)
+        L.check(L.lib().creid_gather_mean_rows(L.ptr(emb), L.ptr(order_t), L.ptr(off_t), len(uniq), emb.shape[1],
+                                               L.ptr(cents), L.stream()), "creid_gather_mean_rows")
+        out = torch.cat((emb[:num_query], cents), dim=0)
+        out_labels = np.hstack((lq, uniq))
+        out_camids = np.hstack((np.zeros_like(lq), np.ones_like(out_labels)))
+        return out, out_labels, out_camids
+
+    def get_val_metrics(self, embeddings, labels, camids):
+        """modelling/bases.py:264-297."""
+        self.r1_map_func = R1_mAP(pl_module=self, num_query=self.hparams.num_query,
+                                  feat_norm=self.hparams.TEST.FEAT_NORM)
+        respect_camids = bool(self.hparams.MODEL.KEEP_CAMID_CENTROIDS and self.hparams.MODEL.USE_CENTROIDS)
+        if respect_camids:
+            raise NotImplementedError("camera-set centroids (KEEP_CAMID_CENTROIDS) are a SURVEY §8f 'next' row")
+        cmc, mAP, all_topk = self.r1_map_func.compute(feats=embeddings.float(), pids=labels, camids=camids,
+                                                      respect_camids=respect_camids)
+        topks = {}
+        for top_k, kk in zip(all_topk, [1, 5, 10, 20, 50]):
+            print("top-k, Rank-{:<3}:{:.1%}".format(kk, top_k))
+            topks[f"Top-{kk}"] = top_k
+        print(f"mAP: {mAP}")
+        log_data = {"mAP": mAP, **topks}
+        logger = getattr(self.trainer, "logger", None)
+        if logger is not None:
+            logger.log_metrics(log_data, step=self.trainer.current_epoch)
+        self.last_val_metrics = log_data
+        return log_data
+
+    def validation_epoch_end(self, outputs):
+        """modelling/bases.py:299-318 -- embeddings stay on the device (the reference moves them to CPU)."""
+        embeddings = torch.cat([x.pop("emb") for x in outputs]).detach()
+        labels = torch.cat([x.pop("labels") for x in outputs]).detach().cpu().numpy()
+        camids = torch.cat([x.pop("camid") for x in outputs]).cpu().detach().numpy()
+        del outputs
+        if self.hparams.MODEL.USE_CENTROIDS:
+            print("Evaluation is done using centroids")
+            embeddings, labels, camids = self.validation_create_centroids(embeddings, labels, camids,
+                                                                          respect_camids=False)
+        return self.get_val_metrics(embeddings, labels, camids)
+
+    @staticmethod
+    def create_masks_train(class_labels):
+        """modelling/bases.py:359-384 (host logic kept for API parity; the training step itself derives
+        the same masks on the fly from the PID-contiguous [P, K] batch layout)."""
+        labels_dict = defaultdict(list)
+        class_labels = class_labels.detach().cpu().numpy()
+        for idx, pid in enumerate(class_labels):
+            labels_dict[pid].append(idx)
+        labels_list = [v for _, v in labels_dict.items()]
+        labels_list_copy = copy.deepcopy(labels_list)
+        lens_list = [len(item) for item in labels_list]
+        lens_list_cs = np.cumsum(lens_list)
+        max_gal_num = max(lens_list)
+        masks = torch.ones((max_gal_num, len(class_labels)), dtype=torch.bool)
+        for r in range(max_gal_num):
+            for i, inner in enumerate(labels_list):
+                if len(inner) > 0:
+                    masks[r, inner.pop(0)] = 0
+                else:
+                    start = lens_list_cs[i - 1]
+                    masks[r, start:start + lens_list[i]] = 0
+        return masks, labels_list_copy
+
+    def test_step(self, batch, batch_idx):
+        return self.validation_step(batch, batch_idx)
+
+    def test_epoch_end(self, outputs):
+        return self.validation_epoch_end(outputs)

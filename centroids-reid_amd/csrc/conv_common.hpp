@@ -1,0 +1,63 @@
+// Geometry shared by the implicit-GEMM convolution kernels (stage A).
+//
+// Every convolution of the backbone (modelling/backbones/resnet.py:56-61,94,109) is lowered to
+// an im2col-FREE GEMM  C[M, N] = sum_k A[m, k] * W[n, k]  over NHWC activations:
+//   m = (b, oy, ox) output pixel, n = output channel, k = (tap, c) with tap = (r, s);
+// the A row for a tap is a CONTIGUOUS run of `span` channels of one source pixel, so the A tile
+// is gathered straight from the activation tensor with 16-byte loads (zero-filled outside the
+// image) -- no column buffer is ever materialised.  The same kernel computes the data gradient
+// (`transposed` = 1: source = dY, weights pre-transposed to [Cin][r][s][Cout]) and the stem
+// (7x7 s2 on a pre-padded NHWC4 image: span = 32 = 8 pixels x 4 channels per kernel row).
+#pragma once
+#include "common.hpp"
+
+struct IGemmGeom {
+  int M;              // rows of the GEMM = batch * OH * OW
+  int OH, OW;         // spatial dims that index the rows
+  int SH, SW;         // source spatial dims (tensor the A operand is gathered from)
+  int pitch;          // elements per source pixel (channels; 4 for the padded stem image)
+  int log2span;       // log2(elements of K per tap)
+  int kw;             // taps per kernel row: tap -> (r = tap / kw, s = tap % kw)
+  int stride, pad;
+  int transposed;     // 0: iy = oy*stride + r - pad ; 1: ty = oy + pad - r, iy = ty/stride if divisible
+  int K;              // reduction length = taps << log2span
+  int N;              // output channels
+  int check_bounds;   // 0: source is pre-padded (stem)
+};
+
+// Source pixel of output row (oy, ox) under tap (r, s); returns false when it falls outside.
+__device__ __forceinline__ bool igemm_src_pixel(const IGemmGeom& g, int oy, int ox, int r, int s, int& iy, int& ix) {
+  if (!g.transposed) {
+    iy = oy * g.stride + r - g.pad;
+    ix = ox * g.stride + s - g.pad;
+  } else {
+    const int ty = oy + g.pad - r, tx = ox + g.pad - s;
+    if (g.stride == 1) { iy = ty; ix = tx; }
+    else {
+      if (ty < 0 || tx < 0 || (ty % g.stride) != 0 || (tx % g.stride) != 0) return false;
+      iy = ty / g.stride; ix = tx / g.stride;
+    }
+  }
+  if (!g.check_bounds) return true;
+  return (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+}
+
+// XCD-aware bijective remap of the linear workgroup id (consecutive ids land on different XCDs;
+// give every XCD a contiguous run of tiles so neighbouring tiles share operand panels in its L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  return base + (bid >> 3);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+  static constexpr int DT = CREID_F32;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemIO<unsigned short> {   // bf16 bits
+  static constexpr int DT = CREID_BF16;
+  static __device__ __forceinline__ float ld(const unsigned short* p) { return bf16_bits_to_f32(*p); }
+  static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_bf16_bits(v); }
+};

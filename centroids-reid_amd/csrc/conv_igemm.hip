@@ -1,0 +1,366 @@
+// Stage A: implicit-GEMM convolution forward / data-gradient for NHWC activations.
+// (replaces nn.Conv2d fwd + dgrad of modelling/backbones/resnet.py:56-61,94,109 and
+//  resnet_ibn_a.py:40-48,83,110 -- bias-free 7x7 s2, 3x3 (s1/s2), 1x1 (s1/s2) convolutions.)
+//
+// bf16: 128 x BN x 64 tile, 256 threads (2x2 waves, 64 x BN/2 per wave) on
+//       v_mfma_f32_32x32x16_bf16, fp32 accumulate; LDS row-major [row][64] with the 16-B chunk
+//       index XOR-swizzled by (row>>1)&7 (conflict-free ds_read_b128), double-buffered,
+//       register-staged gather (the A rows come from different image rows / taps).
+// f32 : 128 x BN x 16 tile on v_mfma_f32_32x32x2_f32 (exact f32; parity mode), K-major LDS.
+// Epilogue (both): optional "+ add_src" (residual-gradient accumulation in dgrad), store in the
+// activation dtype, and optional per-tile per-channel (sum, sum of squares) partials of the fp32
+// accumulators for the training-mode BatchNorm that follows every convolution.
+#include "conv_common.hpp"
+
+// ------------------------------------------------------------------------------------ bf16
+template <int BN>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
+                                                         const unsigned short* __restrict__ wgt,
+                                                         unsigned short* __restrict__ out,
+                                                         const unsigned short* __restrict__ add_src,
+                                                         float* __restrict__ bn_part, int tiles_n) {
+  constexpr int BK = 64, TNW = BN / 64, NB = BN / 32;
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][128 * BK];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int row0 = tile_m * 128, col0 = tile_n * BN;
+  const int span_mask = (1 << g.log2span) - 1;
+
+  const int lrow = tid >> 3, lch = tid & 7;
+  int oy[4], ox[4], bpix[4], soff[4];
+  bool vm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = lrow + 32 * i, m = row0 + r;
+    vm[i] = m < g.M;
+    const int mm = vm[i] ? m : 0;
+    const int b = mm / (g.OH * g.OW), rem = mm - b * (g.OH * g.OW);
+    oy[i] = rem / g.OW; ox[i] = rem - oy[i] * g.OW;
+    bpix[i] = b * g.SH * g.SW;
+    soff[i] = r * BK + ((lch ^ ((r >> 1) & 7)) << 3);
+  }
+  const unsigned short* wp[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) wp[i] = wgt + (int64_t)(col0 + lrow + 32 * i) * g.K + 8 * lch;
+
+  uint4 ra[4], rb[NB];
+  auto gload = [&](int t) {
+    const int kk = t * BK + 8 * lch;
+    const int tap = kk >> g.log2span, c = kk & span_mask;
+    const int r = tap / g.kw, s = tap - r * g.kw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy, ix;
+      if (vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix))
+        ra[i] = *reinterpret_cast<const uint4*>(src + (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + c);
+      else
+        ra[i] = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(wp[i] + t * BK);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&As[buf][soff[i]]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[buf][soff[i]]) = rb[i];
+  };
+
+  f32x16 acc[2][TNW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int l31 = lane & 31, kh = lane >> 5;
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) gload(t + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = 2 * kk + kh;
+      s16x8 a[2], b[TNW];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        a[i] = *reinterpret_cast<const s16x8*>(&As[buf][r * BK + ((ch ^ ((r >> 1) & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) {
+        const int c = wn * (BN / 2) + j * 32 + l31;
+        b[j] = *reinterpret_cast<const s16x8*>(&Bs[buf][c * BK + ((ch ^ ((c >> 1) & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                              __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  float* red = reinterpret_cast<float*>(&As[0][0]);   // [2 (wm)][2 (s1,s2)][BN]
+#pragma unroll
+  for (int j = 0; j < TNW; ++j) {
+    const int cl = wn * (BN / 2) + j * 32 + l31;
+    const int c = col0 + cl;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (rr < g.M) {
+          float v = acc[i][j][r];
+          if (add_src) v += bf16_bits_to_f32(add_src[(int64_t)rr * g.N + c]);
+          s1 += v; s2 = fmaf(v, v, s2);
+          out[(int64_t)rr * g.N + c] = f32_to_bf16_bits(v);
+        }
+      }
+    }
+    if (bn_part) {
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (kh == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
+    }
+  }
+  if (bn_part) {
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, cl = i - which * BN;
+      bn_part[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ f32
+template <int BN>
+__global__ __launch_bounds__(256) void igemm_f32_kernel(IGemmGeom g, const float* __restrict__ src,
+                                                        const float* __restrict__ wgt, float* __restrict__ out,
+                                                        const float* __restrict__ add_src,
+                                                        float* __restrict__ bn_part, int tiles_n) {
+  constexpr int BK = 16, LDA = 129, LDB = BN + 1, TNW = BN / 64, NB = BN / 64;
+  __shared__ float As[2][BK][LDA];
+  __shared__ float Bs[2][BK][LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int row0 = tile_m * 128, col0 = tile_n * BN;
+  const int span_mask = (1 << g.log2span) - 1;
+
+  const int lrow = tid >> 2, lkc = tid & 3;
+  int oy[2], ox[2], bpix[2];
+  bool vm[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = row0 + lrow + 64 * i;
+    vm[i] = m < g.M;
+    const int mm = vm[i] ? m : 0;
+    const int b = mm / (g.OH * g.OW), rem = mm - b * (g.OH * g.OW);
+    oy[i] = rem / g.OW; ox[i] = rem - oy[i] * g.OW;
+    bpix[i] = b * g.SH * g.SW;
+  }
+  const float* wp[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) wp[i] = wgt + (int64_t)(col0 + lrow + 64 * i) * g.K + 4 * lkc;
+  float4 ra[2], rb[NB];
+  auto gload = [&](int t) {
+    const int kk = t * BK + 4 * lkc;
+    const int tap = kk >> g.log2span, c = kk & span_mask;
+    const int r = tap / g.kw, s = tap - r * g.kw;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int iy, ix;
+      if (vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix))
+        ra[i] = *reinterpret_cast<const float4*>(src + (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + c);
+      else
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4*>(wp[i] + t * BK);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = lrow + 64 * i;
+      As[buf][4 * lkc + 0][r] = ra[i].x; As[buf][4 * lkc + 1][r] = ra[i].y;
+      As[buf][4 * lkc + 2][r] = ra[i].z; As[buf][4 * lkc + 3][r] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = lrow + 64 * i;
+      Bs[buf][4 * lkc + 0][r] = rb[i].x; Bs[buf][4 * lkc + 1][r] = rb[i].y;
+      Bs[buf][4 * lkc + 2][r] = rb[i].z; Bs[buf][4 * lkc + 3][r] = rb[i].w;
+    }
+  };
+  f32x16 acc[2][TNW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = g.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int l31 = lane & 31, kh = lane >> 5;
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) gload(t + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[2], b[TNW];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[buf][kk + kh][wm * 64 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) b[j] = Bs[buf][kk + kh][wn * (BN / 2) + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  float* red = &As[0][0][0];
+#pragma unroll
+  for (int j = 0; j < TNW; ++j) {
+    const int cl = wn * (BN / 2) + j * 32 + l31;
+    const int c = col0 + cl;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (rr < g.M) {
+          float v = acc[i][j][r];
+          if (add_src) v += add_src[(int64_t)rr * g.N + c];
+          s1 += v; s2 = fmaf(v, v, s2);
+          out[(int64_t)rr * g.N + c] = v;
+        }
+      }
+    }
+    if (bn_part) {
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (kh == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
+    }
+  }
+  if (bn_part) {
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, cl = i - which * BN;
+      bn_part[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ host
+static int ilog2_exact(int64_t v) {
+  int l = 0;
+  while ((1LL << l) < v) ++l;
+  return ((1LL << l) == v) ? l : -1;
+}
+
+static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src,
+                        float* bn_part, int dtype, hipStream_t s) {
+  const int tiles_m = (g.M + 127) / 128;
+  // pick the N tile: 128 unless that leaves the chip (256 CUs) under-filled or N is only 64
+  int bn = 128;
+  if (g.N % 128 != 0 || (int64_t)tiles_m * (g.N / 128) < 384) bn = 64;
+  if (g.N % bn != 0) return CREID_E_SHAPE;
+  const int tiles_n = g.N / bn;
+  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
+  if (dtype == CREID_BF16) {
+    if (g.K % 64 != 0) return CREID_E_SHAPE;
+    if (bn == 128)
+      hipLaunchKernelGGL(igemm_bf16_kernel<128>, grid, block, 0, s, g, (const unsigned short*)src,
+                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n);
+    else
+      hipLaunchKernelGGL(igemm_bf16_kernel<64>, grid, block, 0, s, g, (const unsigned short*)src,
+                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n);
+  } else if (dtype == CREID_F32) {
+    if (g.K % 16 != 0) return CREID_E_SHAPE;
+    if (bn == 128)
+      hipLaunchKernelGGL(igemm_f32_kernel<128>, grid, block, 0, s, g, (const float*)src, (const float*)wgt, (float*)out,
+                         (const float*)add_src, bn_part, tiles_n);
+    else
+      hipLaunchKernelGGL(igemm_f32_kernel<64>, grid, block, 0, s, g, (const float*)src, (const float*)wgt, (float*)out,
+                         (const float*)add_src, bn_part, tiles_n);
+  } else {
+    return CREID_E_DTYPE;
+  }
+  return (int)hipGetLastError();
+}
+
+static int check_desc(const creid_conv_desc* d) {
+  if (!d || d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->in_c <= 0 || d->out_c <= 0) return CREID_E_ARG;
+  if (d->kh != d->kw || (d->kh != 1 && d->kh != 3) || d->stride < 1 || d->stride > 2) return CREID_E_SHAPE;
+  if (ilog2_exact(d->in_c) < 0 || ilog2_exact(d->out_c) < 0 || d->in_c < 64 || d->out_c < 64) return CREID_E_SHAPE;
+  if (d->out_h != (d->in_h + 2 * d->pad - d->kh) / d->stride + 1) return CREID_E_SHAPE;
+  if (d->out_w != (d->in_w + 2 * d->pad - d->kw) / d->stride + 1) return CREID_E_SHAPE;
+  if (d->batch * d->in_h * d->in_w > 0x7fffffffLL / 4 || d->batch * d->in_h * d->in_w * d->in_c > (1LL << 40)) return CREID_E_SHAPE;
+  return 0;
+}
+
+extern "C" {
+
+int64_t creid_conv2d_bn_partial_rows(const creid_conv_desc* d) {
+  if (!d) return 0;
+  return (d->batch * d->out_h * d->out_w + 127) / 128;   /* (sum, sumsq) row PAIRS */
+}
+
+int creid_conv2d_fwd_nhwc(const creid_conv_desc* d, const void* x, const void* w_krsc, void* y, float* bn_partial,
+                          int dtype, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CREID_CHECK_ARG(x && w_krsc && y);
+  IGemmGeom g;
+  g.M = (int)(d->batch * d->out_h * d->out_w); g.OH = (int)d->out_h; g.OW = (int)d->out_w;
+  g.SH = (int)d->in_h; g.SW = (int)d->in_w; g.pitch = (int)d->in_c; g.log2span = ilog2_exact(d->in_c);
+  g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 0;
+  g.K = (int)(d->kh * d->kw * d->in_c); g.N = (int)d->out_c; g.check_bounds = 1;
+  return launch_igemm(g, x, w_krsc, y, nullptr, bn_partial, dtype, as_stream(stream));
+}
+
+int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx, const void* add_src,
+                            int dtype, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CREID_CHECK_ARG(dy && w_crsk && dx);
+  IGemmGeom g;
+  g.M = (int)(d->batch * d->in_h * d->in_w); g.OH = (int)d->in_h; g.OW = (int)d->in_w;
+  g.SH = (int)d->out_h; g.SW = (int)d->out_w; g.pitch = (int)d->out_c; g.log2span = ilog2_exact(d->out_c);
+  g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 1;
+  g.K = (int)(d->kh * d->kw * d->out_c); g.N = (int)d->in_c; g.check_bounds = 1;
+  return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream));
+}
+
+/* stem: 7x7 stride-2 pad-3 conv, 3 -> 64 channels, on the pre-padded NHWC4 image
+ * xpad [B, H+8, W+6, 4] (image at rows 3..H+2, cols 3..W+2, zeros elsewhere); w_stem [64][8][32]
+ * (k = r*32 + s*4 + c, zero for s = 7, c = 3 and r = 7); y [B, H/2, W/2, 64]. */
+int creid_stem_conv_fwd(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* w_stem, void* y,
+                        float* bn_partial, int dtype, void* stream) {
+  CREID_CHECK_ARG(xpad && w_stem && y && batch > 0 && H > 0 && W > 0);
+  if (H % 2 || W % 2) return CREID_E_SHAPE;
+  IGemmGeom g;
+  g.M = (int)(batch * (H / 2) * (W / 2)); g.OH = (int)(H / 2); g.OW = (int)(W / 2);
+  g.SH = (int)(H + 8); g.SW = (int)(W + 6); g.pitch = 4; g.log2span = 5;
+  g.kw = 1; g.stride = 2; g.pad = 0; g.transposed = 0; g.K = 256; g.N = 64; g.check_bounds = 0;
+  return launch_igemm(g, xpad, w_stem, y, nullptr, bn_partial, dtype, as_stream(stream));
+}
+
+}  // extern "C"

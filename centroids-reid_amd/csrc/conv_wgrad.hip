@@ -1,0 +1,346 @@
+// Stage A: convolution weight gradient  dW[n, (tap, c)] = sum_m dY[m, n] * Xg[m, (tap, c)]
+// (replaces nn.Conv2d wgrad of modelling/backbones/resnet.py:56-61,94,109).
+//
+// Both operands are stored PIXEL-major (the reduction index m is the row index of dY and X), so
+// this is a "TN" GEMM.  bf16: the tiles are copied to LDS exactly as they lie in memory
+// ([pixel][channel], 16-B stores) and the MFMA fragments (8 consecutive pixels of one channel
+// per lane) come out of gfx950's transposing LDS read `ds_read_b64_tr_b16` -- no register or
+// memory transpose.  Row pitch = tile width + 32 elements puts the four 32-B row segments of a
+// 16-lane group (and both groups of a 32-lane service half) on distinct banks.
+// f32 (parity mode): K-major LDS is the natural layout for v_mfma_f32_32x32x2_f32.
+// The pixel range is split over gridDim.y workgroups; fp32 partial tiles go to the workspace and
+// wgrad_reduce sums them (deterministic) and scatters into the OIHW fp32 gradient.
+#include "conv_common.hpp"
+
+namespace {
+constexpr int WKS = 64;   // pixels per k-step (bf16)
+constexpr int WKF = 16;   // pixels per k-step (f32)
+}
+
+// Two MFMA fragments (channel offsets +0 / +32) x two 4-pixel halves from one base address.
+// The loads are issued in one asm statement; the matching s_waitcnt statement below names every
+// destination "+v" so no consumer can be scheduled before the data has landed (hipcc does not
+// count inline-asm LDS reads itself).
+template <int OFF_HI>
+__device__ __forceinline__ void tr_load4(const unsigned short* p, s16x4& f0lo, s16x4& f0hi, s16x4& f1lo, s16x4& f1hi) {
+  const unsigned addr = (unsigned)(uintptr_t)p;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4\n\t"
+      "ds_read_b64_tr_b16 %1, %4 offset:%5\n\t"
+      "ds_read_b64_tr_b16 %2, %4 offset:64\n\t"
+      "ds_read_b64_tr_b16 %3, %4 offset:%6"
+      : "=&v"(f0lo), "=&v"(f0hi), "=&v"(f1lo), "=&v"(f1hi)
+      : "v"(addr), "i"(OFF_HI), "i"(OFF_HI + 64)
+      : "memory");
+}
+__device__ __forceinline__ void tr_wait8(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)::"memory");
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
+                                                         const unsigned short* __restrict__ x, int NCO,
+                                                         float* __restrict__ ws, int tiles_k, int m_per_split) {
+  constexpr int PA = TM + 32, PB = TN + 32;                 // LDS row pitches (elements)
+  constexpr int IM = TM / 64, JN = TN / 64;                 // MFMA tiles per wave
+  constexpr int CA = TM / 8, CB = TN / 8;                   // 16-B chunks per row
+  constexpr int RA = 256 / CA, RB = 256 / CB;               // rows per load pass
+  constexpr int NA = WKS / RA, NBL = WKS / RB;              // load passes
+  __shared__ __attribute__((aligned(16))) unsigned short Ad[WKS * PA];
+  __shared__ __attribute__((aligned(16))) unsigned short Bx[WKS * PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int tile_co = tile / tiles_k, tile_k = tile - tile_co * tiles_k;
+  const int co0 = tile_co * TM, k0 = tile_k * TN;
+  const int m_begin = split * m_per_split, m_end = min(g.M, m_begin + m_per_split);
+  const int span_mask = (1 << g.log2span) - 1;
+
+  // load maps
+  const int a_ch = tid % CA, a_row = tid / CA;
+  const int b_ch = tid % CB, b_row = tid / CB;
+  const int kcol = k0 + 8 * b_ch;
+  const int tap = kcol >> g.log2span, cc = kcol & span_mask;
+  const int tr = tap / g.kw, ts = tap - tr * g.kw;
+  uint4 ra[NA], rb[NBL];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int m = mb + a_row + RA * i;
+      ra[i] = (m < m_end) ? *reinterpret_cast<const uint4*>(dy + (int64_t)m * NCO + co0 + 8 * a_ch)
+                          : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int m = mb + b_row + RB * i;
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (m < m_end) {
+        const int b = m / (g.OH * g.OW), rem = m - b * (g.OH * g.OW);
+        const int oy = rem / g.OW, ox = rem - oy * g.OW;
+        int iy, ix;
+        if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))
+          rb[i] = *reinterpret_cast<const uint4*>(x + (int64_t)((b * g.SH + iy) * g.SW + ix) * g.pitch + cc);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&Ad[(a_row + RA * i) * PA + 8 * a_ch]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) *reinterpret_cast<uint4*>(&Bx[(b_row + RB * i) * PB + 8 * b_ch]) = rb[i];
+  };
+
+  f32x16 acc[IM][JN];
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposing-read lane map: this lane supplies (row = 8*(lane>>5) + (li>>2) [+4q] [+16kk], col = 16*((lane>>4)&1) + 4*(li&3))
+  const int li = lane & 15;
+  const int t_row = 8 * (lane >> 5) + (li >> 2), t_col = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+
+  gload(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += WKS) {
+    __syncthreads();            // previous step's fragment reads are done
+    lstore();
+    __syncthreads();
+    if (mb + WKS < m_end) gload(mb + WKS);
+#pragma unroll
+    for (int kk = 0; kk < WKS / 16; ++kk) {
+      s16x4 al[2], ah[2], bl[2], bh[2];
+      tr_load4<4 * PA * 2>(&Ad[(kk * 16 + t_row) * PA + wm * (TM / 2) + t_col], al[0], ah[0], al[1], ah[1]);
+      tr_load4<4 * PB * 2>(&Bx[(kk * 16 + t_row) * PB + wn * (TN / 2) + t_col], bl[0], bh[0], bl[1], bh[1]);
+      tr_wait8(al[0], ah[0], al[1], ah[1], bl[0], bh[0], bl[1], bh[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      s16x8 a[IM], b[JN];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) a[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < JN; ++j) b[j] = __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                              __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+  // partial tile -> workspace [split][NCO][K]
+  const int l31 = lane & 31, kh = lane >> 5;
+  float* wsp = ws + (int64_t)split * NCO * g.K;
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int kc = k0 + wn * (TN / 2) + j * 32 + l31;
+        wsp[(int64_t)co * g.K + kc] = acc[i][j][r];
+      }
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(IGemmGeom g, const float* __restrict__ dy,
+                                                        const float* __restrict__ x, int NCO, float* __restrict__ ws,
+                                                        int tiles_k, int m_per_split) {
+  constexpr int IM = TM / 64, JN = TN / 64;
+  constexpr int CA = TM / 4, CB = TN / 4;
+  constexpr int RA = 256 / CA, RB = 256 / CB;
+  constexpr int NA = (WKF + RA - 1) / RA, NBL = (WKF + RB - 1) / RB;
+  __shared__ __attribute__((aligned(16))) float Ad[WKF][TM];
+  __shared__ __attribute__((aligned(16))) float Bx[WKF][TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int tile_co = tile / tiles_k, tile_k = tile - tile_co * tiles_k;
+  const int co0 = tile_co * TM, k0 = tile_k * TN;
+  const int m_begin = split * m_per_split, m_end = min(g.M, m_begin + m_per_split);
+  const int span_mask = (1 << g.log2span) - 1;
+  const int a_ch = tid % CA, a_row = tid / CA;
+  const int b_ch = tid % CB, b_row = tid / CB;
+  const int kcol = k0 + 4 * b_ch;
+  const int tap = kcol >> g.log2span, cc = kcol & span_mask;
+  const int tr = tap / g.kw, ts = tap - tr * g.kw;
+  float4 ra[NA], rb[NBL];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int pr = a_row + RA * i, m = mb + pr;
+      ra[i] = (pr < WKF && m < m_end) ? *reinterpret_cast<const float4*>(dy + (int64_t)m * NCO + co0 + 4 * a_ch)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int pr = b_row + RB * i, m = mb + pr;
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pr < WKF && m < m_end) {
+        const int b = m / (g.OH * g.OW), rem = m - b * (g.OH * g.OW);
+        const int oy = rem / g.OW, ox = rem - oy * g.OW;
+        int iy, ix;
+        if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))
+          rb[i] = *reinterpret_cast<const float4*>(x + (int64_t)((b * g.SH + iy) * g.SW + ix) * g.pitch + cc);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (a_row + RA * i < WKF) *reinterpret_cast<float4*>(&Ad[a_row + RA * i][4 * a_ch]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i)
+      if (b_row + RB * i < WKF) *reinterpret_cast<float4*>(&Bx[b_row + RB * i][4 * b_ch]) = rb[i];
+  };
+  f32x16 acc[IM][JN];
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, kh = lane >> 5;
+  gload(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += WKF) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (mb + WKF < m_end) gload(mb + WKF);
+#pragma unroll
+    for (int kk = 0; kk < WKF; kk += 2) {
+      float a[IM], b[JN];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) a[i] = Ad[kk + kh][wm * (TM / 2) + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < JN; ++j) b[j] = Bx[kk + kh][wn * (TN / 2) + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* wsp = ws + (int64_t)split * NCO * g.K;
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int kc = k0 + wn * (TN / 2) + j * 32 + l31;
+        wsp[(int64_t)co * g.K + kc] = acc[i][j][r];
+      }
+}
+
+// sum over splits and scatter [NCO][K = (tap, within)] -> OIHW fp32 gradient (accumulating).
+// r = tap / kw_taps; s = tap % kw_taps + within / cpitch; c = within % cpitch.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int NCO, int K,
+                                                           int log2span, int kw_taps, int cpitch, int cin, int kh,
+                                                           int kw, float* __restrict__ dw_oihw, int accumulate) {
+  const int64_t total = (int64_t)NCO * K;
+  const int span_mask = (1 << log2span) - 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int co = (int)(i / K), kc = (int)(i - (int64_t)co * K);
+    const int tap = kc >> log2span, within = kc & span_mask;
+    const int r = tap / kw_taps, s = tap % kw_taps + within / cpitch, c = within % cpitch;
+    if (r >= kh || s >= kw || c >= cin) continue;
+    float acc = 0.f;
+    for (int sp = 0; sp < splits; ++sp) acc += ws[(int64_t)sp * total + i];
+    float* dst = dw_oihw + (((int64_t)co * cin + c) * kh + r) * kw + s;
+    *dst = accumulate ? *dst + acc : acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------ host
+static int ilog2x(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return ((1LL << l) == v) ? l : -1; }
+
+struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split; };
+
+static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
+  WgradPlan p;
+  p.tm = (NCO % 128 == 0) ? 128 : 64;
+  p.tn = (K % 128 == 0 && K >= 256) ? 128 : 64;
+  if ((int64_t)(NCO / p.tm) * (K / p.tn) < 16 && p.tn == 128) p.tn = 64;
+  p.tiles_k = K / p.tn;
+  p.tiles = (NCO / p.tm) * p.tiles_k;
+  const int ks = (dtype == CREID_BF16) ? WKS : WKF;
+  int splits = (1024 + p.tiles - 1) / p.tiles;
+  const int max_splits = (M + 4 * ks - 1) / (4 * ks);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.m_per_split = ((M + splits - 1) / splits + ks - 1) / ks * ks;
+  p.splits = (M + p.m_per_split - 1) / p.m_per_split;
+  return p;
+}
+
+template <int TM, int TN>
+static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* ws, const WgradPlan& p,
+                           int dtype, hipStream_t s) {
+  dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(256);
+  if (dtype == CREID_BF16)
+    hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN>), grid, block, 0, s, g, (const unsigned short*)dy,
+                       (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+  else
+    hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN>), grid, block, 0, s, g, (const float*)dy, (const float*)x, NCO, ws,
+                       p.tiles_k, p.m_per_split);
+}
+
+static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* dw, int kw_taps, int cpitch,
+                     int cin, int kh, int kw, int accumulate, void* ws, size_t ws_bytes, int dtype, hipStream_t s) {
+  if (dtype != CREID_BF16 && dtype != CREID_F32) return CREID_E_DTYPE;
+  const WgradPlan p = plan_wgrad(g.M, NCO, g.K, dtype);
+  const size_t need = (size_t)p.splits * NCO * g.K * sizeof(float);
+  if (ws_bytes < need) return CREID_E_WS;
+  if (p.tm == 128 && p.tn == 128) launch_wgrad_t<128, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+  else if (p.tm == 128 && p.tn == 64) launch_wgrad_t<128, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+  else if (p.tm == 64 && p.tn == 128) launch_wgrad_t<64, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+  else launch_wgrad_t<64, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+  int64_t blocks = ((int64_t)NCO * g.K + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, p.splits, NCO,
+                     g.K, g.log2span, kw_taps, cpitch, cin, kh, kw, dw, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" {
+
+size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype) {
+  if (!d) return 0;
+  const int M = (int)(d->batch * d->out_h * d->out_w), K = (int)(d->kh * d->kw * d->in_c);
+  const WgradPlan p = plan_wgrad(M, (int)d->out_c, K, dtype);
+  return (size_t)p.splits * d->out_c * K * sizeof(float);
+}
+
+int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
+                            void* ws, size_t ws_bytes, int dtype, void* stream) {
+  CREID_CHECK_ARG(d && x && dy && dw_oihw && ws);
+  if (ilog2x(d->in_c) < 0 || d->in_c < 64 || d->out_c % 64 != 0) return CREID_E_SHAPE;
+  IGemmGeom g;
+  g.M = (int)(d->batch * d->out_h * d->out_w); g.OH = (int)d->out_h; g.OW = (int)d->out_w;
+  g.SH = (int)d->in_h; g.SW = (int)d->in_w; g.pitch = (int)d->in_c; g.log2span = ilog2x(d->in_c);
+  g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 0;
+  g.K = (int)(d->kh * d->kw * d->in_c); g.N = (int)d->out_c; g.check_bounds = 1;
+  return run_wgrad(g, dy, x, (int)d->out_c, dw_oihw, d->kw, (int)d->in_c, (int)d->in_c, d->kh, d->kw, accumulate, ws,
+                   ws_bytes, dtype, as_stream(stream));
+}
+
+size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype) {
+  const WgradPlan p = plan_wgrad((int)(batch * (H / 2) * (W / 2)), 64, 256, dtype);
+  return (size_t)p.splits * 64 * 256 * sizeof(float);
+}
+
+/* stem weight gradient into the OIHW [64,3,7,7] fp32 tensor (see creid_stem_conv_fwd for layouts). */
+int creid_stem_conv_wgrad(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* dy, float* dw_oihw,
+                          int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  CREID_CHECK_ARG(xpad && dy && dw_oihw && ws && batch > 0 && H > 0 && W > 0);
+  if (H % 2 || W % 2) return CREID_E_SHAPE;
+  IGemmGeom g;
+  g.M = (int)(batch * (H / 2) * (W / 2)); g.OH = (int)(H / 2); g.OW = (int)(W / 2);
+  g.SH = (int)(H + 8); g.SW = (int)(W + 6); g.pitch = 4; g.log2span = 5;
+  g.kw = 1; g.stride = 2; g.pad = 0; g.transposed = 0; g.K = 256; g.N = 64; g.check_bounds = 0;
+  return run_wgrad(g, dy, xpad, 64, dw_oihw, 1, 4, 3, 7, 7, accumulate, ws, ws_bytes, dtype, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,574 @@
+// Stage A: the HBM-bound layers around the convolutions, NHWC, 16-byte accesses:
+// training/eval BatchNorm2d (statistics finalize, apply + ReLU + residual, backward reduce/apply),
+// MaxPool 3x3 s2, global average pool, input/weight layout transforms.
+// Reference: nn.BatchNorm2d / ReLU / residual add of modelling/backbones/resnet.py:67-87,
+// MaxPool2d(3,2,1) :98, AdaptiveAvgPool2d(1) modelling/baseline.py:89,93.
+#include "conv_common.hpp"
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec16<unsigned short> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// ------------------------------------------------------------------ BN statistics finalize
+// partial: [rows][2][C] (sum, sumsq per 128-row conv tile).  training: mean/invstd from the batch and
+// running-stat update (momentum, unbiased variance); eval: mean = running_mean, invstd = rsqrt(rv+eps).
+__global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+                                                            double count, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, int training, float momentum,
+                                                            float eps, float* __restrict__ mean_out,
+                                                            float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  if (!training) { mean_out[c] = rmean[c]; invstd_out[c] = 1.0f / sqrtf(rvar[c] + eps); return; }
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) { s1 += (double)partial[((int64_t)r * 2) * C + c]; s2 += (double)partial[((int64_t)r * 2 + 1) * C + c]; }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+}
+
+// stand-alone statistics (used when the producer is not a conv epilogue): partial[(blockIdx.y)][2][C]
+template <typename T>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, int64_t M, int C, int rows_per_block,
+                                                        float* __restrict__ partial) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[8][2][32 * V];
+  const int cch = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + cch) * V;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s1[V], s2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  if (c0 < C)
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      float v[V];
+      Vec16<T>::load(x + r * C + c0, v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
+    }
+#pragma unroll
+  for (int k = 0; k < V; ++k) { red[rl][0][cch * V + k] = s1[k]; red[rl][1][cch * V + k] = s2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 32 * V; i += 256) {
+    const int which = i / (32 * V), cl = i - which * 32 * V;
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += red[q][which][cl];
+    const int c = blockIdx.x * 32 * V + cl;
+    if (c < C) partial[((int64_t)blockIdx.y * 2 + which) * C + c] = a;
+  }
+}
+
+// ------------------------------------------------------------------ BN apply (+residual)(+ReLU)
+template <typename T>
+__global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const T* __restrict__ res,
+                                                         int relu, int64_t M, int C, T* __restrict__ y) {
+  constexpr int V = Vec16<T>::N;
+  const int cpr = C / V;
+  const int64_t total = M * cpr, nthreads = (int64_t)gridDim.x * 256;
+  const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (int)(gtid % cpr) * V;     // nthreads % cpr == 0 -> this thread's channels never change
+  float sc[V], sh[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    sc[k] = invstd[c0 + k] * (gamma ? gamma[c0 + k] : 1.f);
+    sh[k] = (beta ? beta[c0 + k] : 0.f) - mean[c0 + k] * sc[k];
+  }
+  for (int64_t i = gtid; i < total; i += nthreads) {
+    float v[V];
+    Vec16<T>::load(x + i * V, v);
+    if (res) {
+      float rv[V];
+      Vec16<T>::load(res + i * V, rv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = fmaf(v[k], sc[k], sh[k]) + rv[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = fmaf(v[k], sc[k], sh[k]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    Vec16<T>::store(y + i * V, v);
+  }
+}
+
+// ------------------------------------------------------------------ BN backward
+// dy = g * (act > 0 if act) ; partial[(blockIdx.y)][2][C] = (sum dy, sum dy * xhat)
+template <typename T>
+__global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                              const T* __restrict__ act,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, int64_t M, int C,
+                                                              int rows_per_block, float* __restrict__ partial) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[8][2][32 * V];
+  const int cch = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + cch) * V;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s1[V], s2[V], mu[V], is[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; is[k] = 0.f; }
+  if (c0 < C) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) { mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k]; }
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      float xv[V], gv[V];
+      Vec16<T>::load(x + r * C + c0, xv);
+      Vec16<T>::load(g + r * C + c0, gv);
+      if (act) {
+        float av[V];
+        Vec16<T>::load(act + r * C + c0, av);
+#pragma unroll
+        for (int k = 0; k < V; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < V; ++k) { s1[k] += gv[k]; s2[k] = fmaf(gv[k], (xv[k] - mu[k]) * is[k], s2[k]); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) { red[rl][0][cch * V + k] = s1[k]; red[rl][1][cch * V + k] = s2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 32 * V; i += 256) {
+    const int which = i / (32 * V), cl = i - which * 32 * V;
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += red[q][which][cl];
+    const int c = blockIdx.x * 32 * V + cl;
+    if (c < C) partial[((int64_t)blockIdx.y * 2 + which) * C + c] = a;
+  }
+}
+
+// sums[2][C] = sum over row blocks; dgamma += sum dy*xhat ; dbeta += sum dy
+__global__ __launch_bounds__(256) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+                                                                float* __restrict__ sums, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) { s1 += (double)partial[((int64_t)r * 2) * C + c]; s2 += (double)partial[((int64_t)r * 2 + 1) * C + c]; }
+  sums[c] = (float)s1; sums[C + c] = (float)s2;
+  if (dbeta) dbeta[c] += (float)s1;
+  if (dgamma) dgamma[c] += (float)s2;
+}
+
+// dx = gamma*invstd*(dy - sum_dy/M - xhat*sum_dyxhat/M); optional gm_out = dy (the ReLU-masked upstream grad)
+template <typename T>
+__global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                             const T* __restrict__ act,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ sums, int64_t M, int C,
+                                                             T* __restrict__ dx, T* __restrict__ gm_out) {
+  constexpr int V = Vec16<T>::N;
+  const int cpr = C / V;
+  const int64_t total = M * cpr, nthreads = (int64_t)gridDim.x * 256;
+  const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (int)(gtid % cpr) * V;
+  const float invM = 1.0f / (float)M;
+  float mu[V], is[V], k1[V], a1[V], a2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k];
+    k1[k] = (gamma ? gamma[c0 + k] : 1.f) * is[k];
+    a1[k] = sums[c0 + k] * invM; a2[k] = sums[C + c0 + k] * invM;
+  }
+  for (int64_t i = gtid; i < total; i += nthreads) {
+    float xv[V], gv[V];
+    Vec16<T>::load(x + i * V, xv);
+    Vec16<T>::load(g + i * V, gv);
+    if (act) {
+      float av[V];
+      Vec16<T>::load(act + i * V, av);
+#pragma unroll
+      for (int k = 0; k < V; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
+    }
+    if (gm_out) Vec16<T>::store(gm_out + i * V, gv);
+    float o[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = k1[k] * (gv[k] - a1[k] - (xv[k] - mu[k]) * is[k] * a2[k]);
+    Vec16<T>::store(dx + i * V, o);
+  }
+}
+
+// ------------------------------------------------------------------ max-pool 3x3 s2 p1
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int B, int H, int W, int C,
+                                                          T* __restrict__ y, uint8_t* __restrict__ idx) {
+  constexpr int V = Vec16<T>::N;
+  const int OH = H / 2, OW = W / 2, cpr = C / V;
+  const int64_t total = (int64_t)B * OH * OW * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    int64_t p = i / cpr;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    float best[V];
+    uint8_t bi[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iy = oy * 2 + r - 1, ix = ox * 2 + s - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          float v[V];
+          Vec16<T>::load(x + (((int64_t)b * H + iy) * W + ix) * C + cc * V, v);
+#pragma unroll
+          for (int k = 0; k < V; ++k)
+            if (v[k] > best[k]) { best[k] = v[k]; bi[k] = (uint8_t)(r * 3 + s); }   // first max wins
+        }
+      }
+    Vec16<T>::store(y + i * V, best);
+    uint8_t* ip = idx + i * V;
+#pragma unroll
+    for (int k = 0; k < V; ++k) ip[k] = bi[k];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          int B, int H, int W, int C, T* __restrict__ dx) {
+  constexpr int V = Vec16<T>::N;
+  const int OH = H / 2, OW = W / 2, cpr = C / V;
+  const int64_t total = (int64_t)B * H * W * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    int64_t p = i / cpr;
+    const int ix = (int)(p % W); p /= W;
+    const int iy = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    // output windows containing (iy, ix): oy in {(iy+1)/2 - ...}: oy*2 + r - 1 == iy, r in 0..2
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int t = iy + 1 - r;
+      if (t < 0 || (t & 1)) continue;
+      const int oy = t >> 1;
+      if (oy >= OH) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int u = ix + 1 - s;
+        if (u < 0 || (u & 1)) continue;
+        const int ox = u >> 1;
+        if (ox >= OW) continue;
+        const int64_t o = ((((int64_t)b * OH + oy) * OW + ox) * cpr + cc) * V;
+        float g[V];
+        Vec16<T>::load(dy + o, g);
+        const uint8_t* ip = idx + o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += (ip[k] == (uint8_t)(r * 3 + s)) ? g[k] : 0.f;
+      }
+    }
+    Vec16<T>::store(dx + i * V, acc);
+  }
+}
+
+// ------------------------------------------------------------------ global average pool
+template <typename T>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ out) {
+  constexpr int V = Vec16<T>::N;
+  const int b = blockIdx.y, cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc * V >= C) return;
+  float acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
+  const T* p = x + (int64_t)b * HW * C + cc * V;
+  for (int i = 0; i < HW; ++i) {
+    float v[V];
+    Vec16<T>::load(p + (int64_t)i * C, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) out[(int64_t)b * C + cc * V + k] = acc[k] / (float)HW;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dfeat, int HW, int C, int64_t total_chunks,
+                                                      T* __restrict__ dx) {
+  constexpr int V = Vec16<T>::N;
+  const int cpr = C / V;
+  const float inv = 1.0f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    const int64_t b = i / ((int64_t)cpr * HW);
+    float v[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = dfeat[b * C + cc * V + k] * inv;
+    Vec16<T>::store(dx + i * V, v);
+  }
+}
+
+// ------------------------------------------------------------------ layout transforms
+// NCHW fp32 image -> zero-padded NHWC4 [B, H+8, W+6, 4] (image at rows 3.., cols 3..)
+template <typename T>
+__global__ __launch_bounds__(256) void image_pad_kernel(const float* __restrict__ x, int B, int H, int W, T* __restrict__ y) {
+  const int PH = H + 8, PW = W + 6;
+  const int64_t total = (int64_t)B * PH * PW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int px = (int)(i % PW);
+    const int py = (int)((i / PW) % PH);
+    const int b = (int)(i / ((int64_t)PW * PH));
+    const int iy = py - 3, ix = px - 3;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = x[(((int64_t)b * 3 + c) * H + iy) * W + ix];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ElemIO<T>::st(y + i * 4 + c, v[c]);
+  }
+}
+
+// OIHW fp32 -> [O][r][s][I] (forward) and [I][r][s][O] (data gradient), in the compute dtype
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, int O, int I, int kh, int kw,
+                                                          T* __restrict__ w_krsc, T* __restrict__ w_crsk) {
+  const int64_t total = (int64_t)O * I * kh * kw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // i enumerates the KRSC layout (coalesced writes)
+    const int c = (int)(i % I);
+    int64_t t = i / I;
+    const int s = (int)(t % kw); t /= kw;
+    const int r = (int)(t % kh);
+    const int o = (int)(t / kh);
+    const float v = w[(((int64_t)o * I + c) * kh + r) * kw + s];
+    ElemIO<T>::st(w_krsc + i, v);
+    if (w_crsk) ElemIO<T>::st(w_crsk + (((int64_t)c * kh + r) * kw + s) * O + o, v);
+  }
+}
+
+// stem: OIHW [64,3,7,7] -> [64][8][32] with k = r*32 + s*4 + c (zero padded)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_weight_prep_kernel(const float* __restrict__ w, T* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 256) return;
+  const int o = i >> 8, k = i & 255, r = k >> 5, s = (k & 31) >> 2, c = k & 3;
+  const float v = (r < 7 && s < 7 && c < 3) ? w[((o * 3 + c) * 7 + r) * 7 + s] : 0.f;
+  ElemIO<T>::st(out + i, v);
+}
+
+// NHWC (compute dtype) -> NCHW fp32 (to hand `base_out` back in the reference's layout)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, int B, int HW, int C, float* __restrict__ y) {
+  const int64_t total = (int64_t)B * HW * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int64_t b = i / ((int64_t)HW * C);
+    y[i] = ElemIO<T>::ld(x + (b * HW + p) * C + c);
+  }
+}
+
+// ------------------------------------------------------------------ host
+static inline unsigned ew_blocks(int64_t total_threads_needed, int64_t mult) {
+  int64_t b = (total_threads_needed + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  // make blocks*256 a multiple of `mult` (mult is a power of two <= 512)
+  const int64_t q = mult > 256 ? mult / 256 : 1;
+  b = (b + q - 1) / q * q;
+  return (unsigned)b;
+}
+
+#define DISPATCH_T(dtype, EXPR_F32, EXPR_BF16)          \
+  do {                                                  \
+    if ((dtype) == CREID_F32) { EXPR_F32; }             \
+    else if ((dtype) == CREID_BF16) { EXPR_BF16; }      \
+    else return CREID_E_DTYPE;                          \
+  } while (0)
+
+extern "C" {
+
+int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t count, float* running_mean,
+                        float* running_var, int training, float momentum, float eps, float* mean_out,
+                        float* invstd_out, void* stream) {
+  CREID_CHECK_ARG(C > 0 && mean_out && invstd_out && (training ? (partial && rows > 0 && count > 0) : (running_mean && running_var)));
+  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), partial,
+                     (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, mean_out,
+                     invstd_out);
+  CREID_LAUNCH_RET();
+}
+
+int64_t creid_col_stats_rows(int64_t M) { int64_t r = (M + 511) / 512; return r < 1 ? 1 : r; }
+
+int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* partial, void* stream) {
+  CREID_CHECK_ARG(x && partial && M > 0 && C > 0 && C % 8 == 0);
+  const int rows = (int)creid_col_stats_rows(M);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(col_stats_kernel<float>, dim3((unsigned)((C + 127) / 128), rows), dim3(256), 0, s,
+                                (const float*)x, M, (int)C, 512, partial),
+             hipLaunchKernelGGL(col_stats_kernel<unsigned short>, dim3((unsigned)((C + 255) / 256), rows), dim3(256), 0,
+                                s, (const unsigned short*)x, M, (int)C, 512, partial));
+  CREID_LAUNCH_RET();
+}
+
+int creid_bn2d_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const void* residual, int relu, int64_t M, int64_t C, int dtype, void* y, void* stream) {
+  CREID_CHECK_ARG(x && mean && invstd && y && M > 0 && C > 0 && C % 8 == 0);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
+                                (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, M, (int)C, (float*)y),
+             hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+                                (const unsigned short*)x, mean, invstd, gamma, beta, (const unsigned short*)residual, relu, M,
+                                (int)C, (unsigned short*)y));
+  CREID_LAUNCH_RET();
+}
+
+int64_t creid_bn2d_bwd_rows(int64_t M) { int64_t r = (M + 511) / 512; return r < 1 ? 1 : r; }
+
+int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
+                   const float* gamma, int64_t M, int64_t C, int dtype, float* partial, float* sums, float* dgamma_accum,
+                   float* dbeta_accum, void* dx, void* gm_out, void* stream) {
+  CREID_CHECK_ARG(x && g && mean && invstd && partial && sums && dx && M > 0 && C > 0 && C % 8 == 0);
+  const int rows = (int)creid_bn2d_bwd_rows(M);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<float>, dim3((unsigned)((C + 127) / 128), rows), dim3(256), 0, s,
+                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 512, partial),
+             hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C + 255) / 256), rows), dim3(256),
+                                0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
+                                invstd, M, (int)C, 512, partial));
+  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, partial, rows, (int)C,
+                     sums, dgamma_accum, dbeta_accum);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
+                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, gamma, sums, M, (int)C,
+                                (float*)dx, (float*)gm_out),
+             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+                                (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean, invstd,
+                                gamma, sums, M, (int)C, (unsigned short*)dx, (unsigned short*)gm_out));
+  CREID_LAUNCH_RET();
+}
+
+int creid_maxpool3x3s2_fwd(const void* x, int64_t B, int64_t H, int64_t W, int64_t C, int dtype, void* y, uint8_t* idx,
+                           void* stream) {
+  CREID_CHECK_ARG(x && y && idx && B > 0 && H > 0 && W > 0 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(B * H * W * C / 16, 1)), dim3(256), 0, s,
+                                (const float*)x, (int)B, (int)H, (int)W, (int)C, (float*)y, idx),
+             hipLaunchKernelGGL(maxpool_fwd_kernel<unsigned short>, dim3(ew_blocks(B * H * W * C / 32, 1)), dim3(256), 0, s,
+                                (const unsigned short*)x, (int)B, (int)H, (int)W, (int)C, (unsigned short*)y, idx));
+  CREID_LAUNCH_RET();
+}
+
+int creid_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, int64_t B, int64_t H, int64_t W, int64_t C, int dtype,
+                           void* dx, void* stream) {
+  CREID_CHECK_ARG(dy && dx && idx && B > 0 && H > 0 && W > 0 && C % 8 == 0);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_blocks(B * H * W * C / 4, 1)), dim3(256), 0, s,
+                                (const float*)dy, idx, (int)B, (int)H, (int)W, (int)C, (float*)dx),
+             hipLaunchKernelGGL(maxpool_bwd_kernel<unsigned short>, dim3(ew_blocks(B * H * W * C / 8, 1)), dim3(256), 0, s,
+                                (const unsigned short*)dy, idx, (int)B, (int)H, (int)W, (int)C, (unsigned short*)dx));
+  CREID_LAUNCH_RET();
+}
+
+int creid_gap_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* feat, void* stream) {
+  CREID_CHECK_ARG(x && feat && B > 0 && HW > 0 && C % 8 == 0);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((unsigned)((C / 4 + 255) / 256), (unsigned)B), dim3(256), 0, s,
+                                (const float*)x, (int)HW, (int)C, feat),
+             hipLaunchKernelGGL(gap_fwd_kernel<unsigned short>, dim3((unsigned)((C / 8 + 255) / 256), (unsigned)B),
+                                dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, feat));
+  CREID_LAUNCH_RET();
+}
+
+int creid_gap_bwd(const float* dfeat, int64_t B, int64_t HW, int64_t C, int dtype, void* dx, void* stream) {
+  CREID_CHECK_ARG(dfeat && dx && B > 0 && HW > 0 && C % 8 == 0);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(ew_blocks(B * HW * C / 4, 1)), dim3(256), 0, s, dfeat, (int)HW,
+                                (int)C, B * HW * C / 4, (float*)dx),
+             hipLaunchKernelGGL(gap_bwd_kernel<unsigned short>, dim3(ew_blocks(B * HW * C / 8, 1)), dim3(256), 0, s, dfeat,
+                                (int)HW, (int)C, B * HW * C / 8, (unsigned short*)dx));
+  CREID_LAUNCH_RET();
+}
+
+int creid_image_to_nhwc4_pad(const float* x_nchw, int64_t B, int64_t H, int64_t W, int dtype, void* xpad, void* stream) {
+  CREID_CHECK_ARG(x_nchw && xpad && B > 0 && H > 0 && W > 0);
+  hipStream_t s = as_stream(stream);
+  const int64_t total = B * (H + 8) * (W + 6);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(image_pad_kernel<float>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, x_nchw, (int)B, (int)H,
+                                (int)W, (float*)xpad),
+             hipLaunchKernelGGL(image_pad_kernel<unsigned short>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, x_nchw, (int)B,
+                                (int)H, (int)W, (unsigned short*)xpad));
+  CREID_LAUNCH_RET();
+}
+
+int creid_weight_prep(const float* w_oihw, int64_t O, int64_t I, int64_t kh, int64_t kw, int dtype, void* w_krsc,
+                      void* w_crsk, void* stream) {
+  CREID_CHECK_ARG(w_oihw && w_krsc && O > 0 && I > 0 && kh > 0 && kw > 0);
+  hipStream_t s = as_stream(stream);
+  const int64_t total = O * I * kh * kw;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, w_oihw, (int)O, (int)I,
+                                (int)kh, (int)kw, (float*)w_krsc, (float*)w_crsk),
+             hipLaunchKernelGGL(weight_prep_kernel<unsigned short>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, w_oihw,
+                                (int)O, (int)I, (int)kh, (int)kw, (unsigned short*)w_krsc, (unsigned short*)w_crsk));
+  CREID_LAUNCH_RET();
+}
+
+int creid_stem_weight_prep(const float* w_oihw, int dtype, void* w_stem, void* stream) {
+  CREID_CHECK_ARG(w_oihw && w_stem);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(stem_weight_prep_kernel<float>, dim3(64), dim3(256), 0, s, w_oihw, (float*)w_stem),
+             hipLaunchKernelGGL(stem_weight_prep_kernel<unsigned short>, dim3(64), dim3(256), 0, s, w_oihw,
+                                (unsigned short*)w_stem));
+  CREID_LAUNCH_RET();
+}
+
+int creid_nhwc_to_nchw_f32(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* y, void* stream) {
+  CREID_CHECK_ARG(x && y && B > 0 && HW > 0 && C > 0);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_blocks(B * HW * C, 1)), dim3(256), 0, s, (const float*)x,
+                                (int)B, (int)HW, (int)C, y),
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<unsigned short>, dim3(ew_blocks(B * HW * C, 1)), dim3(256), 0, s,
+                                (const unsigned short*)x, (int)B, (int)HW, (int)C, y));
+  CREID_LAUNCH_RET();
+}
+
+}  // extern "C"

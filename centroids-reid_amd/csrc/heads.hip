@@ -418,6 +418,25 @@ __global__ __launch_bounds__(256) void sgd_scaled_kernel(float* __restrict__ p, 
   }
 }
 
+
+// ======================================================================================
+// D2: per-PID gallery centroids for evaluation (modelling/bases.py:92-95,238-241):
+// out[s,:] = sum_{j in [off[s], off[s+1])} emb[order[j],:] / count   (rows summed in list order)
+// ======================================================================================
+__global__ __launch_bounds__(256) void gather_mean_rows_kernel(const float* __restrict__ emb,
+                                                               const int64_t* __restrict__ order,
+                                                               const int64_t* __restrict__ offsets, int D,
+                                                               float* __restrict__ out) {
+  const int s = blockIdx.x;
+  const int64_t j0 = offsets[s], j1 = offsets[s + 1];
+  const float cnt = (float)(j1 - j0);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    for (int64_t j = j0; j < j1; ++j) acc += emb[order[j] * D + d];
+    out[(int64_t)s * D + d] = acc / cnt;
+  }
+}
+
 // ======================================================================================
 extern "C" {
 
@@ -506,6 +525,14 @@ int creid_bn1d_bwd(const float* x, const float* dy, int64_t B, int64_t D, const 
   CREID_CHECK_ARG(x && dy && save_mean && save_invstd && dx_accum && B > 0 && D > 0);
   hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, as_stream(stream), x, dy,
                      (int)B, (int)D, weight, save_mean, save_invstd, dx_accum, dweight_accum, dbias_accum);
+  CREID_LAUNCH_RET();
+}
+
+int creid_gather_mean_rows(const float* emb, const int64_t* order, const int64_t* offsets, int64_t n_seg, int64_t D,
+                           float* out, void* stream) {
+  CREID_CHECK_ARG(emb && order && offsets && out && n_seg > 0 && D > 0);
+  hipLaunchKernelGGL(gather_mean_rows_kernel, dim3((unsigned)n_seg), dim3(256), 0, as_stream(stream), emb, order,
+                     offsets, (int)D, out);
   CREID_LAUNCH_RET();
 }
 

@@ -1,0 +1,121 @@
+"""Optimisers / scheduler of the reference (solver/build.py:9-63) on fused HIP steps.
+
+build_optimizer keeps the reference's grouping rule (everything whose name contains "center" goes to a
+plain SGD(lr=CENTER_LR); the rest to Adam(lr=BASE_LR, weight_decay=WEIGHT_DECAY), parameters with
+requires_grad=False skipped, extra "names" key in the param groups).  The Adam group lives in ONE flat
+fp32 buffer (parameters and gradients are views into it), so a step is a single kernel and the same
+buffer is what the data-parallel all-reduce sends over RCCL.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def flatten_(params, device):
+    """Re-home `params` (list of nn.Parameter) as views of one flat fp32 buffer; returns (flat, gflat)."""
+    n = sum(p.numel() for p in params)
+    n_pad = (n + 3) // 4 * 4
+    flat = torch.zeros(n_pad, dtype=torch.float32, device=device)
+    gflat = torch.zeros(n_pad, dtype=torch.float32, device=device)
+    off = 0
+    for p in params:
+        k = p.numel()
+        off_al = off
+        flat[off_al:off_al + k].copy_(p.data.reshape(-1))
+        p.data = flat[off_al:off_al + k].view(p.shape)
+        p.grad = gflat[off_al:off_al + k].view(p.shape)
+        off += k
+    return flat, gflat
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (L2 weight decay in the gradient) -- one kernel over the flat buffer."""
+
+    def __init__(self, param_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(param_groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        params = [p for g in self.param_groups for p in g["params"]]
+        assert len(self.param_groups) == 1
+        self.flat, self.gflat = flatten_(params, params[0].device)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
+        self.grad_scale = 1.0
+        off = 0
+        for p in params:   # torch-compatible per-parameter state (views) for checkpoints
+            k = p.numel()
+            self.state[p] = dict(step=torch.tensor(0.0), exp_avg=self.exp_avg[off:off + k].view(p.shape),
+                                 exp_avg_sq=self.exp_avg_sq[off:off + k].view(p.shape))
+            off += k
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.gflat.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self.step_count += 1
+        for st in self.state.values():
+            st["step"] += 1
+        b1, b2 = g["betas"]
+        L.check(L.lib().creid_adam_step(L.ptr(self.flat), L.ptr(self.gflat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                        self.flat.numel(), float(g["lr"]), b1, b2, g["eps"], g["weight_decay"],
+                                        self.step_count, float(self.grad_scale), L.stream()), "creid_adam_step")
+
+
+class CenterSGD(torch.optim.Optimizer):
+    """SGD(lr=CENTER_LR) for CenterLoss.centers with the reference's in-place gradient rescale
+    (train_ctl_model.py:157-159) folded into the same kernel: g *= grad_mul; p -= lr * g."""
+
+    def __init__(self, param_groups, lr=0.5):
+        super().__init__(param_groups, dict(lr=lr))
+        self.grad_mul = 1.0
+
+    def zero_grad(self, set_to_none: bool = False):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                else:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                L.check(L.lib().creid_sgd_scaled_step(L.ptr(p.data), L.ptr(p.grad), p.numel(), float(g["lr"]),
+                                                      float(self.grad_mul), L.stream()), "creid_sgd_scaled_step")
+        self.grad_mul = 1.0
+
+
+def build_optimizer(named_parameters, hparams):
+    """solver/build.py:9-47."""
+    regular, regular_names, center, center_names = [], [], [], []
+    for name, parameter in named_parameters:
+        if parameter.requires_grad is False:
+            print(f"Parameter {name} does not need a Grad. Excluding from the optimizer...")
+            continue
+        elif "center" in name:
+            center.append(parameter); center_names.append(name)
+        else:
+            regular.append(parameter); regular_names.append(name)
+    if hparams.SOLVER.OPTIMIZER_NAME != "Adam":
+        raise NotImplementedError(f"No such optimizer {hparams.SOLVER.OPTIMIZER_NAME}")
+    model_optimizer = FusedAdam([{"params": regular, "names": regular_names}], lr=hparams.SOLVER.BASE_LR,
+                                weight_decay=hparams.SOLVER.WEIGHT_DECAY)
+    optimizer_center = CenterSGD([{"params": center, "names": center_names}], lr=hparams.SOLVER.CENTER_LR)
+    return [model_optimizer, optimizer_center]
+
+
+def build_scheduler(model_optimizer, hparams):
+    """solver/build.py:50-63."""
+    if hparams.SOLVER.LR_SCHEDULER_NAME == "cosine_annealing":
+        return torch.optim.lr_scheduler.CosineAnnealingLR(model_optimizer, hparams.SOLVER.MAX_EPOCHS,
+                                                          eta_min=hparams.SOLVER.MIN_LR)
+    elif hparams.SOLVER.LR_SCHEDULER_NAME == "multistep_lr":
+        return torch.optim.lr_scheduler.MultiStepLR(model_optimizer, milestones=hparams.SOLVER.LR_STEPS,
+                                                    gamma=hparams.SOLVER.GAMMA)
+    raise NotImplementedError(f"No such scheduler {hparams.SOLVER.LR_SCHEDULER_NAME}")

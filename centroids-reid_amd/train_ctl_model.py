@@ -1,0 +1,113 @@
+"""train_ctl_model.py:27-179 CTLModel -- the centroid-triplet training step on the HIP kernels.
+
+Same class name, constructor, `losses_names`, `training_step(batch, batch_idx, optimizer_idx=None)`
+signature and return value `{"loss": ..., "other": {"step_dist_ap", "step_dist_an",
+"l2_mean_centroid"}}` as the reference.  Differences that are deliberate and documented in DESIGN.md:
+  * the batch is PID-contiguous [P, K] (the reference assumes the same at :80), so P = B / K is known
+    on the host and the round masks come from `isReal` alone -- no D2H sync for np.unique / masks;
+  * a centroid is dropped from a round iff it has no real member (the reference tests
+    |centroid|_1 > 1e-7, which differs only for an exactly-zero mean);
+  * the seven per-step `float()` host syncs are deferred: the logged values are 0-dim device tensors
+    (they still convert with float()).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .bases import ModelBase
+
+
+class CTLModel(ModelBase):
+    def __init__(self, cfg=None, **kwargs):
+        super().__init__(cfg, **kwargs)
+        self.losses_names = ["query_xent", "query_triplet", "query_center", "centroid_triplet"]
+        self.losses_dict = {n: [] for n in self.losses_names}
+        self.grad_sync = None          # optional callable(model) run between backward and the optimiser steps
+
+    def training_step(self, batch, batch_idx, optimizer_idx=None):
+        hp = self.hparams
+        opt, opt_center = self.optimizers(use_pl_optimizer=True)
+        if hp.SOLVER.USE_WARMUP_LR:                                           # :41-49
+            if self.trainer.current_epoch < hp.SOLVER.WARMUP_EPOCHS:
+                lr_scale = min(1.0, float(self.trainer.current_epoch + 1) / float(hp.SOLVER.WARMUP_EPOCHS))
+                for pg in opt.param_groups:
+                    pg["lr"] = lr_scale * hp.SOLVER.BASE_LR
+        opt_center.zero_grad()
+        opt.zero_grad()
+
+        x, class_labels, camid, isReal = batch
+        K = hp.DATALOADER.NUM_INSTANCE
+        B = x.shape[0]
+        assert B % K == 0, "batch must be PID-contiguous [P, K] (datasets/bases.py:447-455 collate)"
+        P = B // K
+        dev = x.device
+        ir_host = np.asarray(isReal.cpu() if isinstance(isReal, torch.Tensor) else isReal, dtype=bool)
+        all_real = bool(ir_host.all())
+        is_real = (isReal if isinstance(isReal, torch.Tensor) else torch.as_tensor(ir_host)).to(dev, non_blocking=True)
+        class_labels = class_labels.to(dev, non_blocking=True)
+
+        _, features = self.backbone(x)                                        # :59
+
+        contrastive_loss_query, _, _ = self.contrastive_loss(features, class_labels,
+                                                             mask=None if all_real else is_real)  # :62-67
+        contrastive_loss_query = contrastive_loss_query * hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT
+        if all_real:
+            class_labels_real, features_real = class_labels, features
+        else:
+            ridx = torch.as_tensor(np.nonzero(ir_host)[0], device=dev)
+            class_labels_real, features_real = class_labels.index_select(0, ridx), features.index_select(0, ridx)
+        center_loss = hp.SOLVER.CENTER_LOSS_WEIGHT * self.center_loss(features_real, class_labels_real)  # :71-73
+        bn_features = self.bn(features_real)
+        cls_score = self.fc_query(bn_features)
+        xent_query = self.xent(cls_score, class_labels_real) * hp.SOLVER.QUERY_XENT_WEIGHT          # :74-77
+
+        # ---- leave-one-out centroids (:79-104) and the K centroid rounds (:112-148)
+        centroids_emb, _valid = ops.LooCentroids.apply(features, is_real, P, K)
+        ir2 = ir_host.reshape(P, K)
+        labels_pk = class_labels.view(P, K)
+        feats_pk = features.view(P, K, -1)
+        losses, aps, ans, norms = [], [], [], []
+        for i in range(K):
+            others = ir2.copy(); others[:, i] = False
+            valid_p = ir2[:, i] & (others.sum(1) > 0)                       # centroid exists for pid p
+            if int(valid_p.sum()) <= 1:                                        # :113-114
+                continue
+            q_p = ir2[:, i]                                                    # real i-th instances = queries
+            if not np.array_equal(q_p, valid_p):
+                raise RuntimeError("query/centroid count mismatch in a centroid round (the reference fails in "
+                                   "labels.expand at losses/triplet_loss.py:88)")
+            if q_p.all():
+                query_feat, cur_labels, cur_cent = feats_pk[:, i], labels_pk[:, i], centroids_emb[i]
+            else:
+                sel = torch.as_tensor(np.nonzero(q_p)[0], device=dev)
+                query_feat = feats_pk[:, i].index_select(0, sel)
+                cur_labels = labels_pk[:, i].index_select(0, sel)
+                cur_cent = centroids_emb[i].index_select(0, sel)
+            emb = torch.cat((query_feat, cur_cent))
+            lab = torch.cat((cur_labels, cur_labels))
+            loss_i, dap, dan, stats = ops.TripletHardMine.apply(emb, lab, None, self.contrastive_loss.margin)
+            losses.append(loss_i); aps.append(stats[1]); ans.append(stats[2])
+            norms.append(torch.linalg.vector_norm(cur_cent.detach(), dim=1).mean())
+        contrastive_loss_step = torch.mean(torch.stack(losses)) * hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT
+        dist_ap = torch.mean(torch.stack(aps))
+        dist_an = torch.mean(torch.stack(ans))
+        l2_mean_norm_total = torch.mean(torch.stack(norms))
+
+        total_loss = contrastive_loss_step + center_loss + xent_query + contrastive_loss_query       # :150-152
+        self.manual_backward(total_loss, optimizer=opt)
+        if self.grad_sync is not None:
+            self.grad_sync(self)                                               # data-parallel all-reduce (RCCL)
+        opt.step()
+        eng = getattr(self.backbone, "_engine", None)
+        if eng is not None:
+            eng.weights_dirty = True
+        opt_center.grad_mul = 1.0 / hp.SOLVER.CENTER_LOSS_WEIGHT               # :157-158 (fused into the step)
+        opt_center.step()
+
+        for name, val in zip(self.losses_names, (xent_query, contrastive_loss_query, center_loss, contrastive_loss_step)):
+            self.losses_dict[name].append(val.detach())
+        log_data = {"step_dist_ap": dist_ap.detach(), "step_dist_an": dist_an.detach(),
+                    "l2_mean_centroid": l2_mean_norm_total.detach()}
+        return {"loss": total_loss.detach(), "other": log_data}

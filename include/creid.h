@@ -132,6 +132,11 @@ int creid_bn1d_bwd(const float* x, const float* dy, int64_t B, int64_t D, const 
                    const float* save_mean, const float* save_invstd, float* dx_accum,
                    float* dweight_accum, float* dbias_accum, void* stream);
 
+/* modelling/bases.py:92-95,238-241 (validation_create_centroids): out[s,:] = mean of the rows
+ * emb[order[j],:], j in [offsets[s], offsets[s+1]) (summed in list order). */
+int creid_gather_mean_rows(const float* emb, const int64_t* order, const int64_t* offsets,
+                           int64_t n_seg, int64_t D, float* out, void* stream);
+
 /* ------------------------------------------------------------------ optimiser steps */
 
 /* solver/build.py:36-39 torch.optim.Adam (L2 weight decay added to the gradient, bias correction,
@@ -151,6 +156,76 @@ int creid_sgd_scaled_step(float* p, float* g, int64_t n, float lr, float grad_mu
 int creid_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                    float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, float beta,
                    int32_t split_k, void* stream);
+
+/* ------------------------------------------------------------------ stage A: backbone layers */
+
+/* Convolution geometry (NHWC activations; square kernels 1x1 / 3x3, stride 1 or 2; channel counts
+ * powers of two >= 64 -- every non-stem convolution of modelling/backbones/resnet.py:51-120). */
+typedef struct {
+  int64_t batch, in_h, in_w, in_c, out_h, out_w, out_c;
+  int32_t kh, kw, stride, pad;
+} creid_conv_desc;
+
+/* nn.Conv2d forward (resnet.py:56-61,109): y[b,oy,ox,n] = sum_{r,s,c} x[b,oy*st+r-pad,ox*st+s-pad,c] *
+ * w_krsc[n,r,s,c]; im2col-free implicit GEMM on the MFMA pipe (bf16 -> fp32 accumulate, or exact f32).
+ * bn_partial (nullable) receives per-128-row-tile (sum, sumsq) of the fp32 accumulators,
+ * float [creid_conv2d_bn_partial_rows(d)][2][out_c], for the BatchNorm that follows. */
+int64_t creid_conv2d_bn_partial_rows(const creid_conv_desc* d);
+int creid_conv2d_fwd_nhwc(const creid_conv_desc* d, const void* x, const void* w_krsc, void* y,
+                          float* bn_partial, int dtype, void* stream);
+/* data gradient: dx = conv_transpose(dy, w) (+ add_src if non-NULL); w_crsk is [in_c][kh][kw][out_c]. */
+int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
+                            const void* add_src, int dtype, void* stream);
+/* weight gradient into the fp32 OIHW tensor (the reference's nn.Parameter layout), optionally
+ * accumulating; the pixel reduction is split over workgroups through `ws`. */
+size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype);
+int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw,
+                            int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* Stem (resnet.py:94): Conv2d(3, 64, 7, stride 2, pad 3) on the zero-padded NHWC4 image
+ * xpad [B, H+8, W+6, 4] made by creid_image_to_nhwc4_pad; w_stem [64][8][32] from creid_stem_weight_prep. */
+int creid_stem_conv_fwd(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* w_stem, void* y,
+                        float* bn_partial, int dtype, void* stream);
+size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype);
+int creid_stem_conv_wgrad(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* dy,
+                          float* dw_oihw, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);
+int creid_image_to_nhwc4_pad(const float* x_nchw, int64_t B, int64_t H, int64_t W, int dtype, void* xpad,
+                             void* stream);
+/* fp32 OIHW master weights -> compute-dtype [O][r][s][I] (forward) and [I][r][s][O] (dgrad, nullable). */
+int creid_weight_prep(const float* w_oihw, int64_t O, int64_t I, int64_t kh, int64_t kw, int dtype,
+                      void* w_krsc, void* w_crsk, void* stream);
+int creid_stem_weight_prep(const float* w_oihw, int dtype, void* w_stem, void* stream);
+
+/* nn.BatchNorm2d (resnet.py:57-62,96,111; momentum 0.1, eps 1e-5) split in three steps:
+ * finalize: partial (sum,sumsq) rows -> mean / invstd (+ running-stat update, unbiased variance) when
+ * training, or mean = running_mean, invstd = rsqrt(running_var + eps) in eval;
+ * apply: y = (x - mean) * invstd * gamma + beta (+ residual) (ReLU if relu) -- the fused
+ * BN + residual-add + ReLU tail of Bottleneck.forward (resnet.py:72-85);
+ * bwd: dy = g * [act > 0] (act nullable); dgamma += sum dy*xhat; dbeta += sum dy;
+ *      dx = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)); gm_out (nullable) = dy. */
+int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t count, float* running_mean,
+                        float* running_var, int training, float momentum, float eps, float* mean_out,
+                        float* invstd_out, void* stream);
+int64_t creid_col_stats_rows(int64_t M);
+int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* partial, void* stream);
+int creid_bn2d_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, const void* residual, int relu, int64_t M, int64_t C, int dtype,
+                     void* y, void* stream);
+int64_t creid_bn2d_bwd_rows(int64_t M);
+int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
+                   const float* gamma, int64_t M, int64_t C, int dtype, float* partial, float* sums,
+                   float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out, void* stream);
+
+/* nn.MaxPool2d(3, 2, 1) (resnet.py:98) NHWC, with the argmax tap saved for the backward. */
+int creid_maxpool3x3s2_fwd(const void* x, int64_t B, int64_t H, int64_t W, int64_t C, int dtype, void* y,
+                           uint8_t* idx, void* stream);
+int creid_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, int64_t B, int64_t H, int64_t W, int64_t C,
+                           int dtype, void* dx, void* stream);
+/* nn.AdaptiveAvgPool2d(1) (modelling/baseline.py:89,93): feat fp32 [B, C]. */
+int creid_gap_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* feat, void* stream);
+int creid_gap_bwd(const float* dfeat, int64_t B, int64_t HW, int64_t C, int dtype, void* dx, void* stream);
+/* NHWC compute dtype -> NCHW fp32 (to return `base_out` in the reference's layout). */
+int creid_nhwc_to_nchw_f32(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* y, void* stream);
 
 #ifdef __cplusplus
 }

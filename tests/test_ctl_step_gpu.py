@@ -1,0 +1,108 @@
+"""GPU parity: CTLModel.training_step (train_ctl_model.py:38-179) -- heads against the golden vectors
+recorded from the reference's own training_step, and the full fp32 model against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class FeatStub(torch.nn.Module):
+    def __init__(self, feats):
+        super().__init__()
+        self.feats = torch.nn.Parameter(feats.clone())
+
+    def forward(self, x):
+        return None, self.feats * 1.0
+
+
+def _cfg(D, K, margin):
+    from centroids_reid_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    cfg.MODEL.PRETRAINED = False
+    cfg.MODEL.BACKBONE_EMB_SIZE = D
+    cfg.DATALOADER.NUM_INSTANCE = K
+    cfg.SOLVER.MARGIN = margin
+    cfg.USE_MIXED_PRECISION = False
+    return cfg
+
+
+@pytest.mark.parametrize("name", ["heads_p16k4_d128", "heads_p16k4_d128_fake1", "heads_p16k4_d128_fake2", "heads_p8k4_d2048"])
+def test_training_step_heads_golden(golden, name):
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    g = golden(name)
+    P, K, C = int(g["P"]), int(g["K"]), int(g["C"])
+    D = g["feats"].shape[1]
+    model = CTLModel(_cfg(D, K, float(g["margin"])), num_classes=C, num_query=0)
+    model.backbone = FeatStub(torch.from_numpy(g["feats"]))
+    with torch.no_grad():
+        model.center_loss.centers.copy_(torch.from_numpy(g["centers0"]))
+        model.fc_query.weight.copy_(torch.from_numpy(g["fc0"]))
+        model.bn.weight.copy_(torch.from_numpy(g["bn_w0"]))
+    model = model.cuda().train()
+    model.configure_optimizers()
+    batch = (torch.zeros(P * K, 3, 8, 4, device="cuda"), torch.from_numpy(g["labels"]).cuda(),
+             torch.zeros(P * K, dtype=torch.int64), torch.from_numpy(g["is_real"]))
+    nsteps = 2 if "s1_loss_total" in g else 1
+    for s in range(nsteps):
+        out = model.training_step(batch, s)
+        assert abs(float(out["loss"]) - float(g[f"s{s}_loss_total"])) < 3e-5
+        for n in model.losses_names:
+            assert abs(float(model.losses_dict[n][-1]) - float(g[f"s{s}_{n}"])) < 3e-5, n
+        for k, v in out["other"].items():
+            assert abs(float(v) - float(g[f"s{s}_{k}"])) < 3e-5, k
+        if s == 0:
+            np.testing.assert_allclose(model.backbone.feats.grad.cpu().numpy(), g["s0_grad_features"], rtol=1e-4, atol=1e-7)
+            np.testing.assert_allclose(model.fc_query.weight.grad.cpu().numpy(), g["s0_grad_fc"], rtol=1e-4, atol=1e-7)
+            np.testing.assert_allclose(model.bn.weight.grad.cpu().numpy(), g["s0_grad_bn_w"], rtol=1e-3, atol=1e-6)
+            np.testing.assert_allclose(model.center_loss.centers.grad.cpu().numpy(), g["s0_grad_centers_scaled"],
+                                       rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(model.center_loss.centers.detach().cpu().numpy(), g[f"s{s}_centers_after"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(model.fc_query.weight.detach().cpu().numpy(), g[f"s{s}_fc_after"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(model.bn.weight.detach().cpu().numpy(), g[f"s{s}_bn_w_after"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(model.bn.running_mean.cpu().numpy(), g[f"s{s}_bn_rm_after"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(model.bn.running_var.cpu().numpy(), g[f"s{s}_bn_rv_after"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(model.backbone.feats.detach().cpu().numpy(), g[f"s{s}_feats_after"], rtol=1e-5, atol=2e-6)
+
+
+def test_full_model_fp32_vs_oracle():
+    """Whole fp32 step (ResNet50 + heads) on a small PK batch vs the composed CPU oracle."""
+    from oracle import backbone_oracle as bo, reid_oracle as ro
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    torch.set_num_threads(32)
+    P, K, C, H, W = 4, 4, 20, 64, 32
+    model = CTLModel(_cfg(2048, K, 0.5), num_classes=C, num_query=0, compute_dtype=torch.float32)
+    sd = bo.make_state_dict("resnet50", 1, seed=77)
+    model.backbone.base.load_state_dict(sd)
+    rng = np.random.default_rng(5)
+    with torch.no_grad():
+        model.center_loss.centers.copy_(torch.from_numpy(rng.standard_normal((C, 2048)).astype(np.float32)) * 0.3)
+        model.fc_query.weight.copy_(torch.from_numpy((rng.standard_normal((C, 2048)) * 0.01).astype(np.float32)))
+    centers0 = model.center_loss.centers.detach().clone(); fc0 = model.fc_query.weight.detach().clone()
+    model = model.cuda().train()
+    model.configure_optimizers()
+    x = bo.synthetic_images(P * K, H, W, seed=3)
+    labels = torch.from_numpy(np.repeat(np.arange(P) * 3 % C, K).astype(np.int64))
+    is_real = torch.ones(P * K, dtype=torch.bool); is_real[6] = False
+    out = model.training_step((x.cuda(), labels.cuda(), torch.zeros(P * K, dtype=torch.int64), is_real), 0)
+    # oracle
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+    sd2 = {**{k: v.clone() for k, v in sd.items()}, **params}
+    _, feat = bo.backbone_forward(x, sd2, "resnet50", 1, training=True)
+    c = centers0.clone().requires_grad_(True); fc = fc0.clone().requires_grad_(True)
+    bw = torch.ones(2048, requires_grad=True)
+    o = ro.ctl_heads(feat, labels, is_real, bw, torch.zeros(2048), torch.zeros(2048), torch.ones(2048), fc, c, P, K)
+    o["total"].backward()
+    assert abs(float(out["loss"]) - o["total"].item()) < 2e-4, (float(out["loss"]), o["total"].item())
+    for n in ("query_xent", "query_triplet", "query_center", "centroid_triplet"):
+        assert abs(float(model.losses_dict[n][-1]) - o[n].item()) < 2e-4, n
+
+    def close(a, ref, rel=3e-2):
+        a = a.detach().cpu().double().numpy().ravel(); ref = ref.detach().double().numpy().ravel()
+        assert np.linalg.norm(a - ref) <= rel * np.linalg.norm(ref), np.linalg.norm(a - ref) / np.linalg.norm(ref)
+    close(model.fc_query.weight.grad, fc.grad)
+    close(model.backbone.base.layer4[2].conv3.weight.grad, params["layer4.2.conv3.weight"].grad)
+    close(model.backbone.base.layer2[0].conv2.weight.grad, params["layer2.0.conv2.weight"].grad)
+    close(model.backbone.base.conv1.weight.grad, params["conv1.weight"].grad)
+    close(model.backbone.base.layer1[0].bn1.weight.grad, params["layer1.0.bn1.weight"].grad)
