@@ -41,6 +41,7 @@ SIGNATURES = {
     "creid_bn1d_bwd": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "creid_gather_mean_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "creid_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p]),
+    "creid_adam_step_dev": (C.c_int, [_p, _p, _p, _p, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p]),
     "creid_sgd_scaled_step": (C.c_int, [_p, _p, _i64, _f32, _f32, _p]),
     "creid_conv2d_bn_partial_rows": (_i64, [_p]),
     "creid_conv2d_fwd_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p]),

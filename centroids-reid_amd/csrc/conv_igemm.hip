@@ -20,8 +20,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsi
                                                          const unsigned short* __restrict__ add_src,
                                                          float* __restrict__ bn_part, int tiles_n) {
   constexpr int BK = 64, TNW = BN / 64, NB = BN / 32;
-  __shared__ __attribute__((aligned(16))) unsigned short As[2][128 * BK];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * BK];
+  constexpr int CP = BN + 8;                                   // C-tile staging pitch (elements)
+  constexpr int LDS_ELEMS = (2 * 128 * BK + 2 * BN * BK) > (128 * CP) ? (2 * 128 * BK + 2 * BN * BK) : (128 * CP);
+  __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_ELEMS];
+  unsigned short (*As)[128 * BK] = reinterpret_cast<unsigned short (*)[128 * BK]>(smem);
+  unsigned short (*Bs)[BN * BK] = reinterpret_cast<unsigned short (*)[BN * BK]>(smem + 2 * 128 * BK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -110,32 +113,56 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsi
     __syncthreads();
   }
 
-  // ---- epilogue
-  float* red = reinterpret_cast<float*>(&As[0][0]);   // [2 (wm)][2 (s1,s2)][BN]
+  // ---- epilogue: per-channel (sum, sumsq) partials from the fp32 accumulators, then the C tile is
+  // staged through LDS (bf16) so that global stores (and the add_src reads) are 16-B coalesced rows.
+  float s1v[TNW], s2v[TNW];
 #pragma unroll
   for (int j = 0; j < TNW; ++j) {
     const int cl = wn * (BN / 2) + j * 32 + l31;
-    const int c = col0 + cl;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rr = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (rr < g.M) {
-          float v = acc[i][j][r];
-          if (add_src) v += bf16_bits_to_f32(add_src[(int64_t)rr * g.N + c]);
-          s1 += v; s2 = fmaf(v, v, s2);
-          out[(int64_t)rr * g.N + c] = f32_to_bf16_bits(v);
-        }
+        const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float v = acc[i][j][r];               // rows >= M were zero-filled -> contribute 0
+        s1 += v; s2 = fmaf(v, v, s2);
+        smem[rl * CP + cl] = f32_to_bf16_bits(v);
       }
     }
-    if (bn_part) {
-      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (kh == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    s1v[j] = s1; s2v[j] = s2;
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;                                  // 16-B chunks per tile row
+#pragma unroll
+  for (int i = 0; i < (128 * CPR) / 256; ++i) {
+    const int id = tid + 256 * i, rl = id / CPR, ch = id - rl * CPR;
+    const int rr = row0 + rl;
+    if (rr < g.M) {
+      uint4 v = *reinterpret_cast<const uint4*>(&smem[rl * CP + ch * 8]);
+      const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
+      if (add_src) {
+        const uint4 a = *reinterpret_cast<const uint4*>(add_src + off);
+        unsigned* vw = &v.x; const unsigned* aw = &a.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+          const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+          vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(out + off) = v;
     }
   }
   if (bn_part) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);      // [2 (wm)][2 (s1,s2)][BN]
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int cl = wn * (BN / 2) + j * 32 + l31;
+      if (kh == 0) { red[(wm * 2 + 0) * BN + cl] = s1v[j]; red[(wm * 2 + 1) * BN + cl] = s2v[j]; }
+    }
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += 256) {
       const int which = i / BN, cl = i - which * BN;

@@ -266,7 +266,7 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   p.tiles_k = K / p.tn;
   p.tiles = (NCO / p.tm) * p.tiles_k;
   const int ks = (dtype == CREID_BF16) ? WKS : WKF;
-  int splits = (1024 + p.tiles - 1) / p.tiles;
+  int splits = (512 + p.tiles - 1) / p.tiles;
   const int max_splits = (M + 4 * ks - 1) / (4 * ks);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -34,23 +34,39 @@ template <> struct Vec16<unsigned short> {
 // ------------------------------------------------------------------ BN statistics finalize
 // partial: [rows][2][C] (sum, sumsq per 128-row conv tile).  training: mean/invstd from the batch and
 // running-stat update (momentum, unbiased variance); eval: mean = running_mean, invstd = rsqrt(rv+eps).
-__global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+__global__ __launch_bounds__(512) void bn2d_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                             double count, float* __restrict__ rmean,
                                                             float* __restrict__ rvar, int training, float momentum,
                                                             float eps, float* __restrict__ mean_out,
                                                             float* __restrict__ invstd_out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  if (!training) { mean_out[c] = rmean[c]; invstd_out[c] = 1.0f / sqrtf(rvar[c] + eps); return; }
+  // 32 channels x 16 row-groups per workgroup: coalesced 128-B reads, fp64 accumulation, LDS tree
+  __shared__ double red[16][2][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  if (!training) {
+    if (rg == 0 && c < C) { mean_out[c] = rmean[c]; invstd_out[c] = 1.0f / sqrtf(rvar[c] + eps); }
+    return;
+  }
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < rows; ++r) { s1 += (double)partial[((int64_t)r * 2) * C + c]; s2 += (double)partial[((int64_t)r * 2 + 1) * C + c]; }
-  const double mean = s1 / count;
-  double var = s2 / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  mean_out[c] = (float)mean;
-  invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+  if (c < C)
+    for (int r = rg; r < rows; r += 16) {
+      s1 += (double)partial[((int64_t)r * 2) * C + c];
+      s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
+    }
+  red[rg][0][cl] = s1; red[rg][1][cl] = s2;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+  }
 }
 
 // stand-alone statistics (used when the producer is not a conv epilogue): partial[(blockIdx.y)][2][C]
@@ -58,29 +74,29 @@ template <typename T>
 __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, int64_t M, int C, int rows_per_block,
                                                         float* __restrict__ partial) {
   constexpr int V = Vec16<T>::N;
-  __shared__ float red[8][2][32 * V];
-  const int cch = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c0 = (blockIdx.x * 32 + cch) * V;
+  __shared__ float red[2][256 * V];        // [which][row-lane][chunk-lane * V]
+  const int cpr = C / V, cw = cpr < 32 ? cpr : 32, nrl = 256 / cw;     // cw chunk lanes x nrl row lanes
+  const int cch = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int c0 = (blockIdx.x * cw + cch) * V;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s1[V], s2[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
   if (c0 < C)
-    for (int64_t r = r0 + rl; r < r1; r += 8) {
+    for (int64_t r = r0 + rl; r < r1; r += nrl) {
       float v[V];
       Vec16<T>::load(x + r * C + c0, v);
 #pragma unroll
       for (int k = 0; k < V; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
     }
 #pragma unroll
-  for (int k = 0; k < V; ++k) { red[rl][0][cch * V + k] = s1[k]; red[rl][1][cch * V + k] = s2[k]; }
+  for (int k = 0; k < V; ++k) { red[0][(rl * cw + cch) * V + k] = s1[k]; red[1][(rl * cw + cch) * V + k] = s2[k]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * 32 * V; i += 256) {
-    const int which = i / (32 * V), cl = i - which * 32 * V;
+  for (int i = threadIdx.x; i < 2 * cw * V; i += 256) {
+    const int which = i / (cw * V), cl = i - which * cw * V;
     float a = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a += red[q][which][cl];
-    const int c = blockIdx.x * 32 * V + cl;
+    for (int q = 0; q < nrl; ++q) a += red[which][q * cw * V + cl];
+    const int c = blockIdx.x * cw * V + cl;
     if (c < C) partial[((int64_t)blockIdx.y * 2 + which) * C + c] = a;
   }
 }
@@ -132,9 +148,10 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
                                                               const float* __restrict__ invstd, int64_t M, int C,
                                                               int rows_per_block, float* __restrict__ partial) {
   constexpr int V = Vec16<T>::N;
-  __shared__ float red[8][2][32 * V];
-  const int cch = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c0 = (blockIdx.x * 32 + cch) * V;
+  __shared__ float red[2][256 * V];
+  const int cpr = C / V, cw = cpr < 32 ? cpr : 32, nrl = 256 / cw;
+  const int cch = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int c0 = (blockIdx.x * cw + cch) * V;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s1[V], s2[V], mu[V], is[V];
 #pragma unroll
@@ -142,7 +159,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
   if (c0 < C) {
 #pragma unroll
     for (int k = 0; k < V; ++k) { mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k]; }
-    for (int64_t r = r0 + rl; r < r1; r += 8) {
+    for (int64_t r = r0 + rl; r < r1; r += nrl) {
       float xv[V], gv[V];
       Vec16<T>::load(x + r * C + c0, xv);
       Vec16<T>::load(g + r * C + c0, gv);
@@ -157,29 +174,40 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
     }
   }
 #pragma unroll
-  for (int k = 0; k < V; ++k) { red[rl][0][cch * V + k] = s1[k]; red[rl][1][cch * V + k] = s2[k]; }
+  for (int k = 0; k < V; ++k) { red[0][(rl * cw + cch) * V + k] = s1[k]; red[1][(rl * cw + cch) * V + k] = s2[k]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * 32 * V; i += 256) {
-    const int which = i / (32 * V), cl = i - which * 32 * V;
+  for (int i = threadIdx.x; i < 2 * cw * V; i += 256) {
+    const int which = i / (cw * V), cl = i - which * cw * V;
     float a = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a += red[q][which][cl];
-    const int c = blockIdx.x * 32 * V + cl;
+    for (int q = 0; q < nrl; ++q) a += red[which][q * cw * V + cl];
+    const int c = blockIdx.x * cw * V + cl;
     if (c < C) partial[((int64_t)blockIdx.y * 2 + which) * C + c] = a;
   }
 }
 
 // sums[2][C] = sum over row blocks; dgamma += sum dy*xhat ; dbeta += sum dy
-__global__ __launch_bounds__(256) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+__global__ __launch_bounds__(512) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                                 float* __restrict__ sums, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[16][2][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < rows; ++r) { s1 += (double)partial[((int64_t)r * 2) * C + c]; s2 += (double)partial[((int64_t)r * 2 + 1) * C + c]; }
-  sums[c] = (float)s1; sums[C + c] = (float)s2;
-  if (dbeta) dbeta[c] += (float)s1;
-  if (dgamma) dgamma[c] += (float)s2;
+  if (c < C)
+    for (int r = rg; r < rows; r += 16) {
+      s1 += (double)partial[((int64_t)r * 2) * C + c];
+      s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
+    }
+  red[rg][0][cl] = s1; red[rg][1][cl] = s2;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    sums[c] = (float)s1; sums[C + c] = (float)s2;
+    if (dbeta) dbeta[c] += (float)s1;
+    if (dgamma) dgamma[c] += (float)s2;
+  }
 }
 
 // dx = gamma*invstd*(dy - sum_dy/M - xhat*sum_dyxhat/M); optional gm_out = dy (the ReLU-masked upstream grad)
@@ -420,7 +448,7 @@ int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t c
                         float* running_var, int training, float momentum, float eps, float* mean_out,
                         float* invstd_out, void* stream) {
   CREID_CHECK_ARG(C > 0 && mean_out && invstd_out && (training ? (partial && rows > 0 && count > 0) : (running_mean && running_var)));
-  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), partial,
+  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(512), 0, as_stream(stream), partial,
                      (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, mean_out,
                      invstd_out);
   CREID_LAUNCH_RET();
@@ -433,9 +461,9 @@ int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* parti
   const int rows = (int)creid_col_stats_rows(M);
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(col_stats_kernel<float>, dim3((unsigned)((C + 127) / 128), rows), dim3(256), 0, s,
+             hipLaunchKernelGGL(col_stats_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
                                 (const float*)x, M, (int)C, 512, partial),
-             hipLaunchKernelGGL(col_stats_kernel<unsigned short>, dim3((unsigned)((C + 255) / 256), rows), dim3(256), 0,
+             hipLaunchKernelGGL(col_stats_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256), 0,
                                 s, (const unsigned short*)x, M, (int)C, 512, partial));
   CREID_LAUNCH_RET();
 }
@@ -462,12 +490,12 @@ int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* m
   const int rows = (int)creid_bn2d_bwd_rows(M);
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<float>, dim3((unsigned)((C + 127) / 128), rows), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 512, partial),
-             hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C + 255) / 256), rows), dim3(256),
+             hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
                                 invstd, M, (int)C, 512, partial));
-  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, partial, rows, (int)C,
+  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(512), 0, s, partial, rows, (int)C,
                      sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,

@@ -408,6 +408,39 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// device-resident hyper-parameters {lr, step, bc1, bc2s}: lets a captured hipGraph replay the step with
+// the correct bias correction / learning rate (host scalars would be frozen into the graph).
+__global__ void adam_advance_kernel(float* __restrict__ hyper, float b1, float b2) {
+  const float step = hyper[1] + 1.0f;
+  hyper[1] = step;
+  hyper[2] = 1.0f - powf(b1, step);
+  hyper[3] = sqrtf(1.0f - powf(b2, step));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                       const float* __restrict__ hyper, float b1, float b2, float eps,
+                                                       float wd, float gscale) {
+  const float lr = hyper[0], bc1 = hyper[2], bc2s = hyper[3];
+  const float step_size = lr / bc1;
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  for (int64_t i = i0; i + 3 < n; i += stride) {      // n is padded to a multiple of 4 by the caller
+    float4 pv = *reinterpret_cast<float4*>(p + i), gv = *reinterpret_cast<const float4*>(g + i);
+    float4 mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+    float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = fmaf(wd, pp[k], gp[k] * gscale);
+      mp[k] = b1 * mp[k] + (1.f - b1) * gg;
+      vp[k] = b2 * vp[k] + (1.f - b2) * gg * gg;
+      pp[k] = pp[k] - step_size * (mp[k] / (sqrtf(vp[k]) / bc2s + eps));
+    }
+    *reinterpret_cast<float4*>(p + i) = pv; *reinterpret_cast<float4*>(m + i) = mv;
+    *reinterpret_cast<float4*>(v + i) = vv;
+  }
+}
+
 __global__ __launch_bounds__(256) void sgd_scaled_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n,
                                                          float lr, float gmul) {
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -547,6 +580,21 @@ int creid_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  CREID_LAUNCH_RET();
+}
+
+int creid_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+  CREID_CHECK_ARG(p && g && m && v && hyper_dev && n >= 0);
+  if (n % 4 != 0) return CREID_E_SHAPE;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, hyper_dev, beta1, beta2);
+  if (n > 0) {
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper_dev, beta1, beta2,
+                       eps, weight_decay, grad_scale);
+  }
   CREID_LAUNCH_RET();
 }
 

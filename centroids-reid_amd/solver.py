@@ -40,8 +40,10 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat, self.gflat = flatten_(params, params[0].device)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.step_count = 0
         self.grad_scale = 1.0
+        # device-resident {lr, step, bc1, bc2s}: keeps a captured hipGraph of the step valid
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
+        self._lr_on_device = None
         off = 0
         for p in params:   # torch-compatible per-parameter state (views) for checkpoints
             k = p.numel()
@@ -52,16 +54,28 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.gflat.zero_()
 
+    @property
+    def step_count(self):
+        return int(self.hyper[1].item())
+
+    def state_dict(self):
+        n = self.step_count
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(n))
+        return super().state_dict()
+
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        self.step_count += 1
-        for st in self.state.values():
-            st["step"] += 1
+        lr = float(g["lr"])
+        if lr != self._lr_on_device:          # only when the schedule / warm-up changes it (outside graphs)
+            self.hyper[0:1].copy_(torch.tensor([lr], dtype=torch.float32))
+            self._lr_on_device = lr
         b1, b2 = g["betas"]
-        L.check(L.lib().creid_adam_step(L.ptr(self.flat), L.ptr(self.gflat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-                                        self.flat.numel(), float(g["lr"]), b1, b2, g["eps"], g["weight_decay"],
-                                        self.step_count, float(self.grad_scale), L.stream()), "creid_adam_step")
+        L.check(L.lib().creid_adam_step_dev(L.ptr(self.flat), L.ptr(self.gflat), L.ptr(self.exp_avg),
+                                            L.ptr(self.exp_avg_sq), self.flat.numel(), L.ptr(self.hyper), b1, b2,
+                                            g["eps"], g["weight_decay"], float(self.grad_scale), L.stream()),
+                "creid_adam_step_dev")
 
 
 class CenterSGD(torch.optim.Optimizer):

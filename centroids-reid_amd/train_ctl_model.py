@@ -45,7 +45,13 @@ class CTLModel(ModelBase):
         dev = x.device
         ir_host = np.asarray(isReal.cpu() if isinstance(isReal, torch.Tensor) else isReal, dtype=bool)
         all_real = bool(ir_host.all())
-        is_real = (isReal if isinstance(isReal, torch.Tensor) else torch.as_tensor(ir_host)).to(dev, non_blocking=True)
+        if all_real:       # cached device mask: no H2D copy inside the step (keeps it hipGraph-capturable)
+            cache = getattr(self, "_all_real_dev", None)
+            if cache is None or cache.numel() != B or cache.device != dev:
+                cache = self._all_real_dev = torch.ones(B, dtype=torch.bool, device=dev)
+            is_real = cache
+        else:
+            is_real = (isReal if isinstance(isReal, torch.Tensor) else torch.as_tensor(ir_host)).to(dev)
         class_labels = class_labels.to(dev, non_blocking=True)
 
         _, features = self.backbone(x)                                        # :59

@@ -144,6 +144,13 @@ int creid_gather_mean_rows(const float* emb, const int64_t* order, const int64_t
 int creid_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                     void* stream);
+/* Same update with the step-dependent scalars resident on the device: hyper_dev = float[4]
+ * {lr, step, 1-beta1^step, sqrt(1-beta2^step)}; the call first advances step (+1) and the bias
+ * corrections, so a captured hipGraph replays correctly; the host only rewrites hyper_dev[0] when
+ * the learning rate changes.  n % 4 == 0. */
+int creid_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev,
+                        float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                        void* stream);
 /* train_ctl_model.py:157-159 + solver/build.py:44: g *= grad_mul (in place); p -= lr * g. */
 int creid_sgd_scaled_step(float* p, float* g, int64_t n, float lr, float grad_mul, void* stream);
 

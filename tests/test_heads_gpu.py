@@ -118,6 +118,18 @@ def test_optimizer_steps_vs_oracle(mods):
         L.check(L.lib().creid_adam_step(L.ptr(pg), L.ptr(gg), L.ptr(mg), L.ptr(vg), n, 3.5e-5, 0.9, 0.999, 1e-8, 5e-4,
                                         step, 1.0, L.stream()), "adam")
     np.testing.assert_allclose(pg.cpu().numpy(), p.numpy(), rtol=1e-5, atol=1e-7)
+    # device-resident hyper-parameter variant (hipGraph-safe) gives the same trajectory
+    n4 = 100004
+    p2 = torch.from_numpy(rng.standard_normal(n4).astype(np.float32)); g2 = torch.from_numpy(rng.standard_normal(n4).astype(np.float32))
+    pa, ga, ma, va = p2.cuda(), g2.cuda(), torch.zeros(n4).cuda(), torch.zeros(n4).cuda()
+    hyper = torch.tensor([3.5e-5, 0, 0, 0], dtype=torch.float32).cuda()
+    pr, mr, vr = p2.clone(), torch.zeros(n4), torch.zeros(n4)
+    for step in (1, 2, 3):
+        pr, mr, vr = ro.adam_step(pr, g2, mr, vr, step, 3.5e-5)
+        L.check(L.lib().creid_adam_step_dev(L.ptr(pa), L.ptr(ga), L.ptr(ma), L.ptr(va), n4, L.ptr(hyper), 0.9, 0.999, 1e-8,
+                                            5e-4, 1.0, L.stream()), "adam_dev")
+    np.testing.assert_allclose(pa.cpu().numpy(), pr.numpy(), rtol=1e-5, atol=1e-7)
+    assert int(hyper[1].item()) == 3
     c = torch.from_numpy(rng.standard_normal(5000).astype(np.float32)); gc = torch.from_numpy(rng.standard_normal(5000).astype(np.float32) * 1e-4)
     cg, gcg = c.cuda(), gc.cuda()
     L.check(L.lib().creid_sgd_scaled_step(L.ptr(cg), L.ptr(gcg), 5000, 0.5, 1.0 / 5e-4, L.stream()), "sgd")
