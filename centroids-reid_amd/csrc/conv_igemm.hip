@@ -14,23 +14,24 @@
 
 // ------------------------------------------------------------------------------------ bf16
 template <int BN>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
+__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
                                                          const unsigned short* __restrict__ wgt,
                                                          unsigned short* __restrict__ out,
                                                          const unsigned short* __restrict__ add_src,
                                                          float* __restrict__ bn_part, int tiles_n) {
   constexpr int BK = 64, TNW = BN / 64, NB = BN / 32;
   constexpr int CP = BN + 8;                                   // C-tile staging pitch (elements)
-  constexpr int LDS_ELEMS = (2 * 128 * BK + 2 * BN * BK) > (128 * CP) ? (2 * 128 * BK + 2 * BN * BK) : (128 * CP);
+  constexpr int LDS_ELEMS = (128 * BK + BN * BK) > (128 * CP) ? (128 * BK + BN * BK) : (128 * CP);
   __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_ELEMS];
-  unsigned short (*As)[128 * BK] = reinterpret_cast<unsigned short (*)[128 * BK]>(smem);
-  unsigned short (*Bs)[BN * BK] = reinterpret_cast<unsigned short (*)[BN * BK]>(smem + 2 * 128 * BK);
+  unsigned short* As = smem;                 // single-buffered tiles + register prefetch: half the LDS of a
+  unsigned short* Bs = smem + 128 * BK;      // double buffer -> twice the resident workgroups per CU
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int row0 = tile_m * 128, col0 = tile_n * BN;
   const int span_mask = (1 << g.log2span) - 1;
+  const bool tap_uniform = g.log2span >= 6;        // a 64-wide k-tile never straddles two taps (all but the stem)
 
   const int lrow = tid >> 3, lch = tid & 7;
   int oy[4], ox[4], bpix[4], soff[4];
@@ -40,8 +41,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsi
     const int r = lrow + 32 * i, m = row0 + r;
     vm[i] = m < g.M;
     const int mm = vm[i] ? m : 0;
-    const int b = mm / (g.OH * g.OW), rem = mm - b * (g.OH * g.OW);
-    oy[i] = rem / g.OW; ox[i] = rem - oy[i] * g.OW;
+    int b, rem;
+    fast_divmod(mm, g.OH * g.OW, g.inv_ohow, b, rem);
+    fast_divmod(rem, g.OW, g.inv_ow, oy[i], ox[i]);
     bpix[i] = b * g.SH * g.SW;
     soff[i] = r * BK + ((lch ^ ((r >> 1) & 7)) << 3);
   }
@@ -49,28 +51,67 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsi
 #pragma unroll
   for (int i = 0; i < NB; ++i) wp[i] = wgt + (int64_t)(col0 + lrow + 32 * i) * g.K + 8 * lch;
 
-  uint4 ra[4], rb[NB];
-  auto gload = [&](int t) {
-    const int kk = t * BK + 8 * lch;
-    const int tap = kk >> g.log2span, c = kk & span_mask;
+  // A-row source pointers are recomputed only when the k-loop enters a new tap (tap-major K order);
+  // inside a tap consecutive k-tiles just advance by 64 channels.
+  const unsigned short* aptr[4];
+  bool av[4];
+  int cur_tap = -1;
+  auto set_tap = [&](int tap) {
     const int r = tap / g.kw, s = tap - r * g.kw;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int iy, ix;
-      if (vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix))
-        ra[i] = *reinterpret_cast<const uint4*>(src + (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + c);
-      else
-        ra[i] = make_uint4(0, 0, 0, 0);
+      av[i] = vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix);
+      aptr[i] = src + (int64_t)(bpix[i] + (av[i] ? iy * g.SW + ix : 0)) * g.pitch + 8 * lch;
     }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(wp[i] + t * BK);
   };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&As[buf][soff[i]]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[buf][soff[i]]) = rb[i];
-  };
+  // 3-deep register prefetch ring: the loads of k-tile t+3 are issued while tile t is multiplied, so a
+  // load has ~3 compute phases to land (HBM/L2 latency >> one 16-MFMA phase at 2 workgroups per CU).
+  // The ring lives in NAMED scalars (arrays / lambdas taking array references kept ending up in scratch).
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // first-class vector: always SROA-able
+  struct Stage { u32x4 a0, a1, a2, a3, b0, b1, b2, b3; };
+  Stage st0, st1, st2;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#define IGEMM_LDA(I_, DST, C_) DST = av[I_] ? *reinterpret_cast<const u32x4*>(aptr[I_] + (C_)) : zero4
+#define IGEMM_LDA_G(I_, DST, R_, S_, C_)                                                                \
+  do {                                                                                                  \
+    int iy, ix;                                                                                         \
+    if (vm[I_] && igemm_src_pixel(g, oy[I_], ox[I_], R_, S_, iy, ix))                                   \
+      DST = *reinterpret_cast<const u32x4*>(src + (int64_t)(bpix[I_] + iy * g.SW + ix) * g.pitch + (C_)); \
+    else                                                                                                \
+      DST = zero4;                                                                                      \
+  } while (0)
+#define IGEMM_GLOAD(T_, ST)                                                                             \
+  do {                                                                                                  \
+    const int t_ = (T_);                                                                                \
+    if (tap_uniform) {                                                                                  \
+      const int tap_ = (t_ * BK) >> g.log2span;                                                         \
+      if (tap_ != cur_tap) { set_tap(tap_); cur_tap = tap_; }                                           \
+      const int c_ = (t_ * BK) & span_mask;                                                             \
+      IGEMM_LDA(0, ST.a0, c_); IGEMM_LDA(1, ST.a1, c_); IGEMM_LDA(2, ST.a2, c_); IGEMM_LDA(3, ST.a3, c_); \
+    } else {                                                                                            \
+      const int kk_ = t_ * BK + 8 * lch;                                                                \
+      const int tap_ = kk_ >> g.log2span, c_ = kk_ & span_mask;                                         \
+      const int r_ = tap_ / g.kw, s_ = tap_ - r_ * g.kw;                                                \
+      IGEMM_LDA_G(0, ST.a0, r_, s_, c_); IGEMM_LDA_G(1, ST.a1, r_, s_, c_);                             \
+      IGEMM_LDA_G(2, ST.a2, r_, s_, c_); IGEMM_LDA_G(3, ST.a3, r_, s_, c_);                             \
+    }                                                                                                   \
+    ST.b0 = *reinterpret_cast<const u32x4*>(wp[0] + t_ * BK);                                           \
+    ST.b1 = *reinterpret_cast<const u32x4*>(wp[1] + t_ * BK);                                           \
+    if constexpr (NB == 4) {                                                                            \
+      ST.b2 = *reinterpret_cast<const u32x4*>(wp[2] + t_ * BK);                                         \
+      ST.b3 = *reinterpret_cast<const u32x4*>(wp[3] + t_ * BK);                                         \
+    }                                                                                                   \
+  } while (0)
+#define IGEMM_LSTORE(ST)                                                                                \
+  do {                                                                                                  \
+    *reinterpret_cast<u32x4*>(&As[soff[0]]) = ST.a0; *reinterpret_cast<u32x4*>(&As[soff[1]]) = ST.a1;   \
+    *reinterpret_cast<u32x4*>(&As[soff[2]]) = ST.a2; *reinterpret_cast<u32x4*>(&As[soff[3]]) = ST.a3;   \
+    *reinterpret_cast<u32x4*>(&Bs[soff[0]]) = ST.b0; *reinterpret_cast<u32x4*>(&Bs[soff[1]]) = ST.b1;   \
+    if constexpr (NB == 4) {                                                                            \
+      *reinterpret_cast<u32x4*>(&Bs[soff[2]]) = ST.b2; *reinterpret_cast<u32x4*>(&Bs[soff[3]]) = ST.b3; \
+    }                                                                                                   \
+  } while (0)
 
   f32x16 acc[2][TNW];
 #pragma unroll
@@ -81,13 +122,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsi
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = g.K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
   const int l31 = lane & 31, kh = lane >> 5;
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nk) gload(t + 1);
+  auto compute = [&]() {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int ch = 2 * kk + kh;
@@ -95,12 +131,12 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsi
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = wm * 64 + i * 32 + l31;
-        a[i] = *reinterpret_cast<const s16x8*>(&As[buf][r * BK + ((ch ^ ((r >> 1) & 7)) << 3)]);
+        a[i] = *reinterpret_cast<const s16x8*>(&As[r * BK + ((ch ^ ((r >> 1) & 7)) << 3)]);
       }
 #pragma unroll
       for (int j = 0; j < TNW; ++j) {
         const int c = wn * (BN / 2) + j * 32 + l31;
-        b[j] = *reinterpret_cast<const s16x8*>(&Bs[buf][c * BK + ((ch ^ ((c >> 1) & 7)) << 3)]);
+        b[j] = *reinterpret_cast<const s16x8*>(&Bs[c * BK + ((ch ^ ((c >> 1) & 7)) << 3)]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -109,9 +145,26 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IGemmGeom g, const unsi
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
                                                               __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < nk) lstore(buf ^ 1);
+  };
+  // every prefetch is unconditional (the tile index is clamped; a redundant re-load of the last tile is
+  // harmless); the ring rotates by register moves so there is ONE lstore/compute site in the loop body
+  const int last = nk - 1;
+  IGEMM_GLOAD(0, st0);
+  IGEMM_GLOAD(min(1, last), st1);
+  IGEMM_GLOAD(min(2, last), st2);
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();               // fragment reads of the previous tile are done
+    IGEMM_LSTORE(st0);
     __syncthreads();
+    st0 = st1; st1 = st2;
+    IGEMM_GLOAD(min(t + 3, last), st2);
+    compute();
   }
+#undef IGEMM_GLOAD
+#undef IGEMM_LSTORE
+#undef IGEMM_LDA
+#undef IGEMM_LDA_G
+  __syncthreads();
 
   // ---- epilogue: per-channel (sum, sumsq) partials from the fp32 accumulators, then the C tile is
   // staged through LDS (bf16) so that global stores (and the add_src reads) are 16-B coalesced rows.
@@ -339,7 +392,7 @@ static int check_desc(const creid_conv_desc* d) {
   if (ilog2_exact(d->in_c) < 0 || ilog2_exact(d->out_c) < 0 || d->in_c < 64 || d->out_c < 64) return CREID_E_SHAPE;
   if (d->out_h != (d->in_h + 2 * d->pad - d->kh) / d->stride + 1) return CREID_E_SHAPE;
   if (d->out_w != (d->in_w + 2 * d->pad - d->kw) / d->stride + 1) return CREID_E_SHAPE;
-  if (d->batch * d->in_h * d->in_w > 0x7fffffffLL / 4 || d->batch * d->in_h * d->in_w * d->in_c > (1LL << 40)) return CREID_E_SHAPE;
+  if (d->batch * d->in_h * d->in_w >= (1LL << 24) || d->batch * d->out_h * d->out_w >= (1LL << 24) || d->batch * d->in_h * d->in_w * d->in_c > (1LL << 40)) return CREID_E_SHAPE;
   return 0;
 }
 
@@ -360,6 +413,7 @@ int creid_conv2d_fwd_nhwc(const creid_conv_desc* d, const void* x, const void* w
   g.SH = (int)d->in_h; g.SW = (int)d->in_w; g.pitch = (int)d->in_c; g.log2span = ilog2_exact(d->in_c);
   g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 0;
   g.K = (int)(d->kh * d->kw * d->in_c); g.N = (int)d->out_c; g.check_bounds = 1;
+  igemm_finish_geom(g);
   return launch_igemm(g, x, w_krsc, y, nullptr, bn_partial, dtype, as_stream(stream));
 }
 
@@ -373,6 +427,7 @@ int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void
   g.SH = (int)d->out_h; g.SW = (int)d->out_w; g.pitch = (int)d->out_c; g.log2span = ilog2_exact(d->out_c);
   g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 1;
   g.K = (int)(d->kh * d->kw * d->out_c); g.N = (int)d->in_c; g.check_bounds = 1;
+  igemm_finish_geom(g);
   return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream));
 }
 
@@ -387,6 +442,7 @@ int creid_stem_conv_fwd(int64_t batch, int64_t H, int64_t W, const void* xpad, c
   g.M = (int)(batch * (H / 2) * (W / 2)); g.OH = (int)(H / 2); g.OW = (int)(W / 2);
   g.SH = (int)(H + 8); g.SW = (int)(W + 6); g.pitch = 4; g.log2span = 5;
   g.kw = 1; g.stride = 2; g.pad = 0; g.transposed = 0; g.K = 256; g.N = 64; g.check_bounds = 0;
+  igemm_finish_geom(g);
   return launch_igemm(g, xpad, w_stem, y, nullptr, bn_partial, dtype, as_stream(stream));
 }
 

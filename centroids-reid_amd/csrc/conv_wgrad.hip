@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(IGemmGeom g, const unsi
       const int m = mb + b_row + RB * i;
       rb[i] = make_uint4(0, 0, 0, 0);
       if (m < m_end) {
-        const int b = m / (g.OH * g.OW), rem = m - b * (g.OH * g.OW);
-        const int oy = rem / g.OW, ox = rem - oy * g.OW;
+        int b, rem, oy, ox;
+        fast_divmod(m, g.OH * g.OW, g.inv_ohow, b, rem);
+        fast_divmod(rem, g.OW, g.inv_ow, oy, ox);
         int iy, ix;
         if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))
           rb[i] = *reinterpret_cast<const uint4*>(x + (int64_t)((b * g.SH + iy) * g.SW + ix) * g.pitch + cc);
@@ -322,6 +323,7 @@ int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void*
   g.SH = (int)d->in_h; g.SW = (int)d->in_w; g.pitch = (int)d->in_c; g.log2span = ilog2x(d->in_c);
   g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 0;
   g.K = (int)(d->kh * d->kw * d->in_c); g.N = (int)d->out_c; g.check_bounds = 1;
+  igemm_finish_geom(g);
   return run_wgrad(g, dy, x, (int)d->out_c, dw_oihw, d->kw, (int)d->in_c, (int)d->in_c, d->kh, d->kw, accumulate, ws,
                    ws_bytes, dtype, as_stream(stream));
 }
@@ -340,6 +342,7 @@ int creid_stem_conv_wgrad(int64_t batch, int64_t H, int64_t W, const void* xpad,
   g.M = (int)(batch * (H / 2) * (W / 2)); g.OH = (int)(H / 2); g.OW = (int)(W / 2);
   g.SH = (int)(H + 8); g.SW = (int)(W + 6); g.pitch = 4; g.log2span = 5;
   g.kw = 1; g.stride = 2; g.pad = 0; g.transposed = 0; g.K = 256; g.N = 64; g.check_bounds = 0;
+  igemm_finish_geom(g);
   return run_wgrad(g, dy, xpad, 64, dw_oihw, 1, 4, 3, 7, 7, accumulate, ws, ws_bytes, dtype, as_stream(stream));
 }
 

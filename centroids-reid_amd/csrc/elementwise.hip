@@ -119,23 +119,30 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x
     sc[k] = invstd[c0 + k] * (gamma ? gamma[c0 + k] : 1.f);
     sh[k] = (beta ? beta[c0 + k] : 0.f) - mean[c0 + k] * sc[k];
   }
-  for (int64_t i = gtid; i < total; i += nthreads) {
-    float v[V];
+  for (int64_t i = gtid; i < total; i += 2 * nthreads) {      // two independent 16-B streams in flight per thread
+    const int64_t i2 = i + nthreads;
+    const bool two = i2 < total;
+    float v[V], w[V], rv[V], rw[V];
     Vec16<T>::load(x + i * V, v);
+    if (two) Vec16<T>::load(x + i2 * V, w);
     if (res) {
-      float rv[V];
       Vec16<T>::load(res + i * V, rv);
-#pragma unroll
-      for (int k = 0; k < V; ++k) v[k] = fmaf(v[k], sc[k], sh[k]) + rv[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < V; ++k) v[k] = fmaf(v[k], sc[k], sh[k]);
+      if (two) Vec16<T>::load(res + i2 * V, rw);
     }
-    if (relu) {
 #pragma unroll
-      for (int k = 0; k < V; ++k) v[k] = fmaxf(v[k], 0.f);
+    for (int k = 0; k < V; ++k) {
+      v[k] = fmaf(v[k], sc[k], sh[k]) + (res ? rv[k] : 0.f);
+      if (relu) v[k] = fmaxf(v[k], 0.f);
     }
     Vec16<T>::store(y + i * V, v);
+    if (two) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        w[k] = fmaf(w[k], sc[k], sh[k]) + (res ? rw[k] : 0.f);
+        if (relu) w[k] = fmaxf(w[k], 0.f);
+      }
+      Vec16<T>::store(y + i2 * V, w);
+    }
   }
 }
 
@@ -454,7 +461,7 @@ int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t c
   CREID_LAUNCH_RET();
 }
 
-int64_t creid_col_stats_rows(int64_t M) { int64_t r = (M + 511) / 512; return r < 1 ? 1 : r; }
+int64_t creid_col_stats_rows(int64_t M) { int64_t r = (M + 127) / 128; return r < 1 ? 1 : r; }
 
 int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* partial, void* stream) {
   CREID_CHECK_ARG(x && partial && M > 0 && C > 0 && C % 8 == 0);
@@ -462,9 +469,9 @@ int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* parti
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(col_stats_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
-                                (const float*)x, M, (int)C, 512, partial),
+                                (const float*)x, M, (int)C, 128, partial),
              hipLaunchKernelGGL(col_stats_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256), 0,
-                                s, (const unsigned short*)x, M, (int)C, 512, partial));
+                                s, (const unsigned short*)x, M, (int)C, 128, partial));
   CREID_LAUNCH_RET();
 }
 
@@ -481,7 +488,7 @@ int creid_bn2d_apply(const void* x, const float* mean, const float* invstd, cons
   CREID_LAUNCH_RET();
 }
 
-int64_t creid_bn2d_bwd_rows(int64_t M) { int64_t r = (M + 511) / 512; return r < 1 ? 1 : r; }
+int64_t creid_bn2d_bwd_rows(int64_t M) { int64_t r = (M + 127) / 128; return r < 1 ? 1 : r; }
 
 int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
                    const float* gamma, int64_t M, int64_t C, int dtype, float* partial, float* sums, float* dgamma_accum,
@@ -491,10 +498,10 @@ int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* m
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
-                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 512, partial),
+                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 128, partial),
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
-                                invstd, M, (int)C, 512, partial));
+                                invstd, M, (int)C, 128, partial));
   hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(512), 0, s, partial, rows, (int)C,
                      sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,
