@@ -54,10 +54,10 @@ SIGNATURES = {
     "creid_image_to_nhwc4_pad": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
     "creid_weight_prep": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),
     "creid_stem_weight_prep": (C.c_int, [_p, C.c_int, _p, _p]),
-    "creid_bn2d_finalize": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, C.c_int, _f32, _f32, _p, _p, _p]),
+    "creid_bn2d_finalize": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, C.c_int, _f32, _f32, _p, _p, _p, _p, _p, _p]),
     "creid_col_stats_rows": (_i64, [_i64]),
     "creid_col_stats": (C.c_int, [_p, _i64, _i64, C.c_int, _p, _p]),
-    "creid_bn2d_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _i64, _i64, C.c_int, _p, _p]),
+    "creid_bn2d_apply": (C.c_int, [_p, _p, _p, C.c_int, _i64, _i64, C.c_int, _p, _p]),
     "creid_bn2d_bwd_rows": (_i64, [_i64]),
     "creid_bn2d_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
     "creid_maxpool3x3s2_fwd": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),

@@ -139,6 +139,7 @@ class BackboneEngine:
         self.weights_dirty = True
         self._ws = None
         self.saved = None
+        self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
 
     # ---- helpers
     @property
@@ -177,6 +178,14 @@ class BackboneEngine:
                                           L.ptr(u.w_crsk), st), "weight_prep")
         self.weights_dirty = False
 
+    def fold_counters(self):
+        """Fold the pending step count into every BatchNorm2d.num_batches_tracked (before a state_dict)."""
+        if self._pending_steps is None:
+            return
+        for u in self.all_units():
+            u.bn.num_batches_tracked += self._pending_steps.to(u.bn.num_batches_tracked.device)
+        self._pending_steps.zero_()
+
     # ---- layer steps
     def _conv_bn(self, u, a_in, B, H, W, training, relu, residual=None):
         """conv -> BN(batch or running stats) -> (+residual) -> (ReLU).  Returns (x_raw, a_out, mean, invstd, oh, ow)."""
@@ -195,14 +204,13 @@ class BackboneEngine:
         bn = u.bn
         mean = self._empty(u.cout, dtype=torch.float32)
         invstd = self._empty(u.cout, dtype=torch.float32)
+        ss = self._empty(2, u.cout, dtype=torch.float32)
         L.check(lib.creid_bn2d_finalize(L.ptr(part), rows, u.cout, M, L.ptr(bn.running_mean), L.ptr(bn.running_var),
-                                        1 if training else 0, bn.momentum, bn.eps, L.ptr(mean), L.ptr(invstd), st),
-                "bn2d_finalize")
-        if training:
-            bn.num_batches_tracked += 1
+                                        1 if training else 0, bn.momentum, bn.eps, L.ptr(bn.weight), L.ptr(bn.bias),
+                                        L.ptr(mean), L.ptr(invstd), L.ptr(ss), st), "bn2d_finalize")
         a = self._empty(M, u.cout)
-        L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(mean), L.ptr(invstd), L.ptr(bn.weight), L.ptr(bn.bias),
-                                     L.ptr(residual), 1 if relu else 0, M, u.cout, self.dt, L.ptr(a), st), "bn2d_apply")
+        L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(ss), L.ptr(residual), 1 if relu else 0, M, u.cout, self.dt,
+                                     L.ptr(a), st), "bn2d_apply")
         return a, mean, invstd
 
     # ---- forward
@@ -214,6 +222,10 @@ class BackboneEngine:
         lib, st = L.lib(), L.stream()
         B, _, H, W = x_nchw.shape
         sv = {"B": B, "H": H, "W": W, "training": training}
+        if training:      # one counter kernel per step instead of 53 per-layer `num_batches_tracked += 1`
+            if self._pending_steps is None:
+                self._pending_steps = torch.zeros((), dtype=torch.long, device=self.device)
+            self._pending_steps += 1
         # stem
         xpad = self._empty(B, H + 8, W + 6, 4)
         L.check(lib.creid_image_to_nhwc4_pad(L.ptr(x_nchw), B, H, W, self.dt, L.ptr(xpad), st), "image_pad")
@@ -266,7 +278,7 @@ class BackboneEngine:
         lib, st = L.lib(), L.stream()
         rows = lib.creid_bn2d_bwd_rows(M)
         part = self._empty(rows * 2, u.cout, dtype=torch.float32)
-        sums = self._empty(2, u.cout, dtype=torch.float32)
+        sums = self._empty(3, u.cout, dtype=torch.float32)
         dx = self._empty(M, u.cout)
         gm = self._empty(M, u.cout) if want_gm else None
         bn = u.bn

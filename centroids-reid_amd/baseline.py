@@ -40,6 +40,11 @@ class Baseline(nn.Module):
             self._engine = bb.BackboneEngine(self.base, self.compute_dtype)
         return self._engine
 
+    def state_dict(self, *args, **kwargs):
+        if self._engine is not None:
+            self._engine.fold_counters()
+        return super().state_dict(*args, **kwargs)
+
     def forward(self, x):
         eng = self.engine
         x = x.contiguous().float()

@@ -37,14 +37,22 @@ template <> struct Vec16<unsigned short> {
 __global__ __launch_bounds__(512) void bn2d_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                             double count, float* __restrict__ rmean,
                                                             float* __restrict__ rvar, int training, float momentum,
-                                                            float eps, float* __restrict__ mean_out,
-                                                            float* __restrict__ invstd_out) {
+                                                            float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ mean_out,
+                                                            float* __restrict__ invstd_out,
+                                                            float* __restrict__ scale_shift) {
   // 32 channels x 16 row-groups per workgroup: coalesced 128-B reads, fp64 accumulation, LDS tree
   __shared__ double red[16][2][32];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   if (!training) {
-    if (rg == 0 && c < C) { mean_out[c] = rmean[c]; invstd_out[c] = 1.0f / sqrtf(rvar[c] + eps); }
+    if (rg == 0 && c < C) {
+      const float mu = rmean[c], is = 1.0f / sqrtf(rvar[c] + eps);
+      mean_out[c] = mu; invstd_out[c] = is;
+      const float sc = is * (gamma ? gamma[c] : 1.f);
+      scale_shift[c] = sc; scale_shift[C + c] = (beta ? beta[c] : 0.f) - mu * sc;
+    }
     return;
   }
   double s1 = 0.0, s2 = 0.0;
@@ -62,8 +70,11 @@ __global__ __launch_bounds__(512) void bn2d_finalize_kernel(const float* __restr
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
-    mean_out[c] = (float)mean;
-    invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const float mu = (float)mean, is = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[c] = mu;
+    invstd_out[c] = is;
+    const float sc = is * (gamma ? gamma[c] : 1.f);          // y = x * scale + shift
+    scale_shift[c] = sc; scale_shift[C + c] = (beta ? beta[c] : 0.f) - mu * sc;
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
     if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
   }
@@ -103,11 +114,9 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x,
 
 // ------------------------------------------------------------------ BN apply (+residual)(+ReLU)
 template <typename T>
-__global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const T* __restrict__ res,
-                                                         int relu, int64_t M, int C, T* __restrict__ y) {
+__global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift,
+                                                         const T* __restrict__ res, int relu, int64_t M, int C,
+                                                         T* __restrict__ y) {
   constexpr int V = Vec16<T>::N;
   const int cpr = C / V;
   const int64_t total = M * cpr, nthreads = (int64_t)gridDim.x * 256;
@@ -115,9 +124,11 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x
   const int c0 = (int)(gtid % cpr) * V;     // nthreads % cpr == 0 -> this thread's channels never change
   float sc[V], sh[V];
 #pragma unroll
-  for (int k = 0; k < V; ++k) {
-    sc[k] = invstd[c0 + k] * (gamma ? gamma[c0 + k] : 1.f);
-    sh[k] = (beta ? beta[c0 + k] : 0.f) - mean[c0 + k] * sc[k];
+  for (int k = 0; k < V; k += 4) {        // per-channel coefficients: 16-B loads, precomputed by the finalize
+    const float4 a = *reinterpret_cast<const float4*>(scale_shift + c0 + k);
+    const float4 b = *reinterpret_cast<const float4*>(scale_shift + C + c0 + k);
+    sc[k] = a.x; sc[k + 1] = a.y; sc[k + 2] = a.z; sc[k + 3] = a.w;
+    sh[k] = b.x; sh[k + 1] = b.y; sh[k + 2] = b.z; sh[k + 3] = b.w;
   }
   for (int64_t i = gtid; i < total; i += 2 * nthreads) {      // two independent 16-B streams in flight per thread
     const int64_t i2 = i + nthreads;
@@ -165,7 +176,12 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
   for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; is[k] = 0.f; }
   if (c0 < C) {
 #pragma unroll
-    for (int k = 0; k < V; ++k) { mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k]; }
+    for (int k = 0; k < V; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(mean + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(invstd + c0 + k);
+      mu[k] = a.x; mu[k + 1] = a.y; mu[k + 2] = a.z; mu[k + 3] = a.w;
+      is[k] = b.x; is[k + 1] = b.y; is[k + 2] = b.z; is[k + 3] = b.w;
+    }
     for (int64_t r = r0 + rl; r < r1; r += nrl) {
       float xv[V], gv[V];
       Vec16<T>::load(x + r * C + c0, xv);
@@ -194,6 +210,9 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
 
 // sums[2][C] = sum over row blocks; dgamma += sum dy*xhat ; dbeta += sum dy
 __global__ __launch_bounds__(512) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+                                                                double count, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
                                                                 float* __restrict__ sums, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta) {
   __shared__ double red[16][2][32];
@@ -211,33 +230,38 @@ __global__ __launch_bounds__(512) void bn2d_bwd_finalize_kernel(const float* __r
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
-    sums[c] = (float)s1; sums[C + c] = (float)s2;
+    // dx = k1*(dy - a1 - xhat*a2) = A*dy + B*x + Cc  with per-channel A, B, Cc
+    const float invM = (float)(1.0 / count);
+    const float mu = mean[c], is = invstd[c], k1 = (gamma ? gamma[c] : 1.f) * is;
+    const float a1 = (float)s1 * invM, a2 = (float)s2 * invM;
+    sums[c] = k1;
+    sums[C + c] = -k1 * is * a2;
+    sums[2 * C + c] = -k1 * a1 + k1 * is * a2 * mu;
     if (dbeta) dbeta[c] += (float)s1;
     if (dgamma) dgamma[c] += (float)s2;
   }
 }
 
-// dx = gamma*invstd*(dy - sum_dy/M - xhat*sum_dyxhat/M); optional gm_out = dy (the ReLU-masked upstream grad)
+// dx = A*dy + B*x + Cc (per-channel coefficients from the finalize); optional gm_out = dy (ReLU-masked g)
 template <typename T>
 __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                              const T* __restrict__ act,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ sums, int64_t M, int C,
+                                                             const float* __restrict__ coef, int64_t M, int C,
                                                              T* __restrict__ dx, T* __restrict__ gm_out) {
   constexpr int V = Vec16<T>::N;
   const int cpr = C / V;
   const int64_t total = M * cpr, nthreads = (int64_t)gridDim.x * 256;
   const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int c0 = (int)(gtid % cpr) * V;
-  const float invM = 1.0f / (float)M;
-  float mu[V], is[V], k1[V], a1[V], a2[V];
+  float ca[V], cb[V], cc[V];
 #pragma unroll
-  for (int k = 0; k < V; ++k) {
-    mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k];
-    k1[k] = (gamma ? gamma[c0 + k] : 1.f) * is[k];
-    a1[k] = sums[c0 + k] * invM; a2[k] = sums[C + c0 + k] * invM;
+  for (int k = 0; k < V; k += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(coef + c0 + k);
+    const float4 b = *reinterpret_cast<const float4*>(coef + C + c0 + k);
+    const float4 c = *reinterpret_cast<const float4*>(coef + 2 * C + c0 + k);
+    ca[k] = a.x; ca[k + 1] = a.y; ca[k + 2] = a.z; ca[k + 3] = a.w;
+    cb[k] = b.x; cb[k + 1] = b.y; cb[k + 2] = b.z; cb[k + 3] = b.w;
+    cc[k] = c.x; cc[k + 1] = c.y; cc[k + 2] = c.z; cc[k + 3] = c.w;
   }
   for (int64_t i = gtid; i < total; i += nthreads) {
     float xv[V], gv[V];
@@ -252,7 +276,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict
     if (gm_out) Vec16<T>::store(gm_out + i * V, gv);
     float o[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) o[k] = k1[k] * (gv[k] - a1[k] - (xv[k] - mu[k]) * is[k] * a2[k]);
+    for (int k = 0; k < V; ++k) o[k] = fmaf(ca[k], gv[k], fmaf(cb[k], xv[k], cc[k]));
     Vec16<T>::store(dx + i * V, o);
   }
 }
@@ -452,12 +476,13 @@ static inline unsigned ew_blocks(int64_t total_threads_needed, int64_t mult) {
 extern "C" {
 
 int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t count, float* running_mean,
-                        float* running_var, int training, float momentum, float eps, float* mean_out,
-                        float* invstd_out, void* stream) {
-  CREID_CHECK_ARG(C > 0 && mean_out && invstd_out && (training ? (partial && rows > 0 && count > 0) : (running_mean && running_var)));
+                        float* running_var, int training, float momentum, float eps, const float* gamma,
+                        const float* beta, float* mean_out, float* invstd_out, float* scale_shift, void* stream) {
+  CREID_CHECK_ARG(C > 0 && mean_out && invstd_out && scale_shift &&
+                  (training ? (partial && rows > 0 && count > 0) : (running_mean && running_var)));
   hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(512), 0, as_stream(stream), partial,
-                     (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, mean_out,
-                     invstd_out);
+                     (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, gamma, beta,
+                     mean_out, invstd_out, scale_shift);
   CREID_LAUNCH_RET();
 }
 
@@ -475,15 +500,15 @@ int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* parti
   CREID_LAUNCH_RET();
 }
 
-int creid_bn2d_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                     const void* residual, int relu, int64_t M, int64_t C, int dtype, void* y, void* stream) {
-  CREID_CHECK_ARG(x && mean && invstd && y && M > 0 && C > 0 && C % 8 == 0);
+int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M, int64_t C,
+                     int dtype, void* y, void* stream) {
+  CREID_CHECK_ARG(x && scale_shift && y && M > 0 && C > 0 && C % 8 == 0);
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
-                                (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, M, (int)C, (float*)y),
+                                (const float*)x, scale_shift, (const float*)residual, relu, M, (int)C, (float*)y),
              hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
-                                (const unsigned short*)x, mean, invstd, gamma, beta, (const unsigned short*)residual, relu, M,
+                                (const unsigned short*)x, scale_shift, (const unsigned short*)residual, relu, M,
                                 (int)C, (unsigned short*)y));
   CREID_LAUNCH_RET();
 }
@@ -503,14 +528,14 @@ int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* m
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
                                 invstd, M, (int)C, 128, partial));
   hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(512), 0, s, partial, rows, (int)C,
-                     sums, dgamma_accum, dbeta_accum);
+                     (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
-                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, gamma, sums, M, (int)C,
+                                (const float*)x, (const float*)g, (const float*)act, sums, M, (int)C,
                                 (float*)dx, (float*)gm_out),
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
-                                (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean, invstd,
-                                gamma, sums, M, (int)C, (unsigned short*)dx, (unsigned short*)gm_out));
+                                (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, sums, M,
+                                (int)C, (unsigned short*)dx, (unsigned short*)gm_out));
   CREID_LAUNCH_RET();
 }
 

@@ -123,11 +123,12 @@ def bn2d_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, moment
     rows = partial.shape[0]
     mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
     invstd = torch.empty_like(mean)
-    L.check(lib.creid_bn2d_finalize(L.ptr(partial), rows, Cc, M, L.ptr(rmean), L.ptr(rvar), 1, momentum, eps, L.ptr(mean),
-                                    L.ptr(invstd), st), "bn2d_finalize")
+    ss = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    L.check(lib.creid_bn2d_finalize(L.ptr(partial), rows, Cc, M, L.ptr(rmean), L.ptr(rvar), 1, momentum, eps, L.ptr(gamma),
+                                    L.ptr(beta), L.ptr(mean), L.ptr(invstd), L.ptr(ss), st), "bn2d_finalize")
     y = torch.empty_like(x)
-    L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), L.ptr(residual),
-                                 1 if relu else 0, M, Cc, _dt(x), L.ptr(y), st), "bn2d_apply")
+    L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(ss), L.ptr(residual), 1 if relu else 0, M, Cc, _dt(x), L.ptr(y), st),
+            "bn2d_apply")
     return y, mean, invstd
 
 
@@ -137,7 +138,7 @@ def bn2d_bwd(x, g, act, mean, invstd, gamma, want_gm=False):
     lib, st = L.lib(), L.stream()
     rows = lib.creid_bn2d_bwd_rows(M)
     part = torch.empty((rows, 2, Cc), dtype=torch.float32, device=x.device)
-    sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    sums = torch.empty((3, Cc), dtype=torch.float32, device=x.device)
     dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device)
     dbeta = torch.zeros_like(dgamma)
     dx = torch.empty_like(x)

@@ -205,19 +205,21 @@ int creid_stem_weight_prep(const float* w_oihw, int dtype, void* w_stem, void* s
 
 /* nn.BatchNorm2d (resnet.py:57-62,96,111; momentum 0.1, eps 1e-5) split in three steps:
  * finalize: partial (sum,sumsq) rows -> mean / invstd (+ running-stat update, unbiased variance) when
- * training, or mean = running_mean, invstd = rsqrt(running_var + eps) in eval;
- * apply: y = (x - mean) * invstd * gamma + beta (+ residual) (ReLU if relu) -- the fused
+ * training, or mean = running_mean, invstd = rsqrt(running_var + eps) in eval; also emits the
+ * per-channel affine scale_shift = float[2][C] {gamma*invstd, beta - mean*gamma*invstd};
+ * apply: y = x * scale + shift (+ residual) (ReLU if relu) -- the fused
  * BN + residual-add + ReLU tail of Bottleneck.forward (resnet.py:72-85);
  * bwd: dy = g * [act > 0] (act nullable); dgamma += sum dy*xhat; dbeta += sum dy;
- *      dx = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)); gm_out (nullable) = dy. */
+ *      dx = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)); gm_out (nullable) = dy.
+ *      partial = float[creid_bn2d_bwd_rows(M)][2][C] scratch, sums = float[3][C] scratch. */
 int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t count, float* running_mean,
-                        float* running_var, int training, float momentum, float eps, float* mean_out,
-                        float* invstd_out, void* stream);
+                        float* running_var, int training, float momentum, float eps, const float* gamma,
+                        const float* beta, float* mean_out, float* invstd_out, float* scale_shift,
+                        void* stream);
 int64_t creid_col_stats_rows(int64_t M);
 int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* partial, void* stream);
-int creid_bn2d_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
-                     const float* beta, const void* residual, int relu, int64_t M, int64_t C, int dtype,
-                     void* y, void* stream);
+int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M,
+                     int64_t C, int dtype, void* y, void* stream);
 int64_t creid_bn2d_bwd_rows(int64_t M);
 int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
                    const float* gamma, int64_t M, int64_t C, int dtype, float* partial, float* sums,
