@@ -82,13 +82,14 @@ def run_eval(args, rank, world):
     # weak scaling: every rank ranks its own nq queries against the (all-gathered) gallery
     q_pids = torch.as_tensor(pids[:nq], device="cuda"); g_pids = torch.as_tensor(pids[nq:], device="cuda")
     q_cams = torch.as_tensor(cams[:nq], device="cuda"); g_cams = torch.as_tensor(cams[nq:], device="cuda")
-    gal_shard = feats[nq:].chunk(world)[rank].contiguous() if world > 1 else None
+    from centroids_reid_amd import parallel as par
+    glo, ghi = par.shard_bounds(ng, rank, world)
+    gal_shard = feats[nq + glo:nq + ghi].contiguous() if world > 1 else None
+    gcounts = [par.shard_bounds(ng, r, world)[1] - par.shard_bounds(ng, r, world)[0] for r in range(world)]
 
     def step():
         if world > 1:  # node-level all-gather of (gallery) embeddings before the distance matrix
-            parts = [torch.empty_like(c) for c in feats[nq:].chunk(world)]
-            dist.all_gather(parts, gal_shard)
-            f = torch.cat([feats[:nq]] + parts)
+            f = torch.cat([feats[:nq], par.all_gather_rows(gal_shard, gcounts)])
         else:
             f = feats
         fn, sq = rm.l2_normalize(f, return_sqnorm=True)

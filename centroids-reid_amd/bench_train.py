@@ -10,6 +10,7 @@ import torch.distributed as dist
 
 from .config import get_cfg_defaults
 from .train_ctl_model import CTLModel
+from . import parallel
 
 R50_FWD_BWD_GFLOP_PER_IMG = 24.32     # BASELINE.md section 3 (3 x forward conv FLOPs)
 MFMA_BF16_TFLOPS = 2500.0
@@ -37,15 +38,72 @@ def synthetic_batch(P, K, H, W, step, rank=0, num_classes=751, seed=0):
     return x, labels, camid, is_real
 
 
-def make_grad_sync(world):
-    def sync(model):
-        opt, opt_center = model.optimizers()
-        dist.all_reduce(opt.gflat)
-        opt.grad_scale = 1.0 / world
-        cg = model.center_loss.centers.grad
-        dist.all_reduce(cg)
-        cg.mul_(1.0 / world)
-    return sync
+def conv_shapes(B, H, W, last_stride=1):
+    """(cin, cout, k, stride, Hin, Win) of every non-stem convolution of ResNet50 at this input size."""
+    shapes, h, w, inpl = [], H // 4, W // 4, 64
+    for planes, n, st in zip((64, 128, 256, 512), (3, 4, 6, 3), (1, 2, 2, last_stride)):
+        for b in range(n):
+            s = st if b == 0 else 1
+            shapes.append((inpl, planes, 1, 1, h, w))
+            shapes.append((planes, planes, 3, s, h, w))
+            ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+            shapes.append((planes, planes * 4, 1, 1, ho, wo))
+            if b == 0:
+                shapes.append((inpl, planes * 4, 1, s, h, w))
+            inpl, h, w = planes * 4, ho, wo
+    return shapes
+
+
+def igemm_roofline(B, H, W, time_kernel, reps=5):
+    """Live HIP-event timing of the dominant kernel family (igemm_bf16_kernel: conv forward + data gradient)
+    over the real ResNet50 layer mix: achieved = sum(algorithmic FLOPs) / sum(avg launch duration)."""
+    from . import layers as ly
+    tot_flop = tot_ms = 0.0
+    worst = []
+    for cin, cout, k, s, h, w in conv_shapes(B, H, W):
+        x = torch.randn((B, h, w, cin), device="cuda").to(torch.bfloat16)
+        wt = (torch.randn((cout, cin, k, k), device="cuda") / (cin * k * k) ** 0.5)
+        krsc, crsk = ly.weight_prep(wt, torch.bfloat16)
+        pad = k // 2
+        ms_f = time_kernel(lambda: ly.conv2d_fwd(x, krsc, s, pad, with_stats=True), reps)
+        y = ly.conv2d_fwd(x, krsc, s, pad)
+        ms_d = time_kernel(lambda: ly.conv2d_dgrad(y, crsk, (h, w), s, pad), reps)
+        fl = 2.0 * B * y.shape[1] * y.shape[2] * cout * cin * k * k
+        tot_flop += 2 * fl; tot_ms += ms_f + ms_d
+        worst.append((fl / (ms_f * 1e-3) / 1e12, f"{cin}->{cout} k{k} s{s} {h}x{w}"))
+    worst.sort()
+    return tot_flop / (tot_ms * 1e-3) / 1e12, tot_ms, worst[:3], worst[-3:]
+
+
+def cpu_baseline_train(P, K, H, W):
+    """The CPU oracle (kind 'port': torch-CPU restatement of backbone + heads, autograd backward) on the host
+    cores, same synthetic shapes.  Bounded sample: ONE full 64-image step after a 8-image warm-up, on at most 32
+    threads (torch-CPU convolutions get slower, not faster, when oversubscribed across hundreds of cores)."""
+    from oracle import backbone_oracle as bo, reid_oracle as ro
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = bo.make_state_dict("resnet50", 1, seed=1)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+    sd2 = {**{k: v.clone() for k, v in sd.items()}, **params}
+    C = 751
+    centers = torch.randn(C, 2048, requires_grad=True); fc = (torch.randn(C, 2048) * 0.001).requires_grad_(True)
+    bw = torch.ones(2048, requires_grad=True)
+
+    def step(p):
+        x = torch.randn(p * K, 3, H, W)
+        labels = torch.as_tensor(np.repeat((np.arange(p) * 7) % C, K).astype(np.int64))
+        is_real = torch.ones(p * K, dtype=torch.bool)
+        _, feat = bo.backbone_forward(x, sd2, "resnet50", 1, training=True)
+        o = ro.ctl_heads(feat, labels, is_real, bw, torch.zeros(2048), torch.zeros(2048), torch.ones(2048), fc, centers, p, K)
+        o["total"].backward()
+    step(2)
+    t0 = time.perf_counter()
+    step(P)
+    dt = time.perf_counter() - t0
+    return {"value": P * K / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 step of {P * K} images (fwd + bwd, no optimiser) after an 8-image warm-up, torch-CPU oracle",
+            "seconds": dt}
 
 
 def run(args, rank, world, barrier_sync, time_kernel):
@@ -59,7 +117,7 @@ def run(args, rank, world, barrier_sync, time_kernel):
         for b in model.buffers():
             if b.is_floating_point():
                 dist.broadcast(b, 0)
-        model.grad_sync = make_grad_sync(world)
+        model.grad_sync = parallel.make_grad_sync(world)
     batches = [synthetic_batch(P, K, H, W, s, rank) for s in range(4)]
     use_graph = os.environ.get("CREID_NO_GRAPH", "0") != "1" and world == 1
     if use_graph:
@@ -106,10 +164,14 @@ def run(args, rank, world, barrier_sync, time_kernel):
         res["host_enqueue_ms_per_step"] = t_host / args.steps * 1e3
         res["hip_graph"] = bool(use_graph)
         ms = dt / args.steps * 1e3
-        tf = R50_FWD_BWD_GFLOP_PER_IMG * P * K / (ms * 1e-3) / 1e3
-        res["roofline"] = {"kernel": "whole step (conv fwd+dgrad+wgrad MFMA work / step time)", "bound": "mfma",
-                           "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_TFLOPS,
-                           "traffic": None}
+        tf_step = R50_FWD_BWD_GFLOP_PER_IMG * P * K / (ms * 1e-3) / 1e3
+        res["step_mfma_frac"] = tf_step / MFMA_BF16_TFLOPS     # all conv FLOPs / whole-step time (incl. HBM-bound BN etc.)
+        tf, ig_ms, slow, fast = igemm_roofline(P * K, H, W, time_kernel)
+        res["roofline"] = {"kernel": "igemm_bf16_kernel (conv fwd + dgrad, 105 launches/step, real layer mix)",
+                           "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": tf / MFMA_BF16_TFLOPS, "traffic": None, "ms_per_step": ig_ms,
+                           "slowest_TFs": slow, "fastest_TFs": fast}
+        res["cpu_baseline"] = cpu_baseline_train(P, K, H, W)
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
             "ms_per_step": dt / args.steps * 1e3, "dtype": "bf16",
             "config": {"workload": "ResNet50 256x128 CTL training step: fwd+bwd, centroid-triplet + center + xent, "
