@@ -162,6 +162,38 @@ def cpu_baseline_eval(feats, pids, cams, nq, ng):
                       f"(the reference's own per-query Python loop is ~50x slower, BASELINE.md)", "seconds": dt}
 
 
+def cpu_baseline_train(P, K, H, W):
+    """The CPU oracle (kind 'port': torch-CPU restatement of backbone + heads, autograd backward) on the host
+    cores, same synthetic shapes.  Bounded sample: ONE full 64-image step after a 8-image warm-up, on at most 32
+    threads (torch-CPU convolutions get slower, not faster, when oversubscribed across hundreds of cores)."""
+    from oracle import backbone_oracle as bo, reid_oracle as ro
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = bo.make_state_dict("resnet50", 1, seed=1)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+    sd2 = {**{k: v.clone() for k, v in sd.items()}, **params}
+    C = 751
+    centers = torch.randn(C, 2048, requires_grad=True); fc = (torch.randn(C, 2048) * 0.001).requires_grad_(True)
+    bw = torch.ones(2048, requires_grad=True)
+
+    def step(p):
+        x = torch.randn(p * K, 3, H, W)
+        labels = torch.as_tensor(np.repeat((np.arange(p) * 7) % C, K).astype(np.int64))
+        is_real = torch.ones(p * K, dtype=torch.bool)
+        _, feat = bo.backbone_forward(x, sd2, "resnet50", 1, training=True)
+        o = ro.ctl_heads(feat, labels, is_real, bw, torch.zeros(2048), torch.zeros(2048), torch.ones(2048), fc, centers, p, K)
+        o["total"].backward()
+    step(2)
+    t0 = time.perf_counter()
+    step(P)
+    dt = time.perf_counter() - t0
+    return {"value": P * K / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 step of {P * K} images (fwd + bwd, no optimiser) after an 8-image warm-up, torch-CPU oracle",
+            "seconds": dt}
+
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -182,7 +214,7 @@ def main():
         from centroids_reid_amd import bench_train
         args.steps = args.steps or 30
         args.warmup = args.warmup if args.warmup is not None else 5
-        out = bench_train.run(args, rank, world, barrier_sync, time_kernel)
+        out = bench_train.run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_train)
     else:
         args.steps = args.steps or 5
         args.warmup = args.warmup if args.warmup is not None else 2
