@@ -102,6 +102,91 @@ class ResNet(nn.Module):
             own[name].copy_(param_dict[i])
 
 
+class InstanceNorm2d(nn.Module):
+    def __init__(self, c, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = c, eps
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class IBN(nn.Module):
+    """resnet_ibn_a.py:18-32: first half of the channels InstanceNorm2d(affine), second half BatchNorm2d."""
+
+    def __init__(self, planes):
+        super().__init__()
+        self.half = int(planes / 2)
+        self.IN = InstanceNorm2d(self.half)
+        self.BN = BatchNorm2d(planes - self.half)
+
+
+class Bottleneck_IBN(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, ibn=False, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.bn1 = IBN(planes) if ibn else BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3, stride, 1)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, planes * 4, 1)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _UnusedFC(nn.Module):
+    """resnet_ibn_a.py:92-93: the IBN backbone carries an unused Linear(2048 -> 1000) in its state_dict."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cout, cin), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+
+
+class ResNet_IBN(ResNet):
+    """Parameter tree of modelling/backbones/resnet_ibn_a.py:77-124 (IBN in bn1 of layer1-3, stem WITH ReLU)."""
+    arch = "resnet50_ibn_a"
+    stem_relu = True             # resnet_ibn_a.py:129
+
+    def __init__(self, last_stride=2, layers=LAYERS, num_classes=1000):
+        nn.Module.__init__(self)
+        self.inplanes = 64
+        self.conv1 = Conv2d(3, 64, 7, 2, 3)
+        self.bn1 = BatchNorm2d(64)
+        self.layer1 = self._make_ibn_layer(64, layers[0])
+        self.layer2 = self._make_ibn_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_ibn_layer(256, layers[2], stride=2)
+        self.layer4 = self._make_ibn_layer(512, layers[3], stride=last_stride)
+        self.fc = _UnusedFC(512 * 4, num_classes)
+
+    def _make_ibn_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(Conv2d(self.inplanes, planes * 4, 1, stride, 0), BatchNorm2d(planes * 4))
+        ibn = planes != 512                                                       # resnet_ibn_a.py:116-118
+        layers = [Bottleneck_IBN(self.inplanes, planes, ibn, stride, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck_IBN(self.inplanes, planes, ibn))
+        return nn.Sequential(*layers)
+
+    def load_param(self, model_path):
+        """resnet_ibn_a.py:143-162."""
+        param_dict = torch.load(model_path, map_location="cpu")
+        if "state_dict" in param_dict:
+            param_dict = param_dict["state_dict"]
+        own = self.state_dict()
+        for i in param_dict:
+            if any(t in i for t in ("fc", "bottleneck", "reduce_embeddings.weight", "classifier")):
+                continue
+            own[i[5:] if "base" in i else i].copy_(param_dict[i])
+
+
+def resnet50_ibn_a(last_stride, **kwargs):
+    return ResNet_IBN(last_stride, LAYERS, **kwargs)
+
+
 # ----------------------------------------------------------------------------- engine
 def _desc(B, H, W, cin, cout, k, stride, pad):
     oh = (H + 2 * pad - k) // stride + 1
@@ -111,10 +196,11 @@ def _desc(B, H, W, cin, cout, k, stride, pad):
 
 class _ConvUnit:
     """conv + BN bookkeeping for one (holder conv, holder bn) pair."""
-    __slots__ = ("conv", "bn", "w_krsc", "w_crsk", "k", "stride", "pad", "cin", "cout")
+    __slots__ = ("conv", "bn", "ibn", "w_krsc", "w_crsk", "k", "stride", "pad", "cin", "cout")
 
     def __init__(self, conv, bn):
-        self.conv, self.bn = conv, bn
+        self.ibn = bn if isinstance(bn, IBN) else None
+        self.conv, self.bn = conv, (bn.BN if isinstance(bn, IBN) else bn)
         self.k, self.stride, self.pad = conv.kernel_size, conv.stride, conv.padding
         self.cin, self.cout = conv.in_channels, conv.out_channels
         self.w_krsc = self.w_crsk = None
@@ -193,11 +279,44 @@ class BackboneEngine:
         d, oh, ow = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         M = B * oh * ow
         x = self._empty(M, u.cout)
+        if u.ibn is not None:
+            L.check(lib.creid_conv2d_fwd_nhwc(C.byref(d), L.ptr(a_in), L.ptr(u.w_krsc), L.ptr(x), None, self.dt, st),
+                    "conv2d_fwd")
+            return (x,) + self._ibn_tail(u, x, B, oh * ow, training, relu) + (oh, ow)
         rows = lib.creid_conv2d_bn_partial_rows(C.byref(d)) if training else 0
         part = self._empty(rows * 2, u.cout, dtype=torch.float32) if training else None
         L.check(lib.creid_conv2d_fwd_nhwc(C.byref(d), L.ptr(a_in), L.ptr(u.w_krsc), L.ptr(x), L.ptr(part), self.dt, st),
                 "conv2d_fwd")
         return (x,) + self._bn_tail(u, x, part, rows, M, training, relu, residual) + (oh, ow)
+
+    def _ibn_tail(self, u, x, B, HW, training, relu):
+        lib, st = L.lib(), L.stream()
+        ibn, bn = u.ibn, u.bn
+        rpi = lib.creid_ibn_rows_per_image(HW)
+        part = self._empty(B * rpi * 2, u.cout, dtype=torch.float32)
+        mean = self._empty(B, u.cout, dtype=torch.float32)
+        invstd = self._empty(B, u.cout, dtype=torch.float32)
+        ss = self._empty(B * 2, u.cout, dtype=torch.float32)
+        a = self._empty(B * HW, u.cout)
+        L.check(lib.creid_ibn_fwd(L.ptr(x), B, HW, u.cout, ibn.half, L.ptr(ibn.IN.weight), L.ptr(ibn.IN.bias),
+                                  L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                  1 if training else 0, bn.momentum, bn.eps, 1 if relu else 0, self.dt, L.ptr(part),
+                                  L.ptr(mean), L.ptr(invstd), L.ptr(ss), L.ptr(a), st), "ibn_fwd")
+        return a, mean, invstd
+
+    def _ibn_bwd(self, u, x, g, act, mean, invstd, B, HW):
+        lib, st = L.lib(), L.stream()
+        ibn, bn = u.ibn, u.bn
+        rpi = lib.creid_ibn_rows_per_image(HW)
+        part = self._empty(B * rpi * 2, u.cout, dtype=torch.float32)
+        coef = self._empty(B * 3, u.cout, dtype=torch.float32)
+        per_img = self._empty(B * 2, ibn.half, dtype=torch.float32)
+        dx = self._empty(B * HW, u.cout)
+        L.check(lib.creid_ibn_bwd(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mean), L.ptr(invstd), B, HW, u.cout, ibn.half,
+                                  L.ptr(ibn.IN.weight), L.ptr(bn.weight), self.dt, L.ptr(part), L.ptr(coef), L.ptr(per_img),
+                                  L.ptr(self._grad_of(ibn.IN.weight)), L.ptr(self._grad_of(ibn.IN.bias)),
+                                  L.ptr(self._grad_of(bn.weight)), L.ptr(self._grad_of(bn.bias)), L.ptr(dx), st), "ibn_bwd")
+        return dx, None
 
     def _bn_tail(self, u, x, part, rows, M, training, relu, residual):
         lib, st = L.lib(), L.stream()
@@ -326,7 +445,10 @@ class BackboneEngine:
             self._wgrad(b["c2"], s["a1"], dx2, B, s["h1"], s["w1"])
             da1 = self._dgrad(b["c2"], dx2, B, s["h1"], s["w1"])
             M1 = B * s["h1"] * s["w1"]
-            dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1)
+            if b["c1"].ibn is not None:
+                dx1, _ = self._ibn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], B, s["h1"] * s["w1"])
+            else:
+                dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1)
             self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"])
             if b["ds"] is not None:
                 dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3)

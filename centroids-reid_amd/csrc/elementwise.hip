@@ -632,3 +632,292 @@ int creid_nhwc_to_nchw_f32(const void* x, int64_t B, int64_t HW, int64_t C, int 
 }
 
 }  // extern "C"
+
+// ======================================================================================
+// IBN (modelling/backbones/resnet_ibn_a.py:18-32): channels [0, c_in) use InstanceNorm2d(affine) --
+// per-(image, channel) statistics over H*W, fp32, no running stats -- channels [c_in, C) use
+// BatchNorm2d.  All kernels index statistics / coefficients per (image, channel); the BN half simply
+// holds the same value for every image.  Statistics come from a per-image column pass
+// (partial[(n*rpi + rb)][2][C], rpi row-blocks per image).
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void ibn_col_stats_kernel(const T* __restrict__ x, int HW, int C, int rows_per_block,
+                                                            int rpi, float* __restrict__ partial) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[2][256 * V];
+  const int cpr = C / V, cw = cpr < 32 ? cpr : 32, nrl = 256 / cw;
+  const int cch = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int c0 = (blockIdx.x * cw + cch) * V;
+  const int n = blockIdx.z, rb = blockIdx.y;
+  const int r0 = rb * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+  const T* xi = x + (int64_t)n * HW * C;
+  float s1[V], s2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  if (c0 < C)
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      float v[V];
+      Vec16<T>::load(xi + (int64_t)r * C + c0, v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { s1[k] += v[k]; s2[k] = fmaf(v[k], v[k], s2[k]); }
+    }
+#pragma unroll
+  for (int k = 0; k < V; ++k) { red[0][(rl * cw + cch) * V + k] = s1[k]; red[1][(rl * cw + cch) * V + k] = s2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * cw * V; i += 256) {
+    const int which = i / (cw * V), cl = i - which * cw * V;
+    float a = 0.f;
+    for (int q = 0; q < nrl; ++q) a += red[which][q * cw * V + cl];
+    const int c = blockIdx.x * cw * V + cl;
+    if (c < C) partial[(((int64_t)n * rpi + rb) * 2 + which) * C + c] = a;
+  }
+}
+
+// one thread per (image, channel): mean/invstd [B][C], scale_shift [B][2][C]; BN-half running stats by n == 0
+__global__ __launch_bounds__(256) void ibn_finalize_kernel(const float* __restrict__ partial, int B, int rpi, int HW,
+                                                           int C, int c_in, const float* __restrict__ in_w,
+                                                           const float* __restrict__ in_b,
+                                                           const float* __restrict__ bn_w,
+                                                           const float* __restrict__ bn_b, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, int training, float momentum,
+                                                           float eps, float* __restrict__ mean_out,
+                                                           float* __restrict__ invstd_out,
+                                                           float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0, cnt;
+  float g, b;
+  bool use_running = false;
+  if (c < c_in) {                                  // InstanceNorm: this image only (always batch statistics)
+    for (int r = 0; r < rpi; ++r) {
+      s1 += (double)partial[(((int64_t)n * rpi + r) * 2) * C + c];
+      s2 += (double)partial[(((int64_t)n * rpi + r) * 2 + 1) * C + c];
+    }
+    cnt = (double)HW; g = in_w[c]; b = in_b[c];
+  } else {
+    g = bn_w[c - c_in]; b = bn_b[c - c_in];
+    if (training) {
+      for (int r = 0; r < B * rpi; ++r) {
+        s1 += (double)partial[((int64_t)r * 2) * C + c];
+        s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
+      }
+      cnt = (double)B * HW;
+    } else { use_running = true; cnt = 1.0; }
+  }
+  float mu, is;
+  if (use_running) { mu = rmean[c - c_in]; is = 1.0f / sqrtf(rvar[c - c_in] + eps); }
+  else {
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mu = (float)mean; is = (float)(1.0 / sqrt(var + (double)eps));
+    if (c >= c_in && n == 0) {
+      rmean[c - c_in] = (1.f - momentum) * rmean[c - c_in] + momentum * mu;
+      rvar[c - c_in] = (1.f - momentum) * rvar[c - c_in] + momentum * (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
+    }
+  }
+  mean_out[(int64_t)n * C + c] = mu; invstd_out[(int64_t)n * C + c] = is;
+  const float sc = is * g;
+  scale_shift[((int64_t)n * 2) * C + c] = sc;
+  scale_shift[((int64_t)n * 2 + 1) * C + c] = b - mu * sc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ibn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift,
+                                                        int relu, int64_t M, int HW, int C, T* __restrict__ y) {
+  constexpr int V = Vec16<T>::N;
+  const int cpr = C / V;
+  const int64_t total = M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cpr;
+    const int c0 = (int)(i - row * cpr) * V;
+    const int64_t n = row / HW;
+    float v[V];
+    Vec16<T>::load(x + i * V, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      v[k] = fmaf(v[k], scale_shift[(n * 2) * C + c0 + k], scale_shift[(n * 2 + 1) * C + c0 + k]);
+      if (relu) v[k] = fmaxf(v[k], 0.f);
+    }
+    Vec16<T>::store(y + i * V, v);
+  }
+}
+
+// per-image partial sums of dy and dy*xhat (dy = g * [act > 0])
+template <typename T>
+__global__ __launch_bounds__(256) void ibn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                             const T* __restrict__ act,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int HW, int C,
+                                                             int rows_per_block, int rpi,
+                                                             float* __restrict__ partial) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[2][256 * V];
+  const int cpr = C / V, cw = cpr < 32 ? cpr : 32, nrl = 256 / cw;
+  const int cch = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int c0 = (blockIdx.x * cw + cch) * V;
+  const int n = blockIdx.z, rb = blockIdx.y;
+  const int r0 = rb * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+  const int64_t base = (int64_t)n * HW * C;
+  float s1[V], s2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  if (c0 < C)
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      float xv[V], gv[V];
+      Vec16<T>::load(x + base + (int64_t)r * C + c0, xv);
+      Vec16<T>::load(g + base + (int64_t)r * C + c0, gv);
+      if (act) {
+        float av[V];
+        Vec16<T>::load(act + base + (int64_t)r * C + c0, av);
+#pragma unroll
+        for (int k = 0; k < V; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        s1[k] += gv[k];
+        s2[k] = fmaf(gv[k], (xv[k] - mean[(int64_t)n * C + c0 + k]) * invstd[(int64_t)n * C + c0 + k], s2[k]);
+      }
+    }
+#pragma unroll
+  for (int k = 0; k < V; ++k) { red[0][(rl * cw + cch) * V + k] = s1[k]; red[1][(rl * cw + cch) * V + k] = s2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * cw * V; i += 256) {
+    const int which = i / (cw * V), cl = i - which * cw * V;
+    float a = 0.f;
+    for (int q = 0; q < nrl; ++q) a += red[which][q * cw * V + cl];
+    const int c = blockIdx.x * cw * V + cl;
+    if (c < C) partial[(((int64_t)n * rpi + rb) * 2 + which) * C + c] = a;
+  }
+}
+
+// coef [B][3][C]; d(in_w, in_b) += sum over images of per-image sums; d(bn_w, bn_b) += batch sums (by n == 0)
+__global__ __launch_bounds__(256) void ibn_bwd_finalize_kernel(const float* __restrict__ partial, int B, int rpi, int HW,
+                                                               int C, int c_in, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ in_w,
+                                                               const float* __restrict__ bn_w,
+                                                               float* __restrict__ coef, float* __restrict__ per_img,
+                                                               float* __restrict__ d_bn_w, float* __restrict__ d_bn_b) {
+  const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0, cnt;
+  float g;
+  if (c < c_in) {
+    for (int r = 0; r < rpi; ++r) {
+      s1 += (double)partial[(((int64_t)n * rpi + r) * 2) * C + c];
+      s2 += (double)partial[(((int64_t)n * rpi + r) * 2 + 1) * C + c];
+    }
+    cnt = (double)HW; g = in_w[c];
+    per_img[((int64_t)n * 2) * c_in + c] = (float)s1;         // reduced over images by ibn_in_grad_kernel
+    per_img[((int64_t)n * 2 + 1) * c_in + c] = (float)s2;
+  } else {
+    for (int r = 0; r < B * rpi; ++r) {
+      s1 += (double)partial[((int64_t)r * 2) * C + c];
+      s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
+    }
+    cnt = (double)B * HW; g = bn_w[c - c_in];
+    if (n == 0) { if (d_bn_b) d_bn_b[c - c_in] += (float)s1; if (d_bn_w) d_bn_w[c - c_in] += (float)s2; }
+  }
+  const float invM = (float)(1.0 / cnt);
+  const float mu = mean[(int64_t)n * C + c], is = invstd[(int64_t)n * C + c], k1 = g * is;
+  const float a1 = (float)s1 * invM, a2 = (float)s2 * invM;
+  coef[((int64_t)n * 3) * C + c] = k1;
+  coef[((int64_t)n * 3 + 1) * C + c] = -k1 * is * a2;
+  coef[((int64_t)n * 3 + 2) * C + c] = -k1 * a1 + k1 * is * a2 * mu;
+}
+
+__global__ __launch_bounds__(256) void ibn_in_grad_kernel(const float* __restrict__ per_img, int B, int c_in,
+                                                          float* __restrict__ d_in_w, float* __restrict__ d_in_b) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= c_in) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = 0; n < B; ++n) { s1 += per_img[((int64_t)n * 2) * c_in + c]; s2 += per_img[((int64_t)n * 2 + 1) * c_in + c]; }
+  if (d_in_b) d_in_b[c] += s1;
+  if (d_in_w) d_in_w[c] += s2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                            const T* __restrict__ act, const float* __restrict__ coef,
+                                                            int64_t M, int HW, int C, T* __restrict__ dx) {
+  constexpr int V = Vec16<T>::N;
+  const int cpr = C / V;
+  const int64_t total = M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cpr;
+    const int c0 = (int)(i - row * cpr) * V;
+    const int64_t n = row / HW;
+    float xv[V], gv[V], o[V];
+    Vec16<T>::load(x + i * V, xv);
+    Vec16<T>::load(g + i * V, gv);
+    if (act) {
+      float av[V];
+      Vec16<T>::load(act + i * V, av);
+#pragma unroll
+      for (int k = 0; k < V; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+      o[k] = fmaf(coef[(n * 3) * C + c0 + k], gv[k], fmaf(coef[(n * 3 + 1) * C + c0 + k], xv[k], coef[(n * 3 + 2) * C + c0 + k]));
+    Vec16<T>::store(dx + i * V, o);
+  }
+}
+
+extern "C" {
+
+int64_t creid_ibn_rows_per_image(int64_t HW) { int64_t r = (HW + 127) / 128; return r < 1 ? 1 : r; }
+
+int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* in_b,
+                  const float* bn_w, const float* bn_b, float* running_mean, float* running_var, int training,
+                  float momentum, float eps, int relu, int dtype, float* partial, float* mean_out, float* invstd_out,
+                  float* scale_shift, void* y, void* stream) {
+  CREID_CHECK_ARG(x && y && in_w && in_b && bn_w && bn_b && running_mean && running_var && partial && mean_out &&
+                  invstd_out && scale_shift && B > 0 && HW > 0 && C % 8 == 0 && c_in > 0 && c_in < C);
+  const int rpi = (int)creid_ibn_rows_per_image(HW);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(ibn_col_stats_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rpi, (unsigned)B), dim3(256),
+                                0, s, (const float*)x, (int)HW, (int)C, 128, rpi, partial),
+             hipLaunchKernelGGL(ibn_col_stats_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
+                                dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, 128, rpi, partial));
+  hipLaunchKernelGGL(ibn_finalize_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, partial, (int)B,
+                     rpi, (int)HW, (int)C, (int)c_in, in_w, in_b, bn_w, bn_b, running_mean, running_var, training, momentum,
+                     eps, mean_out, invstd_out, scale_shift);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(ibn_apply_kernel<float>, dim3(ew_blocks(B * HW * C / 4, 1)), dim3(256), 0, s, (const float*)x,
+                                scale_shift, relu, B * HW, (int)HW, (int)C, (float*)y),
+             hipLaunchKernelGGL(ibn_apply_kernel<unsigned short>, dim3(ew_blocks(B * HW * C / 8, 1)), dim3(256), 0, s,
+                                (const unsigned short*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (unsigned short*)y));
+  CREID_LAUNCH_RET();
+}
+
+int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd, int64_t B,
+                  int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* bn_w, int dtype, float* partial,
+                  float* coef, float* per_img, float* d_in_w, float* d_in_b, float* d_bn_w, float* d_bn_b, void* dx,
+                  void* stream) {
+  CREID_CHECK_ARG(x && g && mean && invstd && in_w && bn_w && partial && coef && per_img && dx && B > 0 && HW > 0 &&
+                  C % 8 == 0 && c_in > 0 && c_in < C);
+  const int rpi = (int)creid_ibn_rows_per_image(HW);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(ibn_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rpi, (unsigned)B), dim3(256),
+                                0, s, (const float*)x, (const float*)g, (const float*)act, mean, invstd, (int)HW, (int)C, 128,
+                                rpi, partial),
+             hipLaunchKernelGGL(ibn_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
+                                dim3(256), 0, s, (const unsigned short*)x, (const unsigned short*)g,
+                                (const unsigned short*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial));
+  hipLaunchKernelGGL(ibn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, partial,
+                     (int)B, rpi, (int)HW, (int)C, (int)c_in, mean, invstd, in_w, bn_w, coef, per_img, d_bn_w, d_bn_b);
+  hipLaunchKernelGGL(ibn_in_grad_kernel, dim3((unsigned)((c_in + 255) / 256)), dim3(256), 0, s, per_img, (int)B, (int)c_in,
+                     d_in_w, d_in_b);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(ibn_bwd_apply_kernel<float>, dim3(ew_blocks(B * HW * C / 4, 1)), dim3(256), 0, s,
+                                (const float*)x, (const float*)g, (const float*)act, coef, B * HW, (int)HW, (int)C, (float*)dx),
+             hipLaunchKernelGGL(ibn_bwd_apply_kernel<unsigned short>, dim3(ew_blocks(B * HW * C / 8, 1)), dim3(256), 0, s,
+                                (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, coef, B * HW,
+                                (int)HW, (int)C, (unsigned short*)dx));
+  CREID_LAUNCH_RET();
+}
+
+}  // extern "C"

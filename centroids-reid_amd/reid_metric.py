@@ -167,3 +167,34 @@ class R1_mAP:
                                                self.max_rank, respect_camids)
         self.last = dict(distmat=distmat, indices=indices, single_performance=single)
         return cmc, mAP, all_topk
+
+    def compute_chunked(self, feats, pids, camids, query_chunk=4096):
+        """Same result as compute() for galleries whose m x n matrix should not be materialised at once
+        (the reference's `_commpute_batches_double` path, utils/reid_metric.py:93-110,126-129, chunks the
+        gallery on the host instead): query rows are processed `query_chunk` at a time -- distance tile,
+        rank, CMC/AP scan all on the device -- and only per-query (valid, AP, first) results are kept."""
+        if not isinstance(feats, torch.Tensor) or not feats.is_cuda:
+            raise L.CreidError("R1_mAP.compute_chunked needs device features (no CPU fallback)")
+        from .parallel import merge_eval_results
+        feats = feats.float().contiguous()
+        nq = self.num_query
+        if self.feat_norm:
+            f, sq = l2_normalize(feats, out_dtype=self.compute_dtype, return_sqnorm=True)
+        else:
+            f = feats if self.compute_dtype == torch.float32 else feats.to(self.compute_dtype)
+            sq = row_sqnorm(f)
+        g, gg = f[nq:], sq[nq:].contiguous()
+        pids = np.asarray(pids); camids = np.asarray(camids)
+        dev = feats.device
+        gp, gc = _dev_i64(pids[nq:], dev), _dev_i64(camids[nq:], dev)
+        vs, aps, firsts = [], [], []
+        for lo in range(0, nq, query_chunk):
+            hi = min(nq, lo + query_chunk)
+            d = get_euclidean(f[lo:hi], g, sq[lo:hi].contiguous(), gg)
+            idx = rank_rows(d)
+            del d
+            _, _, _, _, v, a, fr = eval_func_device(idx, pids[lo:hi], gp, camids[lo:hi], gc, self.max_rank)
+            vs.append(v); aps.append(a); firsts.append(fr)
+            del idx
+        v = torch.cat(vs).cpu().numpy() > 0; a = torch.cat(aps).cpu().numpy(); fr = torch.cat(firsts).cpu().numpy()
+        return merge_eval_results(v, a, fr, min(self.max_rank, g.shape[0]))

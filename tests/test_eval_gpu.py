@@ -147,3 +147,15 @@ def test_full_size_duke_properties(rm):
     # (5) a 64-query slice of the matrix against float64 CPU arithmetic
     fn = ro.l2_normalize(f[:64].cpu().double()), ro.l2_normalize(f[nq:nq + 512].cpu().double())
     np.testing.assert_allclose(d[:64, :512].cpu().numpy(), ro.sqdist_matrix(*fn).numpy(), rtol=0, atol=5e-6)
+
+
+def test_chunked_compute_equals_full(rm):
+    rng = np.random.default_rng(23)
+    nq, ng, D = 333, 1500, 128
+    f = torch.from_numpy(rng.standard_normal((nq + ng, D)).astype(np.float32)).cuda()
+    pids = rng.integers(0, 60, nq + ng); cams = rng.integers(0, 5, nq + ng)
+    cmc, mAP, topk = rm.R1_mAP(num_query=nq).compute(f, pids, cams)
+    cmc2, mAP2, topk2 = rm.R1_mAP(num_query=nq).compute_chunked(f, pids, cams, query_chunk=100)
+    assert abs(mAP - mAP2) < 1e-12
+    np.testing.assert_allclose(cmc, cmc2, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(topk, topk2, rtol=0, atol=1e-12)
