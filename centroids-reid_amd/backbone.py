@@ -248,20 +248,33 @@ class BackboneEngine:
                     yield b[k]
 
     def prep_weights(self):
-        """fp32 OIHW master weights -> compute-dtype [O][r][s][I] and [I][r][s][O] copies."""
+        """fp32 OIHW master weights -> compute-dtype [O][r][s][I] and [I][r][s][O] copies (ONE launch for all
+        52 non-stem convolutions through a device descriptor table, rebuilt only if a pointer moved)."""
+        import numpy as np
         lib, st = L.lib(), L.stream()
-        for u in self.all_units():
-            w = u.conv.weight
-            if u is self.stem:
-                if u.w_krsc is None:
-                    u.w_krsc = self._empty(64, 8, 32)
-                L.check(lib.creid_stem_weight_prep(L.ptr(w), self.dt, L.ptr(u.w_krsc), st), "stem_weight_prep")
-                continue
+        units = [u for u in self.all_units() if u is not self.stem]
+        for u in units:
             if u.w_krsc is None:
                 u.w_krsc = self._empty(u.cout, u.k, u.k, u.cin)
                 u.w_crsk = self._empty(u.cin, u.k, u.k, u.cout)
-            L.check(lib.creid_weight_prep(L.ptr(w), u.cout, u.cin, u.k, u.k, self.dt, L.ptr(u.w_krsc),
-                                          L.ptr(u.w_crsk), st), "weight_prep")
+        if self.stem.w_krsc is None:
+            self.stem.w_krsc = self._empty(64, 8, 32)
+        key = tuple(u.conv.weight.data_ptr() for u in units)
+        if getattr(self, "_wprep_key", None) != key:
+            rec = np.zeros(len(units), dtype=np.dtype([("w", "<u8"), ("krsc", "<u8"), ("crsk", "<u8"), ("O", "<i4"),
+                                                        ("I", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("start", "<i8")]))
+            assert lib.creid_weight_prep_entry_bytes() == rec.dtype.itemsize == 48
+            start = 0
+            for i, u in enumerate(units):
+                rec[i] = (u.conv.weight.data_ptr(), u.w_krsc.data_ptr(), u.w_crsk.data_ptr(), u.cout, u.cin, u.k, u.k, start)
+                start += u.cout * u.cin * u.k * u.k
+            self._wprep_tab = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+            self._wprep_total = start
+            self._wprep_key = key
+        L.check(lib.creid_weight_prep_multi(L.ptr(self._wprep_tab), len(units), self._wprep_total, self.dt, st),
+                "weight_prep_multi")
+        L.check(lib.creid_stem_weight_prep(L.ptr(self.stem.conv.weight), self.dt, L.ptr(self.stem.w_krsc), st),
+                "stem_weight_prep")
         self.weights_dirty = False
 
     def fold_counters(self):

@@ -62,34 +62,38 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(IGemmGeom g, const unsi
   const int kcol = k0 + 8 * b_ch;
   const int tap = kcol >> g.log2span, cc = kcol & span_mask;
   const int tr = tap / g.kw, ts = tap - tr * g.kw;
-  uint4 ra[NA], rb[NBL];
-  auto gload = [&](int mb) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int m = mb + a_row + RA * i;
-      ra[i] = (m < m_end) ? *reinterpret_cast<const uint4*>(dy + (int64_t)m * NCO + co0 + 8 * a_ch)
-                          : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NBL; ++i) {
-      const int m = mb + b_row + RB * i;
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (m < m_end) {
-        int b, rem, oy, ox;
-        fast_divmod(m, g.OH * g.OW, g.inv_ohow, b, rem);
-        fast_divmod(rem, g.OW, g.inv_ow, oy, ox);
-        int iy, ix;
-        if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))
-          rb[i] = *reinterpret_cast<const uint4*>(x + (int64_t)((b * g.SH + iy) * g.SW + ix) * g.pitch + cc);
-      }
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&Ad[(a_row + RA * i) * PA + 8 * a_ch]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < NBL; ++i) *reinterpret_cast<uint4*>(&Bx[(b_row + RB * i) * PB + 8 * b_ch]) = rb[i];
-  };
+  // 3-deep register prefetch ring (first-class vector type so the ring stays in VGPRs)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  struct Stage { u32x4 a[NA]; u32x4 b[NBL]; };
+  Stage st0, st1, st2;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#define WG_GLOAD(MB_, ST)                                                                                \
+  do {                                                                                                   \
+    const int mb_ = (MB_);                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                     \
+      const int m = mb_ + a_row + RA * i;                                                                \
+      ST.a[i] = (m < m_end) ? *reinterpret_cast<const u32x4*>(dy + (int64_t)m * NCO + co0 + 8 * a_ch) : zero4; \
+    }                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < NBL; ++i) {                                                    \
+      const int m = mb_ + b_row + RB * i;                                                                \
+      ST.b[i] = zero4;                                                                                   \
+      if (m < m_end) {                                                                                   \
+        int b, rem, oy, ox;                                                                              \
+        fast_divmod(m, g.OH * g.OW, g.inv_ohow, b, rem);                                                 \
+        fast_divmod(rem, g.OW, g.inv_ow, oy, ox);                                                        \
+        int iy, ix;                                                                                      \
+        if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))                                                  \
+          ST.b[i] = *reinterpret_cast<const u32x4*>(x + (int64_t)((b * g.SH + iy) * g.SW + ix) * g.pitch + cc); \
+      }                                                                                                  \
+    }                                                                                                    \
+  } while (0)
+#define WG_LSTORE(ST)                                                                                    \
+  do {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                       \
+      *reinterpret_cast<u32x4*>(&Ad[(a_row + RA * i) * PA + 8 * a_ch]) = ST.a[i];                        \
+    _Pragma("unroll") for (int i = 0; i < NBL; ++i)                                                      \
+      *reinterpret_cast<u32x4*>(&Bx[(b_row + RB * i) * PB + 8 * b_ch]) = ST.b[i];                        \
+  } while (0)
 
   f32x16 acc[IM][JN];
 #pragma unroll
@@ -103,12 +107,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(IGemmGeom g, const unsi
   const int li = lane & 15;
   const int t_row = 8 * (lane >> 5) + (li >> 2), t_col = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
 
-  gload(m_begin);
+  // loads past m_end are predicated to zero, so the ring can always run 3 steps ahead
+  WG_GLOAD(m_begin, st0);
+  WG_GLOAD(m_begin + WKS, st1);
+  WG_GLOAD(m_begin + 2 * WKS, st2);
   for (int mb = m_begin; mb < m_end; mb += WKS) {
     __syncthreads();            // previous step's fragment reads are done
-    lstore();
+    WG_LSTORE(st0);
     __syncthreads();
-    if (mb + WKS < m_end) gload(mb + WKS);
+    st0 = st1; st1 = st2;
+    WG_GLOAD(mb + 3 * WKS, st2);
 #pragma unroll
     for (int kk = 0; kk < WKS / 16; ++kk) {
       s16x4 al[2], ah[2], bl[2], bh[2];
@@ -129,6 +137,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(IGemmGeom g, const unsi
                                                               __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
     }
   }
+#undef WG_GLOAD
+#undef WG_LSTORE
   // partial tile -> workspace [split][NCO][K]
   const int l31 = lane & 31, kh = lane >> 5;
   float* wsp = ws + (int64_t)split * NCO * g.K;

@@ -34,7 +34,7 @@ template <> struct Vec16<unsigned short> {
 // ------------------------------------------------------------------ BN statistics finalize
 // partial: [rows][2][C] (sum, sumsq per 128-row conv tile).  training: mean/invstd from the batch and
 // running-stat update (momentum, unbiased variance); eval: mean = running_mean, invstd = rsqrt(rv+eps).
-__global__ __launch_bounds__(512) void bn2d_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+__global__ __launch_bounds__(1024) void bn2d_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                             double count, float* __restrict__ rmean,
                                                             float* __restrict__ rvar, int training, float momentum,
                                                             float eps, const float* __restrict__ gamma,
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(512) void bn2d_finalize_kernel(const float* __restr
                                                             float* __restrict__ mean_out,
                                                             float* __restrict__ invstd_out,
                                                             float* __restrict__ scale_shift) {
-  // 32 channels x 16 row-groups per workgroup: coalesced 128-B reads, fp64 accumulation, LDS tree
-  __shared__ double red[16][2][32];
+  // 32 channels x 32 row-groups per workgroup: coalesced 128-B reads, fp64 accumulation, LDS tree
+  __shared__ double red[32][2][32];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   if (!training) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) void bn2d_finalize_kernel(const float* __restr
   }
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int r = rg; r < rows; r += 16) {
+    for (int r = rg; r < rows; r += 32) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512) void bn2d_finalize_kernel(const float* __restr
   if (rg == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    for (int q = 0; q < 32; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -209,18 +209,18 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
 }
 
 // sums[2][C] = sum over row blocks; dgamma += sum dy*xhat ; dbeta += sum dy
-__global__ __launch_bounds__(512) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+__global__ __launch_bounds__(1024) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                                 double count, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 float* __restrict__ sums, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta) {
-  __shared__ double red[16][2][32];
+  __shared__ double red[32][2][32];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int r = rg; r < rows; r += 16) {
+    for (int r = rg; r < rows; r += 32) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512) void bn2d_bwd_finalize_kernel(const float* __r
   if (rg == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    for (int q = 0; q < 32; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
     // dx = k1*(dy - a1 - xhat*a2) = A*dy + B*x + Cc  with per-channel A, B, Cc
     const float invM = (float)(1.0 / count);
     const float mu = mean[c], is = invstd[c], k1 = (gamma ? gamma[c] : 1.f) * is;
@@ -433,6 +433,28 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
   }
 }
 
+// All convolutions in ONE launch: a device table of {src, krsc, crsk, O, I, kh, kw, first element}; each
+// thread finds its tensor by binary search over the cumulative element counts.
+struct WPrepEntry { const float* w; void* krsc; void* crsk; int O, I, kh, kw; int64_t start; };
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const WPrepEntry* __restrict__ tab, int n_ent,
+                                                                int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int lo = 0, hi = n_ent - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= i) lo = mid; else hi = mid - 1; }
+    const WPrepEntry e = tab[lo];
+    const int64_t j = i - e.start;
+    const int c = (int)(j % e.I);
+    int64_t t = j / e.I;
+    const int s = (int)(t % e.kw); t /= e.kw;
+    const int r = (int)(t % e.kh);
+    const int o = (int)(t / e.kh);
+    const float v = e.w[(((int64_t)o * e.I + c) * e.kh + r) * e.kw + s];
+    ElemIO<T>::st(reinterpret_cast<T*>(e.krsc) + j, v);
+    if (e.crsk) ElemIO<T>::st(reinterpret_cast<T*>(e.crsk) + (((int64_t)c * e.kh + r) * e.kw + s) * e.O + o, v);
+  }
+}
+
 // stem: OIHW [64,3,7,7] -> [64][8][32] with k = r*32 + s*4 + c (zero padded)
 template <typename T>
 __global__ __launch_bounds__(256) void stem_weight_prep_kernel(const float* __restrict__ w, T* __restrict__ out) {
@@ -480,7 +502,7 @@ int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t c
                         const float* beta, float* mean_out, float* invstd_out, float* scale_shift, void* stream) {
   CREID_CHECK_ARG(C > 0 && mean_out && invstd_out && scale_shift &&
                   (training ? (partial && rows > 0 && count > 0) : (running_mean && running_var)));
-  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(512), 0, as_stream(stream), partial,
+  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, as_stream(stream), partial,
                      (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, gamma, beta,
                      mean_out, invstd_out, scale_shift);
   CREID_LAUNCH_RET();
@@ -527,7 +549,7 @@ int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* m
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
                                 invstd, M, (int)C, 128, partial));
-  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(512), 0, s, partial, rows, (int)C,
+  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, s, partial, rows, (int)C,
                      (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
@@ -607,6 +629,19 @@ int creid_weight_prep(const float* w_oihw, int64_t O, int64_t I, int64_t kh, int
                                 (int)kh, (int)kw, (float*)w_krsc, (float*)w_crsk),
              hipLaunchKernelGGL(weight_prep_kernel<unsigned short>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, w_oihw,
                                 (int)O, (int)I, (int)kh, (int)kw, (unsigned short*)w_krsc, (unsigned short*)w_crsk));
+  CREID_LAUNCH_RET();
+}
+
+int64_t creid_weight_prep_entry_bytes(void) { return (int64_t)sizeof(WPrepEntry); }
+
+int creid_weight_prep_multi(const void* table_dev, int64_t n_entries, int64_t total_elems, int dtype, void* stream) {
+  CREID_CHECK_ARG(table_dev && n_entries > 0 && total_elems > 0);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(weight_prep_multi_kernel<float>, dim3(ew_blocks(total_elems, 1)), dim3(256), 0, s,
+                                (const WPrepEntry*)table_dev, (int)n_entries, total_elems),
+             hipLaunchKernelGGL(weight_prep_multi_kernel<unsigned short>, dim3(ew_blocks(total_elems, 1)), dim3(256), 0, s,
+                                (const WPrepEntry*)table_dev, (int)n_entries, total_elems));
   CREID_LAUNCH_RET();
 }
 

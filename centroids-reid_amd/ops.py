@@ -7,7 +7,11 @@ from __future__ import annotations
 
 import torch
 
+import os
+
 from . import _lib as L
+
+_DETERMINISTIC = os.environ.get("CREID_DETERMINISTIC", "0") == "1"
 
 
 def _u8(mask):
@@ -213,7 +217,9 @@ class LinearNoBiasFn(torch.autograd.Function):
         B, D = x.shape
         C = w.shape[0]
         ctx.save_for_backward(x, w)
-        sk = 1     # deterministic (split_k > 1 would combine K-slices with atomics)
+        # few output tiles, long K: split K 8-way (partials combined by fp32 atomics; order-dependent in the last
+        # bits only -- set CREID_DETERMINISTIC=1 for the single-pass kernel)
+        sk = 1 if _DETERMINISTIC else 8
         return gemm_f32(x, D, 1, w, 1, D, B, C, D, split_k=sk)
 
     @staticmethod
@@ -222,6 +228,6 @@ class LinearNoBiasFn(torch.autograd.Function):
         dy = _f32c(dy)
         B, D = x.shape
         C = w.shape[0]
-        dx = gemm_f32(dy, C, 1, w, D, 1, B, D, C) if ctx.needs_input_grad[0] else None      # dy @ W
+        dx = gemm_f32(dy, C, 1, w, D, 1, B, D, C, split_k=1 if _DETERMINISTIC else 4) if ctx.needs_input_grad[0] else None  # dy @ W
         dw = gemm_f32(dy, 1, C, x, D, 1, C, D, B) if ctx.needs_input_grad[1] else None      # dy^T @ x
         return dx, dw
