@@ -88,26 +88,48 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
                 dist.broadcast(b, 0)
         model.grad_sync = parallel.make_grad_sync(world)
     batches = [synthetic_batch(P, K, H, W, s, rank) for s in range(4)]
-    use_graph = os.environ.get("CREID_NO_GRAPH", "0") != "1" and world == 1
+    use_graph = os.environ.get("CREID_NO_GRAPH", "0") != "1"
+    split_graph = world > 1 or os.environ.get("CREID_SPLIT_GRAPH", "0") == "1"
     if use_graph:
-        # The whole step (prep, fwd, losses, bwd, optimiser kernels) is captured ONCE into a hipGraph; every
-        # timed step copies a fresh synthetic batch into the static input buffers and replays it.
+        # The step is captured ONCE into hipGraphs; every timed step copies a fresh synthetic batch into the
+        # static input buffers and replays.  Single GPU: one graph for the whole step.  Data parallel: graph A =
+        # forward + losses + backward, then the RCCL all-reduce of the flat gradient buffer (eager, same stream),
+        # then graph B = Adam + center SGD.
         sx, sl = batches[0][0].clone(), batches[0][1].clone()
         static = (sx, sl, batches[0][2], batches[0][3])
+        sync = model.grad_sync
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for s in range(3):
                 model.training_step(static, s)
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            gout = model.training_step(static, 0)
+        if not split_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gout = model.training_step(static, 0)
 
-        def one_step(s):
-            sx.copy_(batches[s % 4][0]); sl.copy_(batches[s % 4][1])
-            graph.replay()
-            return gout
+            def one_step(s):
+                sx.copy_(batches[s % 4][0]); sl.copy_(batches[s % 4][1])
+                graph.replay()
+                return gout
+        else:
+            model.grad_sync = None
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                gout = model.forward_backward(static, 0)
+            if sync is not None:
+                sync(model)                      # also fixes opt.grad_scale = 1/world before graph B is captured
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                model.apply_optimizers()
+
+            def one_step(s):
+                sx.copy_(batches[s % 4][0]); sl.copy_(batches[s % 4][1])
+                ga.replay()
+                if sync is not None:
+                    sync(model)
+                gb.replay()
+                return gout
     else:
         def one_step(s):
             return model.training_step(batches[s % 4], s)

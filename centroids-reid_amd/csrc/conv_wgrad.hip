@@ -11,6 +11,7 @@
 // The pixel range is split over gridDim.y workgroups; fp32 partial tiles go to the workspace and
 // wgrad_reduce sums them (deterministic) and scatters into the OIHW fp32 gradient.
 #include "conv_common.hpp"
+#include <stdlib.h>
 
 namespace {
 constexpr int WKS = 64;   // pixels per k-step (bf16)
@@ -277,7 +278,8 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   p.tiles_k = K / p.tn;
   p.tiles = (NCO / p.tm) * p.tiles_k;
   const int ks = (dtype == CREID_BF16) ? WKS : WKF;
-  int splits = (512 + p.tiles - 1) / p.tiles;
+  static const int target = [] { const char* e = getenv("CREID_WGRAD_TARGET_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  int splits = (target + p.tiles - 1) / p.tiles;
   const int max_splits = (M + 4 * ks - 1) / (4 * ks);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -27,6 +27,26 @@ class CTLModel(ModelBase):
         self.grad_sync = None          # optional callable(model) run between backward and the optimiser steps
 
     def training_step(self, batch, batch_idx, optimizer_idx=None):
+        """train_ctl_model.py:38-179 = forward_backward (everything up to manual_backward) -> optional
+        data-parallel gradient sync -> apply_optimizers.  The two halves are separately callable so that a
+        launcher can capture each into a hipGraph and run the RCCL all-reduce between them."""
+        out = self.forward_backward(batch, batch_idx)
+        if self.grad_sync is not None:
+            self.grad_sync(self)                                               # data-parallel all-reduce (RCCL)
+        self.apply_optimizers()
+        return out
+
+    def apply_optimizers(self):
+        hp = self.hparams
+        opt, opt_center = self.optimizers(use_pl_optimizer=True)
+        opt.step()                                                             # :155
+        eng = getattr(self.backbone, "_engine", None)
+        if eng is not None:
+            eng.weights_dirty = True
+        opt_center.grad_mul = 1.0 / hp.SOLVER.CENTER_LOSS_WEIGHT               # :157-158 (fused into the step)
+        opt_center.step()                                                      # :159
+
+    def forward_backward(self, batch, batch_idx=0):
         hp = self.hparams
         opt, opt_center = self.optimizers(use_pl_optimizer=True)
         if hp.SOLVER.USE_WARMUP_LR:                                           # :41-49
@@ -103,14 +123,6 @@ class CTLModel(ModelBase):
 
         total_loss = contrastive_loss_step + center_loss + xent_query + contrastive_loss_query       # :150-152
         self.manual_backward(total_loss, optimizer=opt)
-        if self.grad_sync is not None:
-            self.grad_sync(self)                                               # data-parallel all-reduce (RCCL)
-        opt.step()
-        eng = getattr(self.backbone, "_engine", None)
-        if eng is not None:
-            eng.weights_dirty = True
-        opt_center.grad_mul = 1.0 / hp.SOLVER.CENTER_LOSS_WEIGHT               # :157-158 (fused into the step)
-        opt_center.step()
 
         for name, val in zip(self.losses_names, (xent_query, contrastive_loss_query, center_loss, contrastive_loss_step)):
             self.losses_dict[name].append(val.detach())
