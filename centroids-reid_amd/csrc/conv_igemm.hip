@@ -11,6 +11,11 @@
 // activation dtype, and optional per-tile per-channel (sum, sum of squares) partials of the fp32
 // accumulators for the training-mode BatchNorm that follows every convolution.
 #include "conv_common.hpp"
+#include <stdlib.h>
+
+// Out-of-image taps read this 128-byte page of zeros instead of selecting zeros per dword (saves 3 VALU
+// per load in the gather path).
+__device__ __attribute__((aligned(128))) unsigned g_zero_page[32];
 
 // ------------------------------------------------------------------------------------ bf16
 template <int BN>
@@ -54,15 +59,17 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IGemmGeom g, const u
   // A-row source pointers are recomputed only when the k-loop enters a new tap (tap-major K order);
   // inside a tap consecutive k-tiles just advance by 64 channels.
   const unsigned short* aptr[4];
-  bool av[4];
+  int amul[4];                 // 1 for a real source row, 0 for the zero page (kills the channel offset)
   int cur_tap = -1;
+  const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_zero_page) + 8 * lch;
   auto set_tap = [&](int tap) {
     const int r = tap / g.kw, s = tap - r * g.kw;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int iy, ix;
-      av[i] = vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix);
-      aptr[i] = src + (int64_t)(bpix[i] + (av[i] ? iy * g.SW + ix : 0)) * g.pitch + 8 * lch;
+      const bool ok = vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix);
+      aptr[i] = ok ? src + (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + 8 * lch : zpage;
+      amul[i] = ok ? 1 : 0;
     }
   };
   // 3-deep register prefetch ring: the loads of k-tile t+3 are issued while tile t is multiplied, so a
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IGemmGeom g, const u
   struct Stage { u32x4 a0, a1, a2, a3, b0, b1, b2, b3; };
   Stage st0, st1, st2;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-#define IGEMM_LDA(I_, DST, C_) DST = av[I_] ? *reinterpret_cast<const u32x4*>(aptr[I_] + (C_)) : zero4
+#define IGEMM_LDA(I_, DST, C_) DST = *reinterpret_cast<const u32x4*>(aptr[I_] + (C_) * amul[I_])
 #define IGEMM_LDA_G(I_, DST, R_, S_, C_)                                                                \
   do {                                                                                                  \
     int iy, ix;                                                                                         \
@@ -146,18 +153,37 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IGemmGeom g, const u
                                                               __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
     }
   };
-  // every prefetch is unconditional (the tile index is clamped; a redundant re-load of the last tile is
-  // harmless); the ring rotates by register moves so there is ONE lstore/compute site in the loop body
+  // Every prefetch is unconditional (the tile index is clamped; re-loading the last tile is harmless).
+  // Main loop: whole triples of k-tiles with the ring stages named statically (no register rotation);
+  // the 0-2 leftover tiles run through a rotating tail.
   const int last = nk - 1;
   IGEMM_GLOAD(0, st0);
   IGEMM_GLOAD(min(1, last), st1);
   IGEMM_GLOAD(min(2, last), st2);
-  for (int t = 0; t < nk; ++t) {
+  const int nk3 = nk - nk % 3;
+  int t = 0;
+  for (; t < nk3; t += 3) {
     __syncthreads();               // fragment reads of the previous tile are done
     IGEMM_LSTORE(st0);
     __syncthreads();
-    st0 = st1; st1 = st2;
-    IGEMM_GLOAD(min(t + 3, last), st2);
+    IGEMM_GLOAD(min(t + 3, last), st0);
+    compute();
+    __syncthreads();
+    IGEMM_LSTORE(st1);
+    __syncthreads();
+    IGEMM_GLOAD(min(t + 4, last), st1);
+    compute();
+    __syncthreads();
+    IGEMM_LSTORE(st2);
+    __syncthreads();
+    IGEMM_GLOAD(min(t + 5, last), st2);
+    compute();
+  }
+  for (; t < nk; ++t) {            // at most two iterations
+    __syncthreads();
+    IGEMM_LSTORE(st0);
+    __syncthreads();
+    st0 = st1;
     compute();
   }
 #undef IGEMM_GLOAD
@@ -360,7 +386,8 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   const int tiles_m = (g.M + 127) / 128;
   // pick the N tile: 128 unless that leaves the chip (256 CUs) under-filled or N is only 64
   int bn = 128;
-  if (g.N % 128 != 0 || (int64_t)tiles_m * (g.N / 128) < 384) bn = 64;
+  static const int min_wgs = [] { const char* e = getenv("CREID_IGEMM_BN128_MIN_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
+  if (g.N % 128 != 0 || (int64_t)tiles_m * (g.N / 128) < min_wgs) bn = 64;
   if (g.N % bn != 0) return CREID_E_SHAPE;
   const int tiles_n = g.N / bn;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
