@@ -54,7 +54,7 @@ SIGNATURES = {
     "creid_image_to_nhwc4_pad": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
     "creid_weight_prep": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),
     "creid_weight_prep_entry_bytes": (_i64, []),
-    "creid_weight_prep_multi": (C.c_int, [_p, _i64, _i64, C.c_int, _p]),
+    "creid_weight_prep_multi": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
     "creid_stem_weight_prep": (C.c_int, [_p, C.c_int, _p, _p]),
     "creid_bn2d_finalize": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, C.c_int, _f32, _f32, _p, _p, _p, _p, _p, _p]),
     "creid_col_stats_rows": (_i64, [_i64]),

@@ -264,15 +264,18 @@ class BackboneEngine:
             rec = np.zeros(len(units), dtype=np.dtype([("w", "<u8"), ("krsc", "<u8"), ("crsk", "<u8"), ("O", "<i4"),
                                                         ("I", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("start", "<i8")]))
             assert lib.creid_weight_prep_entry_bytes() == rec.dtype.itemsize == 48
-            start = 0
+            start, tiles, tstart = 0, 0, np.zeros(len(units), np.int32)
             for i, u in enumerate(units):
                 rec[i] = (u.conv.weight.data_ptr(), u.w_krsc.data_ptr(), u.w_crsk.data_ptr(), u.cout, u.cin, u.k, u.k, start)
                 start += u.cout * u.cin * u.k * u.k
+                tstart[i] = tiles
+                tiles += ((u.cout + 31) // 32) * ((u.cin + 31) // 32)
             self._wprep_tab = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
-            self._wprep_total = start
+            self._wprep_tiles = torch.from_numpy(tstart).to(self.device)
+            self._wprep_total = tiles
             self._wprep_key = key
-        L.check(lib.creid_weight_prep_multi(L.ptr(self._wprep_tab), len(units), self._wprep_total, self.dt, st),
-                "weight_prep_multi")
+        L.check(lib.creid_weight_prep_multi(L.ptr(self._wprep_tab), L.ptr(self._wprep_tiles), len(units), self._wprep_total,
+                                            self.dt, st), "weight_prep_multi")
         L.check(lib.creid_stem_weight_prep(L.ptr(self.stem.conv.weight), self.dt, L.ptr(self.stem.w_krsc), st),
                 "stem_weight_prep")
         self.weights_dirty = False

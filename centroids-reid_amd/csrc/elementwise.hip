@@ -436,22 +436,38 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 // All convolutions in ONE launch: a device table of {src, krsc, crsk, O, I, kh, kw, first element}; each
 // thread finds its tensor by binary search over the cumulative element counts.
 struct WPrepEntry { const float* w; void* krsc; void* crsk; int O, I, kh, kw; int64_t start; };
+// One workgroup per (entry, 32x32 (o, c) tile): for every tap the tile is read coalesced along c, written to
+// krsc coalesced along c, transposed through LDS and written to crsk coalesced along o.
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const WPrepEntry* __restrict__ tab, int n_ent,
-                                                                int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    int lo = 0, hi = n_ent - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= i) lo = mid; else hi = mid - 1; }
-    const WPrepEntry e = tab[lo];
-    const int64_t j = i - e.start;
-    const int c = (int)(j % e.I);
-    int64_t t = j / e.I;
-    const int s = (int)(t % e.kw); t /= e.kw;
-    const int r = (int)(t % e.kh);
-    const int o = (int)(t / e.kh);
-    const float v = e.w[(((int64_t)o * e.I + c) * e.kh + r) * e.kw + s];
-    ElemIO<T>::st(reinterpret_cast<T*>(e.krsc) + j, v);
-    if (e.crsk) ElemIO<T>::st(reinterpret_cast<T*>(e.crsk) + (((int64_t)c * e.kh + r) * e.kw + s) * e.O + o, v);
+                                                                const int* __restrict__ tile_start) {
+  __shared__ float tl[32][33];
+  int lo = 0, hi = n_ent - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_start[mid] <= bid) lo = mid; else hi = mid - 1; }
+  const WPrepEntry e = tab[lo];
+  const int tiles_c = (e.I + 31) / 32;
+  const int tix = bid - tile_start[lo];
+  const int o0 = (tix / tiles_c) * 32, c0 = (tix % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int taps = e.kh * e.kw;
+  for (int tap = 0; tap < taps; ++tap) {
+    // OIHW source: element (o, c, tap) at ((o*I + c)*taps + tap): gather (strided by taps) -- fp32 reads hit L2
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int o = o0 + ty + 8 * k, c = c0 + tx;
+      tl[ty + 8 * k][tx] = (o < e.O && c < e.I) ? e.w[((int64_t)o * e.I + c) * taps + tap] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int o = o0 + ty + 8 * k, c = c0 + tx;
+      if (o < e.O && c < e.I) ElemIO<T>::st(reinterpret_cast<T*>(e.krsc) + ((int64_t)o * taps + tap) * e.I + c, tl[ty + 8 * k][tx]);
+      const int c2 = c0 + ty + 8 * k, o2 = o0 + tx;
+      if (e.crsk && c2 < e.I && o2 < e.O)
+        ElemIO<T>::st(reinterpret_cast<T*>(e.crsk) + ((int64_t)c2 * taps + tap) * e.O + o2, tl[tx][ty + 8 * k]);
+    }
+    __syncthreads();
   }
 }
 
@@ -634,14 +650,15 @@ int creid_weight_prep(const float* w_oihw, int64_t O, int64_t I, int64_t kh, int
 
 int64_t creid_weight_prep_entry_bytes(void) { return (int64_t)sizeof(WPrepEntry); }
 
-int creid_weight_prep_multi(const void* table_dev, int64_t n_entries, int64_t total_elems, int dtype, void* stream) {
-  CREID_CHECK_ARG(table_dev && n_entries > 0 && total_elems > 0);
+int creid_weight_prep_multi(const void* table_dev, const int32_t* tile_start_dev, int64_t n_entries, int64_t total_tiles,
+                            int dtype, void* stream) {
+  CREID_CHECK_ARG(table_dev && tile_start_dev && n_entries > 0 && total_tiles > 0);
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(weight_prep_multi_kernel<float>, dim3(ew_blocks(total_elems, 1)), dim3(256), 0, s,
-                                (const WPrepEntry*)table_dev, (int)n_entries, total_elems),
-             hipLaunchKernelGGL(weight_prep_multi_kernel<unsigned short>, dim3(ew_blocks(total_elems, 1)), dim3(256), 0, s,
-                                (const WPrepEntry*)table_dev, (int)n_entries, total_elems));
+             hipLaunchKernelGGL(weight_prep_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, s,
+                                (const WPrepEntry*)table_dev, (int)n_entries, tile_start_dev),
+             hipLaunchKernelGGL(weight_prep_multi_kernel<unsigned short>, dim3((unsigned)total_tiles), dim3(256), 0, s,
+                                (const WPrepEntry*)table_dev, (int)n_entries, tile_start_dev));
   CREID_LAUNCH_RET();
 }
 

@@ -202,12 +202,13 @@ int creid_image_to_nhwc4_pad(const float* x_nchw, int64_t B, int64_t H, int64_t 
 int creid_weight_prep(const float* w_oihw, int64_t O, int64_t I, int64_t kh, int64_t kw, int dtype,
                       void* w_krsc, void* w_crsk, void* stream);
 int creid_stem_weight_prep(const float* w_oihw, int dtype, void* w_stem, void* stream);
-/* The same transform for MANY convolutions in one launch.  table_dev = device array of n_entries records
- * { const float* w_oihw; void* w_krsc; void* w_crsk (nullable); int32 O, I, kh, kw; int64 start } (48 bytes,
- * creid_weight_prep_entry_bytes()), `start` = cumulative element count, ascending; total_elems = sum O*I*kh*kw. */
+/* The same transform for MANY convolutions in one launch (LDS-tiled transposes, coalesced writes).
+ * table_dev = device array of n_entries records { const float* w_oihw; void* w_krsc; void* w_crsk (nullable);
+ * int32 O, I, kh, kw; int64 start } (48 bytes, creid_weight_prep_entry_bytes()); tile_start_dev = int32[n_entries]
+ * = cumulative count of 32x32 (o, c) tiles, ceil(O/32)*ceil(I/32) per entry; total_tiles = their sum. */
 int64_t creid_weight_prep_entry_bytes(void);
-int creid_weight_prep_multi(const void* table_dev, int64_t n_entries, int64_t total_elems, int dtype,
-                            void* stream);
+int creid_weight_prep_multi(const void* table_dev, const int32_t* tile_start_dev, int64_t n_entries,
+                            int64_t total_tiles, int dtype, void* stream);
 
 /* nn.BatchNorm2d (resnet.py:57-62,96,111; momentum 0.1, eps 1e-5) split in three steps:
  * finalize: partial (sum,sumsq) rows -> mean / invstd (+ running-stat update, unbiased variance) when
