@@ -250,6 +250,181 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IGemmGeom g, const u
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16, LDS-DMA
+// Same tiling / epilogue as igemm_bf16_kernel, but both operand tiles are fetched with gfx950's
+// global->LDS DMA (`global_load_lds_dwordx4`: LDS[wave base + lane*16] <- that lane's 16 global bytes): no
+// staging VGPRs, no ds_write pass, ~16 address VALU per k-tile.  The LDS image is linear (8 rows x 128 B per
+// wave-instruction); the conflict-free XOR swizzle is applied on the SOURCE side (lane holding LDS chunk c'
+// of row r fetches global chunk c' ^ ((r>>1)&7)) and again on the fragment reads.  Out-of-image taps and
+// rows >= M fetch from a page of zeros.  Two LDS buffers: the DMA of k-tile t+1 flies while tile t is
+// multiplied; one barrier per k-tile.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
+                                                                 const unsigned short* __restrict__ wgt,
+                                                                 unsigned short* __restrict__ out,
+                                                                 const unsigned short* __restrict__ add_src,
+                                                                 float* __restrict__ bn_part, int tiles_n) {
+  constexpr int BK = 64, TNW = BN / 64, NBI = BN / 32;          // NBI = B-tile DMA instructions per wave
+  constexpr int CP = BN + 8;
+  constexpr int TILE_A = 128 * BK, TILE_B = BN * BK, STAGE = TILE_A + TILE_B;
+  constexpr int LDS_ELEMS = (2 * STAGE) > (128 * CP) ? (2 * STAGE) : (128 * CP);
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[LDS_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int row0 = tile_m * 128, col0 = tile_n * BN;
+  const int span_mask = (1 << g.log2span) - 1;
+
+  // DMA lane map: instruction i of this wave covers tile rows ((i*4 + wave)*8 .. +7); lane -> (row, LDS chunk)
+  const int lr8 = lane >> 3, lcp = lane & 7;
+  int oy[4], ox[4], bpix[4], gch[4];
+  bool vm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (i * 4 + wave) * 8 + lr8, m = row0 + r;
+    vm[i] = m < g.M;
+    const int mm = vm[i] ? m : 0;
+    int b, rem;
+    fast_divmod(mm, g.OH * g.OW, g.inv_ohow, b, rem);
+    fast_divmod(rem, g.OW, g.inv_ow, oy[i], ox[i]);
+    bpix[i] = b * g.SH * g.SW;
+    gch[i] = (lcp ^ ((r >> 1) & 7)) << 3;                     // swizzled SOURCE chunk (elements)
+  }
+  const unsigned short* wp[NBI];
+#pragma unroll
+  for (int i = 0; i < NBI; ++i) {
+    const int r = (i * 4 + wave) * 8 + lr8;
+    wp[i] = wgt + (int64_t)(col0 + r) * g.K + ((lcp ^ ((r >> 1) & 7)) << 3);
+  }
+  const unsigned short* aptr[4];
+  int amul[4];
+  int cur_tap = -1;
+  const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_zero_page);
+  auto set_tap = [&](int tap) {
+    const int r = tap / g.kw, s = tap - r * g.kw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy, ix;
+      const bool ok = vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix);
+      aptr[i] = ok ? src + (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + gch[i] : zpage;
+      amul[i] = ok ? 1 : 0;
+    }
+  };
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  auto issue = [&](int t, int buf) {
+    const int tap = (t * BK) >> g.log2span;
+    if (tap != cur_tap) { set_tap(tap); cur_tap = tap; }
+    const int c = (t * BK) & span_mask;
+    unsigned short* la = smem + buf * STAGE + wave * 512;      // + i * 2048 elements (4 KiB) per instruction
+    unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + c * amul[i]), (lptr_t)(la + i * 2048), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NBI; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wp[i] + t * BK), (lptr_t)(lb + i * 2048), 16, 0, 0);
+  };
+
+  f32x16 acc[2][TNW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  const int l31 = lane & 31, kh = lane >> 5;
+  issue(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces of tile t have landed
+    __syncthreads();                                           // ... everyone's have; buffer (t+1)&1 is free again
+    if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+    const unsigned short* As = smem + (t & 1) * STAGE;
+    const unsigned short* Bs = As + TILE_A;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = 2 * kk + kh;
+      s16x8 a[2], b[TNW];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        a[i] = *reinterpret_cast<const s16x8*>(&As[r * BK + ((ch ^ ((r >> 1) & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) {
+        const int c = wn * (BN / 2) + j * 32 + l31;
+        b[j] = *reinterpret_cast<const s16x8*>(&Bs[c * BK + ((ch ^ ((c >> 1) & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                              __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue (identical to igemm_bf16_kernel)
+  float s1v[TNW], s2v[TNW];
+#pragma unroll
+  for (int j = 0; j < TNW; ++j) {
+    const int cl = wn * (BN / 2) + j * 32 + l31;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float v = acc[i][j][r];
+        s1 += v; s2 = fmaf(v, v, s2);
+        smem[rl * CP + cl] = f32_to_bf16_bits(v);
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    s1v[j] = s1; s2v[j] = s2;
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+#pragma unroll
+  for (int i = 0; i < (128 * CPR) / 256; ++i) {
+    const int id = tid + 256 * i, rl = id / CPR, ch = id - rl * CPR;
+    const int rr = row0 + rl;
+    if (rr < g.M) {
+      uint4 v = *reinterpret_cast<const uint4*>(&smem[rl * CP + ch * 8]);
+      const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
+      if (add_src) {
+        const uint4 a = *reinterpret_cast<const uint4*>(add_src + off);
+        unsigned* vw = &v.x; const unsigned* aw = &a.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+          const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+          vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(out + off) = v;
+    }
+  }
+  if (bn_part) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int cl = wn * (BN / 2) + j * 32 + l31;
+      if (kh == 0) { red[(wm * 2 + 0) * BN + cl] = s1v[j]; red[(wm * 2 + 1) * BN + cl] = s2v[j]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, cl = i - which * BN;
+      bn_part[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ f32
 template <int BN>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(IGemmGeom g, const float* __restrict__ src,
@@ -391,7 +566,16 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   if (g.N % bn != 0) return CREID_E_SHAPE;
   const int tiles_n = g.N / bn;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
-  if (dtype == CREID_BF16) {
+  static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
+  if (dtype == CREID_BF16 && use_dma && g.log2span >= 6) {
+    if (g.K % 64 != 0) return CREID_E_SHAPE;
+    if (bn == 128)
+      hipLaunchKernelGGL(igemm_bf16_dma_kernel<128>, grid, block, 0, s, g, (const unsigned short*)src,
+                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n);
+    else
+      hipLaunchKernelGGL(igemm_bf16_dma_kernel<64>, grid, block, 0, s, g, (const unsigned short*)src,
+                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n);
+  } else if (dtype == CREID_BF16) {
     if (g.K % 64 != 0) return CREID_E_SHAPE;
     if (bn == 128)
       hipLaunchKernelGGL(igemm_bf16_kernel<128>, grid, block, 0, s, g, (const unsigned short*)src,
