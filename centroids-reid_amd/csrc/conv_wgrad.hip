@@ -248,20 +248,33 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(IGemmGeom g, const float
 
 // sum over splits and scatter [NCO][K = (tap, within)] -> OIHW fp32 gradient (accumulating).
 // r = tap / kw_taps; s = tap % kw_taps + within / cpitch; c = within % cpitch.
+// Workgroup = 32 consecutive elements x 8 split lanes (coalesced 128-B reads per split, fixed-order LDS
+// combine -> deterministic), so tiny weight tensors with hundreds of pixel-splits still reduce in parallel.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int NCO, int K,
                                                            int log2span, int kw_taps, int cpitch, int cin, int kh,
                                                            int kw, float* __restrict__ dw_oihw, int accumulate) {
+  __shared__ float red[8][32];
   const int64_t total = (int64_t)NCO * K;
   const int span_mask = (1 << log2span) - 1;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int co = (int)(i / K), kc = (int)(i - (int64_t)co * K);
-    const int tap = kc >> log2span, within = kc & span_mask;
-    const int r = tap / kw_taps, s = tap % kw_taps + within / cpitch, c = within % cpitch;
-    if (r >= kh || s >= kw || c >= cin) continue;
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < total; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + el;
     float acc = 0.f;
-    for (int sp = 0; sp < splits; ++sp) acc += ws[(int64_t)sp * total + i];
-    float* dst = dw_oihw + (((int64_t)co * cin + c) * kh + r) * kw + s;
-    *dst = accumulate ? *dst + acc : acc;
+    if (i < total)
+      for (int sp = sl; sp < splits; sp += 8) acc += ws[(int64_t)sp * total + i];
+    red[sl][el] = acc;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      acc = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+      const int co = (int)(i / K), kc = (int)(i - (int64_t)co * K);
+      const int tap = kc >> log2span, within = kc & span_mask;
+      const int r = tap / kw_taps, s = tap % kw_taps + within / cpitch, c = within % cpitch;
+      if (r < kh && s < kw && c < cin) {
+        float* dst = dw_oihw + (((int64_t)co * cin + c) * kh + r) * kw + s;
+        *dst = accumulate ? *dst + acc : acc;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -310,8 +323,8 @@ static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO,
   else if (p.tm == 128 && p.tn == 64) launch_wgrad_t<128, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
   else if (p.tm == 64 && p.tn == 128) launch_wgrad_t<64, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
   else launch_wgrad_t<64, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
-  int64_t blocks = ((int64_t)NCO * g.K + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  int64_t blocks = ((int64_t)NCO * g.K + 31) / 32;
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, p.splits, NCO,
                      g.K, g.log2span, kw_taps, cpitch, cin, kh, kw, dw, accumulate);
   return (int)hipGetLastError();
