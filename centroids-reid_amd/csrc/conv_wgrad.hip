@@ -284,20 +284,30 @@ static int ilog2x(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return ((1
 struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split; };
 
 static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
-  WgradPlan p;
-  p.tm = (NCO % 128 == 0) ? 128 : 64;
-  p.tn = (K % 128 == 0 && K >= 256) ? 128 : 64;
-  if ((int64_t)(NCO / p.tm) * (K / p.tn) < 16 && p.tn == 128) p.tn = 64;
-  p.tiles_k = K / p.tn;
-  p.tiles = (NCO / p.tm) * p.tiles_k;
-  const int ks = (dtype == CREID_BF16) ? WKS : WKF;
+  // The fp32 partial tiles cost  workgroups x TM x TN x 8 bytes  of traffic per layer (write + re-read by the
+  // reduce).  Measured (r01): shrinking the tile to cut that traffic LOSES (6147 vs 6370 img/s) -- the larger
+  // tile's MFMA/LDS efficiency matters more and the partials mostly stay in the 256 MB Infinity Cache -- so the
+  // largest tile wins by default; CREID_WGRAD_MAX_SPLITS re-enables the size/split trade-off for experiments.
   static const int target = [] { const char* e = getenv("CREID_WGRAD_TARGET_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
-  int splits = (target + p.tiles - 1) / p.tiles;
-  const int max_splits = (M + 4 * ks - 1) / (4 * ks);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  p.m_per_split = ((M + splits - 1) / splits + ks - 1) / ks * ks;
-  p.splits = (M + p.m_per_split - 1) / p.m_per_split;
+  static const int max_splits_pref = [] { const char* e = getenv("CREID_WGRAD_MAX_SPLITS"); int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 30); }();
+  const int ks = (dtype == CREID_BF16) ? WKS : WKF;
+  const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  WgradPlan p;
+  for (int ci = 0; ci < 3; ++ci) {
+    int tm = cand[ci][0], tn = cand[ci][1];
+    if (NCO % tm != 0) tm = 64;
+    if (K % tn != 0) tn = 64;
+    p.tm = tm; p.tn = tn;
+    p.tiles_k = K / tn;
+    p.tiles = (NCO / tm) * p.tiles_k;
+    int splits = (target + p.tiles - 1) / p.tiles;
+    const int max_splits = (M + 4 * ks - 1) / (4 * ks);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.m_per_split = ((M + splits - 1) / splits + ks - 1) / ks * ks;
+    p.splits = (M + p.m_per_split - 1) / p.m_per_split;
+    if (p.splits <= max_splits_pref) break;
+  }
   return p;
 }
 
