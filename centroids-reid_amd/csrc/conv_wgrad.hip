@@ -155,6 +155,150 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(IGemmGeom g, const unsi
       }
 }
 
+// ------------------------------------------------------------------------------------ bf16, LDS-DMA
+// Same math as wgrad_bf16_kernel; both pixel-major tiles are fetched with the global->LDS DMA into LINEAR rows
+// (pitch = tile width), double-buffered.  Bank conflicts of the transposing reads are avoided by an XOR
+// swizzle of the 64-byte units of a row (key = row&3 for 256-B rows, (row>>1)&1 for 128-B rows: the four
+// pixel rows a 16-lane group touches land on four different 16-bank ranges), applied on the DMA SOURCE column
+// and again in the per-lane read address.  Rows past the split / out-of-image taps read a page of zeros.
+__device__ __attribute__((aligned(128))) unsigned g_wgrad_zero_page[32];
+
+template <int OFF_LO, int OFF_HI>
+__device__ __forceinline__ void tr_load2(unsigned addr, s16x4& lo, s16x4& hi) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(lo), "=&v"(hi) : "v"(addr), "i"(OFF_LO), "i"(OFF_HI) : "memory");
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
+                                                                 const unsigned short* __restrict__ x, int NCO,
+                                                                 float* __restrict__ ws, int tiles_k, int m_per_split) {
+  constexpr int IM = TM / 64, JN = TN / 64;
+  constexpr int LPR_A = TM / 8, LPR_B = TN / 8;                // lanes (16-B chunks) per tile row
+  constexpr int RPI_A = 64 / LPR_A, RPI_B = 64 / LPR_B;        // rows per wave-instruction
+  constexpr int NIA = WKS / (4 * RPI_A), NIB = WKS / (4 * RPI_B);   // DMA instructions per wave per tile
+  constexpr int TILE_A = WKS * TM, TILE_B = WKS * TN, STAGE = TILE_A + TILE_B;
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int tile_co = tile / tiles_k, tile_k = tile - tile_co * tiles_k;
+  const int co0 = tile_co * TM, k0 = tile_k * TN;
+  const int m_begin = split * m_per_split, m_end = min(g.M, m_begin + m_per_split);
+  const int span_mask = (1 << g.log2span) - 1;
+  const int tap = k0 >> g.log2span, cc = k0 & span_mask;
+  const int tr = tap / g.kw, ts = tap - tr * g.kw;
+  const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_wgrad_zero_page);
+
+  // DMA lane maps (row within the instruction's row group, swizzled source column)
+  const int ar = lane / LPR_A, aq = lane % LPR_A;
+  const int br = lane / LPR_B, bq = lane % LPR_B;
+  int arow[NIA], acol[NIA], brow[NIB], bcol[NIB];
+#pragma unroll
+  for (int i = 0; i < NIA; ++i) {
+    arow[i] = (i * 4 + wave) * RPI_A + ar;
+    const int key = (TM == 128) ? (arow[i] & 3) : ((arow[i] >> 1) & 1);
+    acol[i] = ((((aq >> 2) ^ key) << 2) + (aq & 3)) << 3;
+  }
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    brow[i] = (i * 4 + wave) * RPI_B + br;
+    const int key = (TN == 128) ? (brow[i] & 3) : ((brow[i] >> 1) & 1);
+    bcol[i] = ((((bq >> 2) ^ key) << 2) + (bq & 3)) << 3;
+  }
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  auto issue = [&](int mb, int buf) {
+    unsigned short* la = smem + buf * STAGE + wave * 512;
+    unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int m = mb + arow[i];
+      const unsigned short* p = (m < m_end) ? dy + (int64_t)m * NCO + co0 + acol[i] : zpage;
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(la + i * 2048), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int m = mb + brow[i];
+      const unsigned short* p = zpage;
+      if (m < m_end) {
+        int b, rem, oy, ox, iy, ix;
+        fast_divmod(m, g.OH * g.OW, g.inv_ohow, b, rem);
+        fast_divmod(rem, g.OW, g.inv_ow, oy, ox);
+        if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))
+          p = x + (int64_t)((b * g.SH + iy) * g.SW + ix) * g.pitch + cc + bcol[i];
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(lb + i * 2048), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[IM][JN];
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposing-read lane map + swizzled per-fragment base byte addresses (relative to the stage base)
+  const int li = lane & 15;
+  const int t_row = 8 * (lane >> 5) + (li >> 2), t_col = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+  const int keyA = (TM == 128) ? (t_row & 3) : ((t_row >> 1) & 1);
+  const int keyB = (TN == 128) ? (t_row & 3) : ((t_row >> 1) & 1);
+  unsigned fa[IM], fb[JN];
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const int col = wm * (TM / 2) + i * 32 + t_col;
+    fa[i] = lds0 + 2u * (unsigned)(t_row * TM + (((col >> 5) ^ keyA) << 5) + (col & 31));
+  }
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+    const int col = wn * (TN / 2) + j * 32 + t_col;
+    fb[j] = lds0 + 2u * (unsigned)(TILE_A + t_row * TN + (((col >> 5) ^ keyB) << 5) + (col & 31));
+  }
+
+  issue(m_begin, 0);
+  int it = 0;
+  for (int mb = m_begin; mb < m_end; mb += WKS, ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (mb + WKS < m_end) issue(mb + WKS, (it + 1) & 1);
+    const unsigned sb = (unsigned)((it & 1) * STAGE * 2);
+#define WG_KK(KK)                                                                                        \
+    {                                                                                                    \
+      s16x4 al[2], ah[2], bl[2], bh[2];                                                                  \
+      tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[0] + sb, al[0], ah[0]);                  \
+      tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[IM - 1] + sb, al[1], ah[1]);             \
+      tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[0] + sb, bl[0], bh[0]);                  \
+      tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[JN - 1] + sb, bl[1], bh[1]);             \
+      tr_wait8(al[0], ah[0], al[1], ah[1], bl[0], bh[0], bl[1], bh[1]);                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+      s16x8 a[IM], b[JN];                                                                                \
+      _Pragma("unroll") for (int i = 0; i < IM; ++i) a[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7); \
+      _Pragma("unroll") for (int j = 0; j < JN; ++j) b[j] = __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7); \
+      _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < JN; ++j)                                                   \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),          \
+                                                              __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0); \
+    }
+    WG_KK(0) WG_KK(1) WG_KK(2) WG_KK(3)
+#undef WG_KK
+  }
+  const int l31 = lane & 31, kh = lane >> 5;
+  float* wsp = ws + (int64_t)split * NCO * g.K;
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int kc = k0 + wn * (TN / 2) + j * 32 + l31;
+        wsp[(int64_t)co * g.K + kc] = acc[i][j][r];
+      }
+}
+
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(IGemmGeom g, const float* __restrict__ dy,
                                                         const float* __restrict__ x, int NCO, float* __restrict__ ws,
@@ -315,7 +459,11 @@ template <int TM, int TN>
 static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* ws, const WgradPlan& p,
                            int dtype, hipStream_t s) {
   dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(256);
-  if (dtype == CREID_BF16)
+  static const int use_dma = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+  if (dtype == CREID_BF16 && use_dma && (1 << g.log2span) >= TN)
+    hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN>), grid, block, 0, s, g, (const unsigned short*)dy,
+                       (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+  else if (dtype == CREID_BF16)
     hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN>), grid, block, 0, s, g, (const unsigned short*)dy,
                        (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
   else
