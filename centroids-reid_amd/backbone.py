@@ -225,6 +225,9 @@ class BackboneEngine:
         self.weights_dirty = True
         self._ws = None
         self.saved = None
+        import os
+        self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
+            and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
         self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
 
     # ---- helpers
@@ -409,10 +412,13 @@ class BackboneEngine:
             p.grad = torch.zeros_like(p)
         return p.grad
 
-    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False):
+    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False, part=None):
+        """BN backward; `part` = column-reduction partials already produced by a fused dgrad epilogue."""
         lib, st = L.lib(), L.stream()
         rows = lib.creid_bn2d_bwd_rows(M)
-        part = self._empty(rows * 2, u.cout, dtype=torch.float32)
+        ready = 1 if part is not None else 0
+        if part is None:
+            part = self._empty(rows * 2, u.cout, dtype=torch.float32)
         sums = self._empty(3, u.cout, dtype=torch.float32)
         dx = self._empty(M, u.cout)
         gm = self._empty(M, u.cout) if want_gm else None
@@ -420,8 +426,8 @@ class BackboneEngine:
         dgam = self._grad_of(bn.weight) if bn.weight.requires_grad else None
         dbet = self._grad_of(bn.bias) if bn.bias.requires_grad else None
         L.check(lib.creid_bn2d_bwd(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(bn.weight), M, u.cout,
-                                   self.dt, L.ptr(part), L.ptr(sums), L.ptr(dgam), L.ptr(dbet), L.ptr(dx), L.ptr(gm), st),
-                "bn2d_bwd")
+                                   self.dt, L.ptr(part), ready, L.ptr(sums), L.ptr(dgam), L.ptr(dbet), L.ptr(dx), L.ptr(gm),
+                                   st), "bn2d_bwd")
         return dx, gm
 
     def _wgrad(self, u, a_in, dy, B, H, W):
@@ -434,13 +440,23 @@ class BackboneEngine:
         L.check(lib.creid_conv2d_wgrad_nhwc(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(self._grad_of(u.conv.weight)), 1,
                                             L.ptr(ws), nbytes, self.dt, st), "conv2d_wgrad")
 
-    def _dgrad(self, u, dy, B, H, W, add_src=None):
+    def _dgrad(self, u, dy, B, H, W, add_src=None, bnred=None):
+        """Data gradient.  bnred = (x, act, mean, invstd) of the BN layer that consumes the result: its column
+        reduction is fused into the epilogue (bf16) and the partials are returned."""
         lib, st = L.lib(), L.stream()
         d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
-        dx = self._empty(B * H * W, u.cin)
+        M = B * H * W
+        dx = self._empty(M, u.cin)
+        if bnred is not None and self.fuse_bn_reduce:
+            x, act, mean, invstd = bnred
+            part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32)
+            L.check(lib.creid_conv2d_dgrad_bnred_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src),
+                                                      L.ptr(x), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(part), self.dt,
+                                                      st), "conv2d_dgrad_bnred")
+            return dx, part
         L.check(lib.creid_conv2d_dgrad_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src), self.dt, st),
                 "conv2d_dgrad")
-        return dx
+        return dx, None
 
     def backward(self, dfeat: torch.Tensor):
         """Accumulates parameter gradients into `.grad` (fp32, reference layouts)."""
@@ -452,27 +468,34 @@ class BackboneEngine:
         dfeat = dfeat.contiguous().float()
         g = self._empty(B * h * w, 2048)
         L.check(lib.creid_gap_bwd(L.ptr(dfeat), B, h * w, 2048, self.dt, L.ptr(g), st), "gap_bwd")
-        for b, s in zip(reversed(self.blocks), reversed(sv["blocks"])):
+        blocks = list(zip(self.blocks, sv["blocks"]))
+        part3 = None                      # bn3 partials of the CURRENT block, produced by the previous (deeper) block
+        for bi in range(len(blocks) - 1, -1, -1):
+            b, s = blocks[bi]
+            prev = blocks[bi - 1] if bi > 0 else None          # the block whose output gradient we produce
             M3 = B * s["h2"] * s["w2"]
-            dx3, gm = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, want_gm=True)
+            dx3, gm = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, want_gm=True, part=part3)
             self._wgrad(b["c3"], s["a2"], dx3, B, s["h2"], s["w2"])
-            da2 = self._dgrad(b["c3"], dx3, B, s["h2"], s["w2"])
-            dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3)
+            da2, p2 = self._dgrad(b["c3"], dx3, B, s["h2"], s["w2"], bnred=(s["x2"], s["a2"], s["m2"], s["i2"]))
+            dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3, part=p2)
             self._wgrad(b["c2"], s["a1"], dx2, B, s["h1"], s["w1"])
-            da1 = self._dgrad(b["c2"], dx2, B, s["h1"], s["w1"])
+            ibn1 = b["c1"].ibn is not None
+            da1, p1 = self._dgrad(b["c2"], dx2, B, s["h1"], s["w1"],
+                                  bnred=None if ibn1 else (s["x1"], s["a1"], s["m1"], s["i1"]))
             M1 = B * s["h1"] * s["w1"]
-            if b["c1"].ibn is not None:
+            if ibn1:
                 dx1, _ = self._ibn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], B, s["h1"] * s["w1"])
             else:
-                dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1)
+                dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1, part=p1)
             self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"])
+            nxt = None if prev is None else (prev[1]["x3"], prev[1]["a3"], prev[1]["m3"], prev[1]["i3"])
             if b["ds"] is not None:
                 dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3)
                 self._wgrad(b["ds"], s["a_in"], dxd, B, s["hin"], s["win"])
-                tmp = self._dgrad(b["ds"], dxd, B, s["hin"], s["win"])
-                g = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp)
+                tmp, _ = self._dgrad(b["ds"], dxd, B, s["hin"], s["win"])
+                g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt)
             else:
-                g = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm)
+                g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm, bnred=nxt)
         # stem
         xpad, x0, y0, mean0, invstd0, idx0 = sv["stem"]
         H, W = sv["H"], sv["W"]

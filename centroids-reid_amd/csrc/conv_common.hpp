@@ -58,6 +58,18 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
   if (r < 0) { --q; r += d; }
 }
 
+// Optional fusion of the NEXT BatchNorm-backward's column reduction into a data-gradient epilogue: the tile
+// just produced is g = dL/da for the layer whose raw conv output is `x` and post-ReLU activation is `act`;
+// the epilogue accumulates (sum dy, sum dy*xhat), dy = g*[act>0], per channel into
+// partial[tile_m][2][N] (the layout creid_bn2d_bwd expects, one row pair per 128 rows).
+struct BnRedArgs {
+  const void* x;
+  const void* act;       // nullable: no ReLU mask
+  const float* mean;
+  const float* invstd;
+  float* partial;
+};
+
 // XCD-aware bijective remap of the linear workgroup id (consecutive ids land on different XCDs;
 // give every XCD a contiguous run of tiles so neighbouring tiles share operand panels in its L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

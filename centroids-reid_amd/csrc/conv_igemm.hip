@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IGemmGeom g, con
                                                                  const unsigned short* __restrict__ wgt,
                                                                  unsigned short* __restrict__ out,
                                                                  const unsigned short* __restrict__ add_src,
-                                                                 float* __restrict__ bn_part, int tiles_n) {
+                                                                 float* __restrict__ bn_part, int tiles_n,
+                                                                 BnRedArgs bnred) {
   constexpr int BK = 64, TNW = BN / 64, NBI = BN / 32;          // NBI = B-tile DMA instructions per wave
   constexpr int CP = BN + 8;
   constexpr int TILE_A = 128 * BK, TILE_B = BN * BK, STAGE = TILE_A + TILE_B;
@@ -389,6 +390,22 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IGemmGeom g, con
   }
   __syncthreads();
   constexpr int CPR = BN / 8;
+  constexpr int NRG = 256 / CPR;                               // row groups among the threads sharing a chunk column
+  const unsigned short* bx = reinterpret_cast<const unsigned short*>(bnred.x);
+  const unsigned short* bact = reinterpret_cast<const unsigned short*>(bnred.act);
+  float rs1[8], rs2[8], rmu[8], ris[8];
+  if (bx) {
+    const int c0 = col0 + (tid % CPR) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(bnred.mean + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(bnred.invstd + c0 + k);
+      rmu[k] = a.x; rmu[k + 1] = a.y; rmu[k + 2] = a.z; rmu[k + 3] = a.w;
+      ris[k] = b.x; ris[k + 1] = b.y; ris[k + 2] = b.z; ris[k + 3] = b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { rs1[k] = 0.f; rs2[k] = 0.f; }
+  }
 #pragma unroll
   for (int i = 0; i < (128 * CPR) / 256; ++i) {
     const int id = tid + 256 * i, rl = id / CPR, ch = id - rl * CPR;
@@ -407,6 +424,37 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IGemmGeom g, con
         }
       }
       *reinterpret_cast<uint4*>(out + off) = v;
+      if (bx) {                                                // fused BN-backward column reduction
+        const uint4 xv = *reinterpret_cast<const uint4*>(bx + off);
+        uint4 av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
+        const unsigned* vw = &v.x; const unsigned* xw = &xv.x; const unsigned* aw = &av.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float g0 = __uint_as_float(vw[q] << 16), g1 = __uint_as_float(vw[q] & 0xffff0000u);
+          const float a0 = __uint_as_float(aw[q] << 16), a1 = __uint_as_float(aw[q] & 0xffff0000u);
+          const float x0 = __uint_as_float(xw[q] << 16), x1 = __uint_as_float(xw[q] & 0xffff0000u);
+          g0 = a0 > 0.f ? g0 : 0.f; g1 = a1 > 0.f ? g1 : 0.f;
+          rs1[2 * q] += g0; rs1[2 * q + 1] += g1;
+          rs2[2 * q] = fmaf(g0, (x0 - rmu[2 * q]) * ris[2 * q], rs2[2 * q]);
+          rs2[2 * q + 1] = fmaf(g1, (x1 - rmu[2 * q + 1]) * ris[2 * q + 1], rs2[2 * q + 1]);
+        }
+      }
+    }
+  }
+  if (bx) {
+    __syncthreads();                                           // staged C tile no longer needed
+    float* red2 = reinterpret_cast<float*>(smem);              // [NRG][2][BN]
+    const int rg = tid / CPR, cb = (tid % CPR) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red2[(rg * 2 + 0) * BN + cb + k] = rs1[k]; red2[(rg * 2 + 1) * BN + cb + k] = rs2[k]; }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, cl = i - which * BN;
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < NRG; ++q) a += red2[(q * 2 + which) * BN + cl];
+      bnred.partial[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = a;
     }
   }
   if (bn_part) {
@@ -557,7 +605,7 @@ static int ilog2_exact(int64_t v) {
 }
 
 static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src,
-                        float* bn_part, int dtype, hipStream_t s) {
+                        float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   const int tiles_m = (g.M + 127) / 128;
   // pick the N tile: 128 unless that leaves the chip (256 CUs) under-filled or N is only 64
   int bn = 128;
@@ -571,10 +619,14 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
     if (g.K % 64 != 0) return CREID_E_SHAPE;
     if (bn == 128)
       hipLaunchKernelGGL(igemm_bf16_dma_kernel<128>, grid, block, 0, s, g, (const unsigned short*)src,
-                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n);
+                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n,
+                         bnred);
     else
       hipLaunchKernelGGL(igemm_bf16_dma_kernel<64>, grid, block, 0, s, g, (const unsigned short*)src,
-                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n);
+                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n,
+                         bnred);
+  } else if (bnred.x) {
+    return CREID_E_DTYPE;          // the fused reduction exists only in the bf16 LDS-DMA kernel
   } else if (dtype == CREID_BF16) {
     if (g.K % 64 != 0) return CREID_E_SHAPE;
     if (bn == 128)
@@ -640,6 +692,25 @@ int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void
   g.K = (int)(d->kh * d->kw * d->out_c); g.N = (int)d->in_c; g.check_bounds = 1;
   igemm_finish_geom(g);
   return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream));
+}
+
+/* dgrad with the NEXT BatchNorm-backward's column reduction fused into the epilogue (bf16 only). */
+int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
+                                  const void* add_src, const void* bn_x, const void* bn_act, const float* bn_mean,
+                                  const float* bn_invstd, float* bn_partial, int dtype, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CREID_CHECK_ARG(dy && w_crsk && dx && bn_x && bn_mean && bn_invstd && bn_partial);
+  static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
+  if (dtype != CREID_BF16 || !use_dma) return CREID_E_DTYPE;
+  IGemmGeom g;
+  g.M = (int)(d->batch * d->in_h * d->in_w); g.OH = (int)d->in_h; g.OW = (int)d->in_w;
+  g.SH = (int)d->out_h; g.SW = (int)d->out_w; g.pitch = (int)d->out_c; g.log2span = ilog2_exact(d->out_c);
+  g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 1;
+  g.K = (int)(d->kh * d->kw * d->out_c); g.N = (int)d->in_c; g.check_bounds = 1;
+  igemm_finish_geom(g);
+  BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial};
+  return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream), br);
 }
 
 /* stem: 7x7 stride-2 pad-3 conv, 3 -> 64 channels, on the pre-padded NHWC4 image

@@ -42,10 +42,11 @@ __global__ __launch_bounds__(1024) void bn2d_finalize_kernel(const float* __rest
                                                             float* __restrict__ mean_out,
                                                             float* __restrict__ invstd_out,
                                                             float* __restrict__ scale_shift) {
-  // 32 channels x 32 row-groups per workgroup: coalesced 128-B reads, fp64 accumulation, LDS tree
-  __shared__ double red[32][2][32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  // 16 channels x 64 row-groups per workgroup: 64-B coalesced reads, 4 independent loads in flight per
+  // thread, fp64 accumulation, LDS tree (the kernel is pure latency: keep the dependent chain short)
+  __shared__ double red[64][2][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   if (!training) {
     if (rg == 0 && c < C) {
       const float mu = rmean[c], is = 1.0f / sqrtf(rvar[c] + eps);
@@ -57,16 +58,27 @@ __global__ __launch_bounds__(1024) void bn2d_finalize_kernel(const float* __rest
   }
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int r = rg; r < rows; r += 32) {
+  {
+    int r = rg;
+    for (; r + 192 < rows; r += 256) {          // 8 independent loads per trip
+      const float a0 = partial[((int64_t)r * 2) * C + c], b0 = partial[((int64_t)r * 2 + 1) * C + c];
+      const float a1 = partial[((int64_t)(r + 64) * 2) * C + c], b1 = partial[((int64_t)(r + 64) * 2 + 1) * C + c];
+      const float a2 = partial[((int64_t)(r + 128) * 2) * C + c], b2 = partial[((int64_t)(r + 128) * 2 + 1) * C + c];
+      const float a3 = partial[((int64_t)(r + 192) * 2) * C + c], b3 = partial[((int64_t)(r + 192) * 2 + 1) * C + c];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; r < rows; r += 64) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
+  }
   red[rg][0][cl] = s1; red[rg][1][cl] = s2;
   __syncthreads();
   if (rg == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -215,21 +227,32 @@ __global__ __launch_bounds__(1024) void bn2d_bwd_finalize_kernel(const float* __
                                                                 const float* __restrict__ gamma,
                                                                 float* __restrict__ sums, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta) {
-  __shared__ double red[32][2][32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double red[64][2][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int r = rg; r < rows; r += 32) {
+  {
+    int r = rg;
+    for (; r + 192 < rows; r += 256) {          // 8 independent loads per trip
+      const float a0 = partial[((int64_t)r * 2) * C + c], b0 = partial[((int64_t)r * 2 + 1) * C + c];
+      const float a1 = partial[((int64_t)(r + 64) * 2) * C + c], b1 = partial[((int64_t)(r + 64) * 2 + 1) * C + c];
+      const float a2 = partial[((int64_t)(r + 128) * 2) * C + c], b2 = partial[((int64_t)(r + 128) * 2 + 1) * C + c];
+      const float a3 = partial[((int64_t)(r + 192) * 2) * C + c], b3 = partial[((int64_t)(r + 192) * 2 + 1) * C + c];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; r < rows; r += 64) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
+  }
   red[rg][0][cl] = s1; red[rg][1][cl] = s2;
   __syncthreads();
   if (rg == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
     // dx = k1*(dy - a1 - xhat*a2) = A*dy + B*x + Cc  with per-channel A, B, Cc
     const float invM = (float)(1.0 / count);
     const float mu = mean[c], is = invstd[c], k1 = (gamma ? gamma[c] : 1.f) * is;
@@ -518,7 +541,7 @@ int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t c
                         const float* beta, float* mean_out, float* invstd_out, float* scale_shift, void* stream) {
   CREID_CHECK_ARG(C > 0 && mean_out && invstd_out && scale_shift &&
                   (training ? (partial && rows > 0 && count > 0) : (running_mean && running_var)));
-  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, as_stream(stream), partial,
+  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, as_stream(stream), partial,
                      (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, gamma, beta,
                      mean_out, invstd_out, scale_shift);
   CREID_LAUNCH_RET();
@@ -554,18 +577,19 @@ int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residu
 int64_t creid_bn2d_bwd_rows(int64_t M) { int64_t r = (M + 127) / 128; return r < 1 ? 1 : r; }
 
 int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
-                   const float* gamma, int64_t M, int64_t C, int dtype, float* partial, float* sums, float* dgamma_accum,
-                   float* dbeta_accum, void* dx, void* gm_out, void* stream) {
+                   const float* gamma, int64_t M, int64_t C, int dtype, float* partial, int partial_ready, float* sums,
+                   float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out, void* stream) {
   CREID_CHECK_ARG(x && g && mean && invstd && partial && sums && dx && M > 0 && C > 0 && C % 8 == 0);
   const int rows = (int)creid_bn2d_bwd_rows(M);
   hipStream_t s = as_stream(stream);
+  if (!partial_ready)
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 128, partial),
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
                                 invstd, M, (int)C, 128, partial));
-  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, s, partial, rows, (int)C,
+  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, rows, (int)C,
                      (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,

@@ -166,13 +166,15 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
                                                           const float* __restrict__ coef,
                                                           const float* __restrict__ gscale_ptr, float gscale,
                                                           float* __restrict__ dx) {
+  // phase 1: the (few) anchors that touch this row, compacted IN ANCHOR ORDER into LDS as
+  // (other row, signed coefficient) terms:  dx[r] += sum_terms w * (x[r] - x[other])
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  int* t_other = reinterpret_cast<int*>(sm);           // [<= 4N] capacity 4 terms per anchor
+  float* t_w = sm + 4 * N;
+  __shared__ int n_terms;
   const int r = blockIdx.x;
-  const float g = gscale * (gscale_ptr ? *gscale_ptr : 1.f);
-  const float* xr = x + (int64_t)r * D;
-  float* out = dx + (int64_t)r * D;
-  for (int d = threadIdx.x; d < D; d += 256) {
-    const float xv = xr[d];
-    float acc = 0.f;
+  if (threadIdx.x == 0) {
+    int k = 0;
     for (int a = 0; a < N; ++a) {
       const float c = coef[a];
       if (c == 0.f) continue;
@@ -180,10 +182,22 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
       if (a != r && p != r && n != r) continue;
       const float dap = dist_ap[a], dan = dist_an[a];
       const float ip = dap > 1e-6f ? c / dap : 0.f, in_ = dan > 1e-6f ? c / dan : 0.f;
-      if (a == r) acc += ip * (xv - x[(int64_t)p * D + d]) - in_ * (xv - x[(int64_t)n * D + d]);
-      if (p == r) acc += ip * (xv - x[(int64_t)a * D + d]);
-      if (n == r) acc -= in_ * (xv - x[(int64_t)a * D + d]);
+      if (a == r) { t_other[k] = p; t_w[k++] = ip; t_other[k] = n; t_w[k++] = -in_; }
+      if (p == r) { t_other[k] = a; t_w[k++] = ip; }
+      if (n == r) { t_other[k] = a; t_w[k++] = -in_; }
     }
+    n_terms = k;
+  }
+  __syncthreads();
+  const int nt = n_terms;
+  if (nt == 0) return;
+  const float g = gscale * (gscale_ptr ? *gscale_ptr : 1.f);
+  const float* xr = x + (int64_t)r * D;
+  float* out = dx + (int64_t)r * D;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float xv = xr[d];
+    float acc = 0.f;
+    for (int k = 0; k < nt; ++k) acc += t_w[k] * (xv - x[(int64_t)t_other[k] * D + d]);
     out[d] += g * acc;
   }
 }
@@ -508,8 +522,9 @@ int creid_triplet_bwd(const float* x, int64_t N, int64_t D, const float* dist_ap
                       const int32_t* p_idx, const int32_t* n_idx, const float* coef, const float* gscale_dev,
                       float gscale, float* dx_accum, void* stream) {
   CREID_CHECK_ARG(x && dist_ap && dist_an && p_idx && n_idx && coef && dx_accum && N > 0 && D > 0);
-  hipLaunchKernelGGL(triplet_bwd_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), x, (int)N, (int)D,
-                     dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum);
+  if ((size_t)N * 8 * sizeof(float) > 48 * 1024) return CREID_E_SHAPE;
+  hipLaunchKernelGGL(triplet_bwd_kernel, dim3((unsigned)N), dim3(256), (size_t)N * 8 * sizeof(float), as_stream(stream), x,
+                     (int)N, (int)D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum);
   CREID_LAUNCH_RET();
 }
 

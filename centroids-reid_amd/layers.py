@@ -144,5 +144,5 @@ def bn2d_bwd(x, g, act, mean, invstd, gamma, want_gm=False):
     dx = torch.empty_like(x)
     gm = torch.empty_like(x) if want_gm else None
     L.check(lib.creid_bn2d_bwd(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), M, Cc, _dt(x),
-                               L.ptr(part), L.ptr(sums), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx), L.ptr(gm), st), "bn2d_bwd")
+                               L.ptr(part), 0, L.ptr(sums), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx), L.ptr(gm), st), "bn2d_bwd")
     return dx, dgamma, dbeta, gm

@@ -183,6 +183,13 @@ int creid_conv2d_fwd_nhwc(const creid_conv_desc* d, const void* x, const void* w
 /* data gradient: dx = conv_transpose(dy, w) (+ add_src if non-NULL); w_crsk is [in_c][kh][kw][out_c]. */
 int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
                             const void* add_src, int dtype, void* stream);
+/* The same data gradient with the column reduction of the NEXT BatchNorm backward fused into the epilogue
+ * (bf16 only): dx is g = dL/da of the layer whose raw conv output is bn_x and post-ReLU activation bn_act
+ * (nullable); bn_partial[ceil(M/128)][2][in_c] receives (sum dy, sum dy*xhat), dy = g*[bn_act > 0]. */
+int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
+                                  const void* add_src, const void* bn_x, const void* bn_act,
+                                  const float* bn_mean, const float* bn_invstd, float* bn_partial, int dtype,
+                                  void* stream);
 /* weight gradient into the fp32 OIHW tensor (the reference's nn.Parameter layout), optionally
  * accumulating; the pixel reduction is split over workgroups through `ws`. */
 size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype);
@@ -218,7 +225,8 @@ int creid_weight_prep_multi(const void* table_dev, const int32_t* tile_start_dev
  * BN + residual-add + ReLU tail of Bottleneck.forward (resnet.py:72-85);
  * bwd: dy = g * [act > 0] (act nullable); dgamma += sum dy*xhat; dbeta += sum dy;
  *      dx = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)); gm_out (nullable) = dy.
- *      partial = float[creid_bn2d_bwd_rows(M)][2][C] scratch, sums = float[3][C] scratch. */
+ *      partial = float[creid_bn2d_bwd_rows(M)][2][C] scratch (partial_ready != 0: already filled by
+ *      creid_conv2d_dgrad_bnred_nhwc, the column pass is skipped), sums = float[3][C] scratch. */
 int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t count, float* running_mean,
                         float* running_var, int training, float momentum, float eps, const float* gamma,
                         const float* beta, float* mean_out, float* invstd_out, float* scale_shift,
@@ -229,8 +237,8 @@ int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residu
                      int64_t C, int dtype, void* y, void* stream);
 int64_t creid_bn2d_bwd_rows(int64_t M);
 int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
-                   const float* gamma, int64_t M, int64_t C, int dtype, float* partial, float* sums,
-                   float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out, void* stream);
+                   const float* gamma, int64_t M, int64_t C, int dtype, float* partial, int partial_ready,
+                   float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out, void* stream);
 
 /* IBN of ResNet50-IBN-a (modelling/backbones/resnet_ibn_a.py:18-32): channels [0, c_in) InstanceNorm2d
  * (affine, per-(image, channel) statistics over H*W, eps 1e-5, no running stats), channels [c_in, C)

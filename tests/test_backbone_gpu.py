@@ -271,3 +271,27 @@ def test_ibn_layer_vs_torch(dtype):
         np.testing.assert_allclose(dx.float().cpu().permute(0, 3, 1, 2).numpy(), xr.grad.float().numpy(), **t2)
         for got, ref in zip(d, p):
             np.testing.assert_allclose(got.cpu().numpy(), ref.grad.float().numpy(), rtol=2e-3, atol=2e-2 if dtype == torch.bfloat16 else 1e-4)
+
+
+def test_fused_bn_reduce_matches_separate_pass():
+    """bf16: the BN-backward column reduction fused into the dgrad epilogue gives the same gradients as the
+    separate reduction pass (identical bf16 inputs, only the fp32 summation order differs)."""
+    from oracle import backbone_oracle as bo
+    x = bo.synthetic_images(4, 128, 64, seed=21).cuda()
+    coef = torch.from_numpy(np.random.default_rng(3).standard_normal((4, 2048)).astype(np.float32)).cuda()
+    grads = []
+    for fuse in (True, False):
+        net, eng, _ = _build("resnet50", torch.bfloat16)
+        eng.fuse_bn_reduce = fuse
+        _, feat = eng.forward(x, training=True)
+        eng.backward(coef)
+        grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        a, b = grads[0][n].double().flatten(), grads[1][n].double().flatten()
+        if float(b.norm()) < 1e-6:      # analytically-zero gradients (bn1.bias): both are rounding noise
+            continue
+        # the two evaluations differ by fp32 summation order only; bf16 re-rounding of dx amplifies that along
+        # the 53-layer chain, so the bound is tight where the fusion first acts (layer4) and loose at the stem
+        # (measured: 1e-7 in layer4.2, growing ~3x per layer -- train-mode BN over 4 tiny images is chaotic)
+        tol = 1e-5 if n.startswith("layer4.2") else 0.1
+        assert float((a - b).norm() / b.norm()) < tol, (n, float((a - b).norm() / b.norm()))
