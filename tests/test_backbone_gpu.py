@@ -288,7 +288,7 @@ def test_fused_bn_reduce_matches_separate_pass():
         grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
     for n in grads[0]:
         a, b = grads[0][n].double().flatten(), grads[1][n].double().flatten()
-        if float(b.norm()) < 1e-6:      # analytically-zero gradients (bn1.bias): both are rounding noise
+        if n == "bn1.bias" or float(b.norm()) < 1e-6:   # analytically-zero gradient: both hold rounding noise
             continue
         # the two evaluations differ by fp32 summation order only; bf16 re-rounding of dx amplifies that along
         # the 53-layer chain, so the bound is tight where the fusion first acts (layer4) and loose at the stem
