@@ -146,3 +146,19 @@ def bn2d_bwd(x, g, act, mean, invstd, gamma, want_gm=False):
     L.check(lib.creid_bn2d_bwd(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), M, Cc, _dt(x),
                                L.ptr(part), 0, L.ptr(sums), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx), L.ptr(gm), st), "bn2d_bwd")
     return dx, dgamma, dbeta, gm
+
+
+def conv2d_dgrad_bnred(dy, w_crsk, in_hw, stride, pad, bn_x, bn_act, mean, invstd, add_src=None):
+    """dgrad + fused column reduction of the next BN backward -> (dx, partial [rows, 2, Cin])."""
+    L.require_gpu(dy, w_crsk, bn_x)
+    B, oh, ow, cout = dy.shape
+    cin, k = w_crsk.shape[0], w_crsk.shape[1]
+    H, W = in_hw
+    d, _, _ = conv_desc(B, H, W, cin, cout, k, stride, pad)
+    dx = torch.empty((B, H, W, cin), dtype=dy.dtype, device=dy.device)
+    rows = L.lib().creid_bn2d_bwd_rows(B * H * W)
+    part = torch.empty((rows, 2, cin), dtype=torch.float32, device=dy.device)
+    L.check(L.lib().creid_conv2d_dgrad_bnred_nhwc(C.byref(d), L.ptr(dy), L.ptr(w_crsk), L.ptr(dx), L.ptr(add_src), L.ptr(bn_x),
+                                                  L.ptr(bn_act), L.ptr(mean), L.ptr(invstd), L.ptr(part), _dt(dy), L.stream()),
+            "conv2d_dgrad_bnred")
+    return dx, part

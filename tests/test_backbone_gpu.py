@@ -295,3 +295,31 @@ def test_fused_bn_reduce_matches_separate_pass():
         # (measured: 1e-7 in layer4.2, growing ~3x per layer -- train-mode BN over 4 tiny images is chaotic)
         tol = 1e-5 if n.startswith("layer4.2") else 0.1
         assert float((a - b).norm() / b.norm()) < tol, (n, float((a - b).norm() / b.norm()))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 8, 64, 128, 3, 1), (2, 16, 8, 256, 64, 1, 1), (1, 10, 10, 128, 256, 1, 1)])
+def test_dgrad_fused_bn_reduction(case):
+    """creid_conv2d_dgrad_bnred_nhwc: dx equals the plain dgrad, and the fused partials equal the column sums
+    (sum dy, sum dy*xhat), dy = dx*[act>0], computed by torch from the SAME bf16 dx."""
+    from centroids_reid_amd import layers as ly
+    B, H, W, cin, cout, k, stride = case
+    pad = k // 2
+    rng = np.random.default_rng(sum(case) + 1)
+    w = torch.from_numpy((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)).cuda()
+    krsc, crsk = ly.weight_prep(w, torch.bfloat16)
+    gy = torch.from_numpy(rng.standard_normal((B, H, W, cout)).astype(np.float32)).to(torch.bfloat16).cuda()
+    bn_x = torch.from_numpy((rng.standard_normal((B, H, W, cin)) * 1.5).astype(np.float32)).to(torch.bfloat16).cuda()
+    act = torch.relu(torch.from_numpy(rng.standard_normal((B, H, W, cin)).astype(np.float32))).to(torch.bfloat16).cuda()
+    add = torch.from_numpy(rng.standard_normal((B, H, W, cin)).astype(np.float32)).to(torch.bfloat16).cuda()
+    mean = torch.from_numpy(rng.standard_normal(cin).astype(np.float32)).cuda()
+    invstd = torch.from_numpy((0.5 + rng.random(cin)).astype(np.float32)).cuda()
+    ref = ly.conv2d_dgrad(gy, crsk, (H, W), stride, pad, add_src=add)
+    dx, part = ly.conv2d_dgrad_bnred(gy, crsk, (H, W), stride, pad, bn_x, act, mean, invstd, add_src=add)
+    assert torch.equal(dx, ref)
+    dyv = dx.float() * (act.float() > 0)
+    s1 = dyv.sum(dim=(0, 1, 2)); s2 = (dyv * (bn_x.float() - mean) * invstd).sum(dim=(0, 1, 2))
+    got = part.sum(0)
+    np.testing.assert_allclose(got[0].cpu().numpy(), s1.cpu().numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(got[1].cpu().numpy(), s2.cpu().numpy(), rtol=1e-4, atol=2e-2)
+    dx2, part2 = ly.conv2d_dgrad_bnred(gy, crsk, (H, W), stride, pad, bn_x, None, mean, invstd)    # no mask, no add
+    np.testing.assert_allclose(part2.sum(0)[0].cpu().numpy(), dx2.float().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-2)
