@@ -300,7 +300,7 @@ def gen_backbone(ref, name, arch, B, H, W):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.load()
-    which = sys.argv[1:] or ["eval", "losses", "heads", "backbone"]
+    which = [a for a in sys.argv[1:] if a != "sampler"] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
     if "eval" in which:
         gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
         gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
@@ -321,3 +321,40 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def gen_sampler():
+    """PK sampler + per-PID dataset of the reference on a synthetic identity table."""
+    import importlib, random, json
+    ref_import.install_stubs(); ref_import.ref_path_first()
+    smod = importlib.import_module("datasets.samplers.distributed_pids_sampler")
+    rng = np.random.default_rng(41)
+    counts = rng.integers(2, 11, 60)
+    table = {int(p): [(f"img{p}_{i}", int(p), int(rng.integers(0, 6)), int(1000 * p + i)) for i in range(int(c))]
+             for p, c in enumerate(counts)}
+    rec = {"counts": counts.astype(np.int64)}
+    for world in (1, 2):
+        for rank in range(world):
+            s = smod.RandomIdentitySampler({p: [t[3] for t in v] for p, v in table.items()}, 4, 4, world, rank)
+            for ep in (0, 1):
+                s.set_epoch(ep)
+                rec[f"w{world}_r{rank}_e{ep}"] = np.asarray([int(x) for x in s], np.int64)
+                rec[f"w{world}_r{rank}_e{ep}_len"] = np.int64(len(s))
+    bases = importlib.import_module("datasets.bases")
+    for resample in (False, True):
+        ds = bases.BaseDatasetLabelledPerPid({p: list(v) for p, v in table.items()}, None, 4, resample)
+        ds.prepare_img = lambda path: torch.full((1, 2, 2), float(int(path[3:].split("_")[0]) * 100 + int(path.split("_")[1])))
+        random.seed(5); np.random.seed(5)
+        rows = []
+        for pid in (0, 3, 7, 3, 11, 20):
+            if len(ds.samples[pid]) <= 1:
+                continue
+            out = ds[pid]
+            rows.append([[float(t[0].flatten()[0]), t[1], t[2], t[3], int(t[4])] for t in out])
+        rec[f"items_resample{int(resample)}"] = np.asarray(rows, np.float64)
+    np.savez_compressed(os.path.join(OUT, "sampler"), table=np.array(json.dumps({str(k): v for k, v in table.items()})), **rec)
+    print("[sampler] sequences", {k: len(v) for k, v in rec.items() if k.startswith("w") and not k.endswith("len")})
+
+
+if __name__ == "__main__" and "sampler" in sys.argv[1:]:
+    gen_sampler()
