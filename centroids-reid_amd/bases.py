@@ -103,6 +103,37 @@ class ModelBase(_Base):
         def current_epoch(self):
             return self.trainer.current_epoch
 
+    # ------------------------------------------------------------------ checkpoint IO
+    def checkpoint_dict(self, epoch=0, global_step=0):
+        """The pytorch-lightning 1.1.4 checkpoint layout the reference's callbacks write
+        (utils/misc.py:80-93, callbacks/chechpointer_callback.py:56-74): state_dict (325 keys for R50-CTL),
+        hyper_parameters, optimizer_states, lr_schedulers, epoch, global_step, callbacks."""
+        def plain(d):
+            return {k: plain(v) if isinstance(v, dict) else v for k, v in d.items()}
+        opts = self._optimizers if pl is None else None
+        return {
+            "epoch": epoch, "global_step": global_step, "pytorch-lightning_version": "1.1.4",
+            "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+            "hparams_name": "kwargs", "hyper_parameters": plain(dict(self.hparams)),
+            "optimizer_states": [o.state_dict() for o in (opts or [])],
+            "lr_schedulers": [self.lr_scheduler.state_dict()] if hasattr(self, "lr_scheduler") else [],
+            "callbacks": {},
+        }
+
+    def save_checkpoint(self, path, epoch=0, global_step=0):
+        torch.save(self.checkpoint_dict(epoch, global_step), path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location="cpu", strict=True, **overrides):
+        """pl.LightningModule.load_from_checkpoint as the reference uses it (utils/misc.py:128-147,
+        inference/get_similar.py:84): rebuild the module from `hyper_parameters`, then load `state_dict`."""
+        ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+        hp = _to_attr({**ckpt["hyper_parameters"], **overrides})
+        hp["MODEL"]["PRETRAINED"] = False            # weights come from the checkpoint, not from ImageNet
+        model = cls(cfg=None, **hp)
+        model.load_state_dict(ckpt["state_dict"], strict=strict)
+        return model
+
     def training_step(self, batch, batch_idx, opt_idx=None):
         raise NotImplementedError("A used model should have its own training_step method implemented")
 
@@ -141,26 +172,52 @@ class ModelBase(_Base):
         """modelling/bases.py:179-262 (respect_camids=False): gallery -> per-PID mean (device kernel);
         returns (embeddings [nq + n_centroids, D], labels, camids) with the reference's dummy camids
         (including its nq-longer-than-needed camid vector, bases.py:255-260)."""
-        if respect_camids:
-            raise NotImplementedError("camera-set centroids (KEEP_CAMID_CENTROIDS) are a SURVEY §8f 'next' row")
         num_query = self.hparams.num_query
         labels = np.asarray(labels)
         emb = embeddings.float().contiguous()
         L.require_gpu(emb)
         lq, lg = labels[:num_query], labels[num_query:]
-        uniq, inverse = np.unique(lg, return_inverse=True)
-        order = np.argsort(inverse, kind="stable")            # gallery rows grouped by PID, original order kept
-        counts = np.bincount(inverse, minlength=len(uniq))
-        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        groups, cent_labels, cent_cams = [], [], []
+        if respect_camids:
+            # modelling/bases.py:205-236.  For each gallery PID and each distinct camera of its QUERIES: one
+            # centroid of the gallery rows from other cameras, de-duplicated by camera set.  The reference looks
+            # the gallery cameras up as camids[inds] with gallery-relative indices on the full vector (:214);
+            # that quirk is kept so results match.
+            camids = np.asarray(camids)
+            for u in np.unique(lg):
+                inds = np.nonzero(lg == u)[0]
+                cams_g = camids[inds]
+                seen = set()
+                for cur in np.unique(camids[np.nonzero(lq == u)[0]]):
+                    sel = np.nonzero(cams_g != cur)[0]
+                    if len(sel) == 0:
+                        continue
+                    used = tuple(sorted(np.unique(cams_g[cams_g != cur]).tolist()))
+                    if used in seen:
+                        continue
+                    seen.add(used)
+                    groups.append(inds[sel]); cent_labels.append(u); cent_cams.append(list(used))
+        else:
+            uniq, inverse = np.unique(lg, return_inverse=True)
+            order_all = np.argsort(inverse, kind="stable")        # gallery rows grouped by PID, original order kept
+            counts = np.bincount(inverse, minlength=len(uniq))
+            bounds = np.concatenate([[0], np.cumsum(counts)])
+            groups = [order_all[bounds[i]:bounds[i + 1]] for i in range(len(uniq))]
+            cent_labels = list(uniq)
+        order = np.concatenate(groups).astype(np.int64) + num_query
+        offsets = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.int64)
         dev = emb.device
-        order_t = torch.as_tensor(order.astype(np.int64) + num_query, device=dev)
+        order_t = torch.as_tensor(order, device=dev)
         off_t = torch.as_tensor(offsets, device=dev)
-        cents = torch.empty((len(uniq), emb.shape[1]), dtype=torch.float32, device=dev)
-        L.check(L.lib().creid_gather_mean_rows(L.ptr(emb), L.ptr(order_t), L.ptr(off_t), len(uniq), emb.shape[1],
+        cents = torch.empty((len(groups), emb.shape[1]), dtype=torch.float32, device=dev)
+        L.check(L.lib().creid_gather_mean_rows(L.ptr(emb), L.ptr(order_t), L.ptr(off_t), len(groups), emb.shape[1],
                                                L.ptr(cents), L.stream()), "creid_gather_mean_rows")
         out = torch.cat((emb[:num_query], cents), dim=0)
-        out_labels = np.hstack((lq, uniq))
-        out_camids = np.hstack((np.zeros_like(lq), np.ones_like(out_labels)))
+        out_labels = np.hstack((lq, np.asarray(cent_labels)))
+        if respect_camids:
+            out_camids = [[c] for c in camids[:num_query]] + cent_cams             # :250-253
+        else:
+            out_camids = np.hstack((np.zeros_like(lq), np.ones_like(out_labels)))   # :255-260 (quirk kept)
         return out, out_labels, out_camids
 
     def get_val_metrics(self, embeddings, labels, camids):
@@ -168,8 +225,6 @@ class ModelBase(_Base):
         self.r1_map_func = R1_mAP(pl_module=self, num_query=self.hparams.num_query,
                                   feat_norm=self.hparams.TEST.FEAT_NORM)
         respect_camids = bool(self.hparams.MODEL.KEEP_CAMID_CENTROIDS and self.hparams.MODEL.USE_CENTROIDS)
-        if respect_camids:
-            raise NotImplementedError("camera-set centroids (KEEP_CAMID_CENTROIDS) are a SURVEY §8f 'next' row")
         cmc, mAP, all_topk = self.r1_map_func.compute(feats=embeddings.float(), pids=labels, camids=camids,
                                                       respect_camids=respect_camids)
         topks = {}
@@ -192,8 +247,8 @@ class ModelBase(_Base):
         del outputs
         if self.hparams.MODEL.USE_CENTROIDS:
             print("Evaluation is done using centroids")
-            embeddings, labels, camids = self.validation_create_centroids(embeddings, labels, camids,
-                                                                          respect_camids=False)
+            embeddings, labels, camids = self.validation_create_centroids(
+                embeddings, labels, camids, respect_camids=self.hparams.MODEL.KEEP_CAMID_CENTROIDS)
         return self.get_val_metrics(embeddings, labels, camids)
 
     @staticmethod

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(RT) void rank_rows_kernel(const float* __restrict__
 // segment of rank positions; pass 1 counts kept / matched per segment, pass 2 re-walks with
 // the exclusive bases and accumulates AP in float64.
 // ----------------------------------------------------------------------------------------
+template <bool CAMSETS>
 __global__ __launch_bounds__(256) void cmc_ap_ranked_kernel(const int64_t* __restrict__ idx, int64_t m, int64_t n,
                                                             const int64_t* __restrict__ q_pids,
                                                             const int64_t* __restrict__ g_pids,
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(256) void cmc_ap_ranked_kernel(const int64_t* __res
     if (k < s1) {
       const int64_t gi = row[k];
       const bool match = g_pids[gi] == qp;
-      keep = !(match && g_cams[gi] == qc);
+      // CAMSETS: g_cams holds a bitmask of cameras per gallery entry; drop if the query's camera is in the set
+      keep = !(match && (CAMSETS ? (((unsigned long long)g_cams[gi] >> qc) & 1ull) != 0 : g_cams[gi] == qc));
       mk = match && keep;
     }
     nkeep += __popcll(__ballot(keep));
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void cmc_ap_ranked_kernel(const int64_t* __res
     if (k < s1) {
       const int64_t gi = row[k];
       const bool match = g_pids[gi] == qp;
-      keep = !(match && g_cams[gi] == qc);
+      keep = !(match && (CAMSETS ? (((unsigned long long)g_cams[gi] >> qc) & 1ull) != 0 : g_cams[gi] == qc));
       mk = match && keep;
     }
     const unsigned long long km = __ballot(keep), mm = __ballot(mk);
@@ -254,8 +256,20 @@ int creid_cmc_ap_ranked(const int64_t* idx, int64_t m, int64_t n, const int64_t*
   if (m == 0) return 0;
   CREID_CHECK_ARG(idx && q_pids && g_pids && q_camids && g_camids && out_valid && out_ap && out_first);
   if (m > 0x7fffffffLL || n > 0x7fffff00LL) return CREID_E_SHAPE;
-  hipLaunchKernelGGL(cmc_ap_ranked_kernel, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
+  hipLaunchKernelGGL(cmc_ap_ranked_kernel<false>, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
                      g_pids, q_camids, g_camids, out_valid, out_ap, out_first);
+  CREID_LAUNCH_RET();
+}
+
+int creid_cmc_ap_ranked_camsets(const int64_t* idx, int64_t m, int64_t n, const int64_t* q_pids, const int64_t* g_pids,
+                                const int64_t* q_camids, const int64_t* g_cam_masks, uint8_t* out_valid, double* out_ap,
+                                int32_t* out_first, void* stream) {
+  CREID_CHECK_ARG(m >= 0 && n >= 0);
+  if (m == 0) return 0;
+  CREID_CHECK_ARG(idx && q_pids && g_pids && q_camids && g_cam_masks && out_valid && out_ap && out_first);
+  if (m > 0x7fffffffLL || n > 0x7fffff00LL) return CREID_E_SHAPE;
+  hipLaunchKernelGGL(cmc_ap_ranked_kernel<true>, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
+                     g_pids, q_camids, g_cam_masks, out_valid, out_ap, out_first);
   CREID_LAUNCH_RET();
 }
 

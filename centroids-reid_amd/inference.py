@@ -1,0 +1,103 @@
+"""Second caller of stages A + D + E: embedding extraction and similarity search with
+the reference's on-disk formats.
+
+Mirrors inference/inference_utils.py:104-159 (`_inference`, `run_inference`, `create_pid_path_index`,
+`calculate_centroids`) and inference/get_similar.py:99-137 (normalise -> distance -> argsort -> top-k dict ->
+`results.npy` / `query_embeddings.npy` / `query_paths.npy`), inference/create_embeddings.py:75-97
+(`embeddings.npy`, `paths.npy`).  All arithmetic runs on the device through the same kernels as evaluation;
+files are written with numpy exactly like the reference (dict-of-dicts pickled by np.save).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Callable, Dict, List
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import reid_metric as rm
+
+
+def _inference(model, batch, use_cuda=True, normalize_with_bn=True):
+    """inference_utils.py:104-113: eval-mode backbone (+ BNNeck)."""
+    model.eval()
+    with torch.no_grad():
+        data, _, filename = batch
+        _, global_feat = model.backbone(data.cuda() if use_cuda else data)
+        if normalize_with_bn:
+            global_feat = model.bn(global_feat)
+        return global_feat, filename
+
+
+def run_inference(model, val_loader, cfg=None, print_freq=0, use_cuda=True):
+    """inference_utils.py:116-131 -> (embeddings float32 [N, D] ndarray, paths ndarray); the embeddings are
+    also kept on the device in `run_inference.last_device_embeddings` for a following get_similar()."""
+    embs, paths = [], []
+    for batch in val_loader:
+        e, p = _inference(model, batch, use_cuda)
+        embs.append(e.float())
+        paths.extend(list(p))
+    dev = torch.cat(embs)
+    run_inference.last_device_embeddings = dev
+    return dev.cpu().numpy(), np.array(paths)
+
+
+def create_pid_path_index(paths: List[str], func: Callable[[str], str]) -> Dict[str, list]:
+    """inference_utils.py:134-144."""
+    index: Dict[str, list] = {}
+    for i, p in enumerate(paths):
+        index.setdefault(func(p), []).append(i)
+    return index
+
+
+def calculate_centroids(embeddings, pid_path_index):
+    """inference_utils.py:147-159: per-PID mean embedding -> (centroids [n_pid, D] float32, pid keys as str)."""
+    keys = list(pid_path_index.keys())
+    order = np.concatenate([np.asarray(pid_path_index[k], np.int64) for k in keys])
+    offsets = np.concatenate([[0], np.cumsum([len(pid_path_index[k]) for k in keys])]).astype(np.int64)
+    emb = embeddings if isinstance(embeddings, torch.Tensor) else torch.from_numpy(np.asarray(embeddings, np.float32))
+    emb = emb.float().cuda().contiguous()
+    out = torch.empty((len(keys), emb.shape[1]), dtype=torch.float32, device=emb.device)
+    L.check(L.lib().creid_gather_mean_rows(L.ptr(emb), L.ptr(torch.as_tensor(order, device=emb.device)),
+                                           L.ptr(torch.as_tensor(offsets, device=emb.device)), len(keys), emb.shape[1],
+                                           L.ptr(out), L.stream()), "creid_gather_mean_rows")
+    return out.cpu().numpy(), np.array(keys, dtype=np.str_)
+
+
+def save_embeddings(save_dir, embeddings, paths):
+    """inference/create_embeddings.py:92-97."""
+    d = Path(save_dir); d.mkdir(exist_ok=True, parents=True)
+    np.save(d / "embeddings.npy", np.asarray(embeddings))
+    np.save(d / "paths.npy", np.asarray(paths))
+
+
+def load_gallery(load_dir):
+    d = Path(load_dir)
+    return np.load(d / "embeddings.npy", allow_pickle=True), np.load(d / "paths.npy", allow_pickle=True)
+
+
+def get_similar(embeddings, paths, embeddings_gallery, paths_gallery, topk=0, normalize_features=True,
+                distance_func="euclidean"):
+    """inference/get_similar.py:99-125 -> {query_path: {"indices", "paths", "distances"}} (numpy arrays)."""
+    q = torch.as_tensor(np.asarray(embeddings, np.float32)).cuda() if not isinstance(embeddings, torch.Tensor) else embeddings.float().cuda()
+    g = torch.as_tensor(np.asarray(embeddings_gallery, np.float32)).cuda() if not isinstance(embeddings_gallery, torch.Tensor) else embeddings_gallery.float().cuda()
+    if normalize_features:
+        q, g = rm.l2_normalize(q.contiguous()), rm.l2_normalize(g.contiguous())
+    distmat = rm.get_dist_func(distance_func)(x=q.contiguous(), y=g.contiguous())
+    indices = rm.rank_rows(distmat.contiguous())
+    if topk:
+        indices = indices[:, :topk]
+    dist_sel = torch.gather(distmat, 1, indices).cpu().numpy()
+    idx = indices.cpu().numpy()
+    paths_gallery = np.asarray(paths_gallery)
+    return {qp: {"indices": idx[i, :], "paths": paths_gallery[idx[i, :]], "distances": dist_sel[i, :]}
+            for i, qp in enumerate(paths)}
+
+
+def save_results(out_dir, results, embeddings, paths):
+    """inference/get_similar.py:127-137."""
+    d = Path(out_dir); d.mkdir(exist_ok=True, parents=True)
+    np.save(d / "results.npy", results)
+    np.save(d / "query_embeddings.npy", np.asarray(embeddings))
+    np.save(d / "query_paths.npy", np.asarray(paths))

@@ -85,22 +85,38 @@ def _dev_i64(a, device):
     return torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.int64), device=device)
 
 
-def eval_func_device(indices: torch.Tensor, q_pids, g_pids, q_camids, g_camids, max_rank=50):
+def _camset_masks(g_camids):
+    """list of camera-id lists -> int64 bitmasks (camera ids must be < 63)."""
+    out = np.zeros(len(g_camids), np.int64)
+    for j, cs in enumerate(g_camids):
+        for c in np.atleast_1d(cs):
+            c = int(c)
+            if not 0 <= c < 63:
+                raise L.CreidError("camera-set evaluation supports camera ids 0..62")
+            out[j] |= np.int64(1) << np.int64(c)
+    return out
+
+
+def eval_func_device(indices: torch.Tensor, q_pids, g_pids, q_camids, g_camids, max_rank=50, camsets=False):
     """Device half of eval_func: returns device tensors (cmc f32[max_rank], mAP f64[1], topk f64[5],
-    nvalid i64[1], valid u8[m], ap f64[m], first i32[m])."""
+    nvalid i64[1], valid u8[m], ap f64[m], first i32[m]).  camsets: g_camids is a list of camera-id lists."""
     L.require_gpu(indices)
     dev = indices.device
     m, n = indices.shape
     if n < max_rank:  # utils/eval_reid.py:33-35
         max_rank = n
         print("Note: number of gallery samples is quite small, got {}".format(n))
+    if camsets:
+        g_camids = _camset_masks(g_camids)
+        q_camids = np.asarray([int(np.atleast_1d(c)[0]) for c in q_camids], np.int64)
     qp, gp, qc, gc = (_dev_i64(a, dev) for a in (q_pids, g_pids, q_camids, g_camids))
     valid = torch.empty(m, dtype=torch.uint8, device=dev)
     ap = torch.empty(m, dtype=torch.float64, device=dev)
     first = torch.empty(m, dtype=torch.int32, device=dev)
     lib = L.lib()
-    L.check(lib.creid_cmc_ap_ranked(L.ptr(indices), m, n, L.ptr(qp), L.ptr(gp), L.ptr(qc), L.ptr(gc),
-                                    L.ptr(valid), L.ptr(ap), L.ptr(first), L.stream()), "creid_cmc_ap_ranked")
+    fn = lib.creid_cmc_ap_ranked_camsets if camsets else lib.creid_cmc_ap_ranked
+    L.check(fn(L.ptr(indices), m, n, L.ptr(qp), L.ptr(gp), L.ptr(qc), L.ptr(gc), L.ptr(valid), L.ptr(ap), L.ptr(first),
+               L.stream()), "creid_cmc_ap_ranked")
     cmc = torch.empty(max_rank, dtype=torch.float32, device=dev)
     mAP = torch.empty(1, dtype=torch.float64, device=dev)
     topk = torch.empty(5, dtype=torch.float64, device=dev)
@@ -113,11 +129,10 @@ def eval_func_device(indices: torch.Tensor, q_pids, g_pids, q_camids, g_camids, 
 def eval_func(indices, q_pids, g_pids, q_camids, g_camids, max_rank=50, respect_camids=False):
     """utils/eval_reid.py:25-92: returns (all_cmc float32[max_rank], mAP float, all_topk float64[5],
     single_performance float64[n_valid, 3] = rows [q_idx, q_pid, AP])."""
-    if respect_camids:
-        raise NotImplementedError("respect_camids=True (camera-set centroids) is a SURVEY §8f 'next' row")
     if not isinstance(indices, torch.Tensor):
         raise L.CreidError("eval_func needs a device tensor of ranked indices (no CPU fallback)")
-    cmc, mAP, topk, nvalid, valid, ap, first = eval_func_device(indices, q_pids, g_pids, q_camids, g_camids, max_rank)
+    cmc, mAP, topk, nvalid, valid, ap, first = eval_func_device(indices, q_pids, g_pids, q_camids, g_camids, max_rank,
+                                                                camsets=bool(respect_camids))
     valid_h = valid.cpu().numpy().astype(bool)
     vi = np.nonzero(valid_h)[0]
     qp = np.asarray(q_pids.cpu() if isinstance(q_pids, torch.Tensor) else q_pids)
@@ -162,7 +177,9 @@ class R1_mAP:
             f = l2_normalize(feats) if self.feat_norm else feats
             distmat = self.dist_func(f[:nq].contiguous(), f[nq:].contiguous())
         indices = rank_rows(distmat)
-        pids = np.asarray(pids); camids = np.asarray(camids)
+        pids = np.asarray(pids)
+        if not respect_camids:
+            camids = np.asarray(camids)     # (ragged list-of-lists in camera-set mode: keep as a list)
         cmc, mAP, all_topk, single = eval_func(indices, pids[:nq], pids[nq:], camids[:nq], camids[nq:],
                                                self.max_rank, respect_camids)
         self.last = dict(distmat=distmat, indices=indices, single_performance=single)

@@ -73,6 +73,13 @@ int creid_cmc_ap_ranked(const int64_t* idx, int64_t m, int64_t n, const int64_t*
                         const int64_t* g_pids, const int64_t* q_camids, const int64_t* g_camids,
                         uint8_t* out_valid, double* out_ap, int32_t* out_first, void* stream);
 
+/* The same scan for camera-set gallery entries (respect_camids=True, utils/eval_reid.py:51-55, fed by
+ * modelling/bases.py:205-236): g_cam_masks[j] = bitmask of the camera ids (< 64) of gallery entry j; an entry
+ * is dropped for a query iff it has the query's pid AND bit q_camids[i] is set in its mask. */
+int creid_cmc_ap_ranked_camsets(const int64_t* idx, int64_t m, int64_t n, const int64_t* q_pids,
+                                const int64_t* g_pids, const int64_t* q_camids, const int64_t* g_cam_masks,
+                                uint8_t* out_valid, double* out_ap, int32_t* out_first, void* stream);
+
 /* utils/eval_reid.py:86-90: means over valid queries.  out_cmc float32[max_rank]
  * (= count(first<=r)/n_valid in float32), out_map float64[1], out_topk float64[5] for
  * k in {1,5,10,20,50}, out_nvalid int64[1]. */

@@ -118,6 +118,64 @@ def val_centroids(emb: torch.Tensor, labels, camids, num_query: int):
     return out, out_labels, out_cam
 
 
+def val_centroids_camera(emb: torch.Tensor, labels, camids, num_query: int):
+    """modelling/bases.py:179-262 with respect_camids=True.  For every gallery PID and every distinct camera of
+    its QUERIES, one centroid of the gallery rows seen by OTHER cameras, de-duplicated by camera set.  Quirk
+    kept on purpose (:214): the gallery rows' camera ids are looked up as camids[inds] with GALLERY-relative
+    indices on the FULL (query-first) camid vector.  Returns (emb [nq + n_cent, D], labels, cam_sets) where
+    cam_sets is a list of lists ([cam] for each query, the used-camera list for each centroid)."""
+    labels = np.asarray(labels); camids = np.asarray(camids)
+    eq, lq = emb[:num_query], labels[:num_query]
+    eg, lg = emb[num_query:], labels[num_query:]
+    cents, cl, cc = [], [], []
+    for u in np.unique(lg):
+        inds = np.nonzero(lg == u)[0]
+        inds_q = np.nonzero(lq == u)[0]
+        cams_g = camids[inds]                      # the reference's indexing quirk
+        seen = set()
+        for cur in np.unique(camids[inds_q]):
+            sel = np.nonzero(cams_g != cur)[0]
+            if len(sel) == 0:
+                continue
+            used = tuple(sorted(np.unique(cams_g[cams_g != cur]).tolist()))
+            if used in seen:
+                continue
+            seen.add(used)
+            rows = eg[torch.from_numpy(inds[sel])]
+            cents.append(rows.sum(0) / rows.shape[0]); cl.append(u); cc.append(list(used))
+    out = torch.cat([eq, torch.stack(cents)], 0)
+    return out, np.hstack([lq, np.asarray(cl)]), [[int(c)] for c in camids[:num_query]] + cc
+
+
+def eval_market_camsets(indices, q_pids, g_pids, q_cams, g_cam_sets, max_rank: int = 50):
+    """utils/eval_reid.py:25-92 with respect_camids=True (:51-55): a gallery entry is dropped for a query iff it
+    has the query's pid AND the query's camera is in the entry's camera SET."""
+    indices = np.asarray(indices)
+    nq, ng = indices.shape
+    member = np.zeros((ng, 64), bool)
+    for j, cs in enumerate(g_cam_sets):
+        member[j, list(cs)] = True
+    q_pids = np.asarray(q_pids); g_pids = np.asarray(g_pids); q_cams = np.asarray(q_cams)
+    if ng < max_rank:
+        max_rank = ng
+    valid = np.zeros(nq, bool); ap = np.zeros(nq); first = np.full(nq, -1, np.int64)
+    for qi in range(nq):
+        order = indices[qi]
+        match = g_pids[order] == q_pids[qi]
+        keep = ~(match & member[order, q_cams[qi]])
+        mk = match & keep
+        if not mk.any():
+            continue
+        kpos = np.cumsum(keep); cum = np.cumsum(mk)
+        valid[qi] = True
+        ap[qi] = (np.where(mk, cum / np.maximum(kpos, 1), 0.0)).sum() / mk.sum()
+        first[qi] = kpos[mk.argmax()] - 1
+    nv = float(valid.sum())
+    cmc = ((first[valid][:, None] <= np.arange(max_rank)[None, :]).astype(np.float32).sum(0) / nv).astype(np.float32)
+    topk = np.stack([(first[valid] < k) for k in K_LIST], axis=1).astype(np.int64).mean(0)
+    return cmc, float(np.mean(ap[valid])), topk, dict(valid=valid, ap=ap, first=first)
+
+
 def r1_map(feats: torch.Tensor, pids, camids, num_query: int, feat_norm: bool = True,
            dist: str = "euclidean"):
     """utils/reid_metric.py:112-151 R1_mAP.compute."""

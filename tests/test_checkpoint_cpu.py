@@ -1,0 +1,44 @@
+"""CPU: checkpoint layout contract: our CTLModel's state_dict has exactly the
+reference's keys and shapes (R50: 325, IBN-a: 353), and the PL-style checkpoint dict round-trips."""
+import numpy as np
+import pytest
+import torch
+
+
+def _cfg(arch):
+    from centroids_reid_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    cfg.MODEL.PRETRAINED = False
+    cfg.MODEL.NAME = arch
+    return cfg
+
+
+@pytest.mark.parametrize("arch,n", [("resnet50", 325), ("resnet50_ibn_a", 353)])
+def test_state_dict_layout_matches_reference(golden, arch, n):
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    g = golden("ckpt_keys")
+    m = CTLModel(_cfg(arch), num_classes=751, num_query=10)
+    sd = m.state_dict()
+    assert len(sd) == n == len(g[f"{arch}_keys"])
+    assert list(sd.keys()) == [str(k) for k in g[f"{arch}_keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g[f"{arch}_shapes"]]
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    m = CTLModel(_cfg("resnet50"), num_classes=37, num_query=5)
+    ck = m.checkpoint_dict(epoch=3, global_step=120)
+    assert {"state_dict", "hyper_parameters", "optimizer_states", "lr_schedulers", "epoch", "global_step", "callbacks"} <= set(ck)
+    assert ck["hyper_parameters"]["num_classes"] == 37 and ck["hyper_parameters"]["SOLVER"]["MARGIN"] == 0.5
+    p = tmp_path / "epoch=3.ckpt"
+    m.save_checkpoint(p, 3, 120)
+    m2 = CTLModel.load_from_checkpoint(p)
+    assert m2.hparams.num_classes == 37 and m2.hparams.MODEL.NAME == "resnet50"
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    # a reference-style pretrained backbone file ('base.' / 'backbone.base.' prefixes) loads through load_param
+    sd = {"state_dict": {"backbone.base." + k: v for k, v in m.backbone.base.state_dict().items()}}
+    torch.save(sd, tmp_path / "pre.pth")
+    m3 = CTLModel(_cfg("resnet50"), num_classes=37, num_query=5)
+    m3.backbone.base.load_param(str(tmp_path / "pre.pth"))
+    assert torch.equal(m3.backbone.base.layer3[2].conv2.weight, m.backbone.base.layer3[2].conv2.weight)

@@ -144,3 +144,26 @@ def test_backbone_oracle(golden, name):
     np.testing.assert_allclose(gc1, g["grad_conv1"], rtol=2e-3, atol=2e-3 * scale)
     gl4 = params["layer4.2.conv3.weight"].grad[:16, :, 0, 0].numpy()
     np.testing.assert_allclose(gl4, g["grad_l4_conv3_slice"], rtol=2e-3, atol=2e-3 * np.abs(gl4).max())
+
+
+def test_val_centroids_camera_sets(golden):
+    """respect_camids=True (modelling/bases.py:205-253 + utils/eval_reid.py:51-55) against the reference."""
+    g = golden("eval_camsets")
+    nq = int(g["num_query"])
+    emb, labels, camsets = ro.val_centroids_camera(torch.from_numpy(g["feats"]), g["pids"], g["camids"], nq)
+    np.testing.assert_allclose(emb.numpy(), g["cent_emb"], rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(labels, g["cent_labels"])
+    ref_sets = [[int(c) for c in row if c >= 0] for row in g["cent_camsets"]]
+    assert camsets[nq:] == ref_sets
+    cmc, mAP, topk, ex = ro.eval_market_camsets(g["indices"], labels[:nq], labels[nq:], g["camids"][:nq], camsets[nq:])
+    assert abs(mAP - float(g["mAP"])) < 1e-12
+    np.testing.assert_allclose(cmc, g["cmc"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(topk, g["topk"], rtol=0, atol=1e-12)
+    # and the oracle's own ranking of the centroid gallery reproduces the reference's indices
+    f = ro.l2_normalize(emb)
+    idx = ro.rank_rows(ro.sqdist_matrix(f[:nq], f[nq:]))
+    gap_ok = np.ones_like(idx, bool)
+    ds = np.take_along_axis(ro.sqdist_matrix(f[:nq], f[nq:]).numpy(), idx, 1)
+    gap = np.diff(ds, axis=1) > 1e-6
+    gap_ok[:, 1:] &= gap; gap_ok[:, :-1] &= gap
+    np.testing.assert_array_equal(idx[gap_ok], g["indices"][gap_ok])

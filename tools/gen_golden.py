@@ -300,7 +300,7 @@ def gen_backbone(ref, name, arch, B, H, W):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.load()
-    which = [a for a in sys.argv[1:] if a != "sampler"] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
+    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
     if "eval" in which:
         gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
         gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
@@ -358,3 +358,58 @@ def gen_sampler():
 
 if __name__ == "__main__" and "sampler" in sys.argv[1:]:
     gen_sampler()
+
+
+def gen_ckpt_keys():
+    """state_dict key/shape layout of the reference's CTLModel (R50 and R50-IBN-a) -> checkpoint contract."""
+    ref = ref_import.load()
+    rec = {}
+    for arch in ("resnet50", "resnet50_ibn_a"):
+        cfg = make_cfg(ref)
+        cfg.MODEL.NAME = arch
+        m = ref.train_ctl_model.CTLModel(cfg, num_classes=751, num_query=10)
+        sd = m.state_dict()
+        rec[f"{arch}_keys"] = np.array(list(sd.keys()))
+        rec[f"{arch}_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+    np.savez_compressed(os.path.join(OUT, "ckpt_keys"), **rec)
+    print("[ckpt_keys]", {k: len(v) for k, v in rec.items()})
+
+
+if __name__ == "__main__" and "ckpt" in sys.argv[1:]:
+    gen_ckpt_keys()
+
+
+def gen_camsets():
+    """Camera-aware centroid evaluation (MODEL.KEEP_CAMID_CENTROIDS): modelling/bases.py:179-262 with
+    respect_camids=True, then utils/eval_reid.py:25-92 with respect_camids=True."""
+    ref = ref_import.load()
+    nq, ng, D, n_pid, n_cam = 200, 3000, 32, 120, 5
+    f, _ = gapped_features(nq, ng, D, 51, 0.0)
+    rng = np.random.default_rng(52)
+    pids = rng.integers(0, n_pid, nq + ng).astype(np.int64)
+    cams = rng.integers(0, n_cam, nq + ng).astype(np.int64)
+    fake = types.SimpleNamespace(hparams=ref_import.AttrDict(num_query=nq))
+    fake._calculate_centroids = ref.bases.ModelBase._calculate_centroids
+    emb, labels, camids = ref.bases.ModelBase.validation_create_centroids(fake, torch.from_numpy(f), pids, cams,
+                                                                          respect_camids=True)
+    fn = torch.nn.functional.normalize(emb.float(), dim=1, p=2)
+    distmat = ref.reid_metric.get_euclidean(x=fn[:nq], y=fn[nq:])
+    indices = np.argsort(distmat.numpy(), axis=1, kind="stable")
+    g_sets = np.empty(len(camids) - nq, dtype=object)
+    for i, cs in enumerate(camids[nq:]):
+        g_sets[i] = list(cs)
+    q_c = np.asarray([c[0] for c in camids[:nq]])
+    cmc, mAP, topk, single = ref.eval_reid.eval_func(indices, labels[:nq], labels[nq:], q_c, g_sets, 50, True)
+    ncent = emb.shape[0] - nq
+    sets_flat = np.full((ncent, n_cam), -1, np.int64)
+    for i, cs in enumerate(camids[nq:]):
+        sets_flat[i, :len(cs)] = cs
+    np.savez_compressed(os.path.join(OUT, "eval_camsets"), feats=f, pids=pids, camids=cams, num_query=np.int64(nq),
+                        cent_emb=emb.numpy(), cent_labels=np.asarray(labels, np.int64), cent_camsets=sets_flat,
+                        indices=indices.astype(np.int64), cmc=np.asarray(cmc, np.float32), mAP=np.float64(mAP),
+                        topk=np.asarray(topk, np.float64), single=np.asarray(single, np.float64))
+    print(f"[eval_camsets] centroids={ncent} mAP={mAP:.6f} valid={len(single)}")
+
+
+if __name__ == "__main__" and "camsets" in sys.argv[1:]:
+    gen_camsets()
