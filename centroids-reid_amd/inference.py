@@ -59,8 +59,9 @@ def calculate_centroids(embeddings, pid_path_index):
     emb = embeddings if isinstance(embeddings, torch.Tensor) else torch.from_numpy(np.asarray(embeddings, np.float32))
     emb = emb.float().cuda().contiguous()
     out = torch.empty((len(keys), emb.shape[1]), dtype=torch.float32, device=emb.device)
-    L.check(L.lib().creid_gather_mean_rows(L.ptr(emb), L.ptr(torch.as_tensor(order, device=emb.device)),
-                                           L.ptr(torch.as_tensor(offsets, device=emb.device)), len(keys), emb.shape[1],
+    order_t = torch.as_tensor(order, device=emb.device)        # named: must outlive the launch
+    off_t = torch.as_tensor(offsets, device=emb.device)
+    L.check(L.lib().creid_gather_mean_rows(L.ptr(emb), L.ptr(order_t), L.ptr(off_t), len(keys), emb.shape[1],
                                            L.ptr(out), L.stream()), "creid_gather_mean_rows")
     return out.cpu().numpy(), np.array(keys, dtype=np.str_)
 
