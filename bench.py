@@ -135,7 +135,8 @@ def run_eval(args, rank, world):
             "l2norm_GBs": (nq + ng) * D * 8 / (t_norm * 1e-3) / 1e9,
             "rank_rows_GBs": rank_bytes / (t_rank * 1e-3) / 1e9,
             "peak_GBs": HBM_PEAK_GBS}
-        res["cpu_baseline"] = cpu_baseline_eval(feats, pids, cams, nq, ng)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_eval(feats, pids, cams, nq, ng)
         res["mAP"] = mAP
     return {
         "metric": "eval_dist_pairs_per_sec", "value": pairs / dt, "unit": "pairs/s",
@@ -201,6 +202,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=["train", "eval"], default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the CPU leg (profiling runs; the default run always reports it)")
     args = ap.parse_args()
     rank, world = ddp_setup(args.gpus)
     workload = args.workload
@@ -214,7 +217,8 @@ def main():
         from centroids_reid_amd import bench_train
         args.steps = args.steps or 30
         args.warmup = args.warmup if args.warmup is not None else 5
-        out = bench_train.run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_train)
+        out = bench_train.run(args, rank, world, barrier_sync, time_kernel,
+                              None if args.no_cpu_baseline else cpu_baseline_train)
     else:
         args.steps = args.steps or 5
         args.warmup = args.warmup if args.warmup is not None else 2

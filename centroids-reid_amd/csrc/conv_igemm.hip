@@ -256,10 +256,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IGemmGeom g, const u
 // staging VGPRs, no ds_write pass, ~16 address VALU per k-tile.  The LDS image is linear (8 rows x 128 B per
 // wave-instruction); the conflict-free XOR swizzle is applied on the SOURCE side (lane holding LDS chunk c'
 // of row r fetches global chunk c' ^ ((r>>1)&7)) and again on the fragment reads.  Out-of-image taps and
-// rows >= M fetch from a page of zeros.  Two LDS buffers: the DMA of k-tile t+1 flies while tile t is
-// multiplied; one barrier per k-tile.
-template <int BN>
-__global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
+// rows >= M fetch from a page of zeros.  NS-stage LDS ring: the DMAs of k-tiles t+1 .. t+NS-2 fly while tile t
+// is multiplied; `s_waitcnt vmcnt(n)` with n = the DMA instructions of the younger tiles still in flight; one
+// bare s_barrier per k-tile.  Measured (r01, profiles/r01_igemm_stage_sweep.md): NS = 2 wins on every ResNet50
+// layer -- the loop is not DMA-latency bound, and 3+ stages cost a workgroup per CU.
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BN, int NS>
+__global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) void igemm_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
                                                                  const unsigned short* __restrict__ wgt,
                                                                  unsigned short* __restrict__ out,
                                                                  const unsigned short* __restrict__ add_src,
@@ -268,7 +272,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IGemmGeom g, con
   constexpr int BK = 64, TNW = BN / 64, NBI = BN / 32;          // NBI = B-tile DMA instructions per wave
   constexpr int CP = BN + 8;
   constexpr int TILE_A = 128 * BK, TILE_B = BN * BK, STAGE = TILE_A + TILE_B;
-  constexpr int LDS_ELEMS = (2 * STAGE) > (128 * CP) ? (2 * STAGE) : (128 * CP);
+  constexpr int LDS_ELEMS = (NS * STAGE) > (128 * CP) ? (NS * STAGE) : (128 * CP);
+  constexpr int LPT = 4 + NBI;                                   // DMA instructions per wave per k-tile
+  static_assert((NS - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) unsigned short smem[LDS_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -338,12 +344,23 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IGemmGeom g, con
 
   const int nk = g.K / BK;
   const int l31 = lane & 31, kh = lane >> 5;
-  issue(0, 0);
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p)
+    if (p < nk) issue(p, p);
+  int buf = 0;                                                 // t % NS
   for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces of tile t have landed
-    __syncthreads();                                           // ... everyone's have; buffer (t+1)&1 is free again
-    if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
-    const unsigned short* As = smem + (t & 1) * STAGE;
+    // this wave's DMA pieces of tile t have landed once at most the younger tiles' instructions are pending
+    const int younger = min(nk - 1 - t, NS - 2);
+    if constexpr (NS >= 5) { if (younger == 3) wait_vm<3 * LPT>(); }
+    if constexpr (NS >= 4) { if (younger == 2) wait_vm<2 * LPT>(); }
+    if constexpr (NS >= 3) { if (younger == 1) wait_vm<1 * LPT>(); }
+    if (younger == 0) wait_vm<0>();
+    // bare s_barrier: __syncthreads() carries a release fence that drains vmcnt to 0, i.e. the whole ring.
+    // LDS-DMA data is visible once vmcnt has counted it; this wave's ds_reads of tile t-1 were consumed by MFMAs.
+    asm volatile("s_barrier" ::: "memory");                    // everyone's pieces landed; buffer (t-1)%NS is free
+    if (t + NS - 1 < nk) issue(t + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+    const unsigned short* As = smem + buf * STAGE;
+    buf = (buf + 1 == NS) ? 0 : buf + 1;
     const unsigned short* Bs = As + TILE_A;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -617,14 +634,23 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
   if (dtype == CREID_BF16 && use_dma && g.log2span >= 6) {
     if (g.K % 64 != 0) return CREID_E_SHAPE;
-    if (bn == 128)
-      hipLaunchKernelGGL(igemm_bf16_dma_kernel<128>, grid, block, 0, s, g, (const unsigned short*)src,
-                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n,
-                         bnred);
-    else
-      hipLaunchKernelGGL(igemm_bf16_dma_kernel<64>, grid, block, 0, s, g, (const unsigned short*)src,
-                         (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n,
-                         bnred);
+    // LDS ring depth (CREID_IGEMM_STAGES = 2..5, default 2 -- measured r01: deeper rings LOSE, the k-loop is bound
+    // by the LDS->MFMA chain and by workgroups/CU, not by DMA latency; 3+ stages cost occupancy)
+    static const int stages = [] { const char* e = getenv("CREID_IGEMM_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 5) ? v : 2; }();
+#define CREID_DMA_LAUNCH(BN_, NS_)                                                                                     \
+  hipLaunchKernelGGL((igemm_bf16_dma_kernel<BN_, NS_>), grid, block, 0, s, g, (const unsigned short*)src,              \
+                     (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n, \
+                     bnred)
+    if (bn == 128) {
+      switch (stages) { case 2: CREID_DMA_LAUNCH(128, 2); break; case 3: CREID_DMA_LAUNCH(128, 3); break;
+                        case 4: case 5: CREID_DMA_LAUNCH(128, 4); break;   // 5 x 32 KB would not fit
+                        default: CREID_DMA_LAUNCH(128, 2); break; }
+    } else {
+      switch (stages) { case 2: CREID_DMA_LAUNCH(64, 2); break; case 3: CREID_DMA_LAUNCH(64, 3); break;
+                        case 4: CREID_DMA_LAUNCH(64, 4); break; case 5: CREID_DMA_LAUNCH(64, 5); break;
+                        default: CREID_DMA_LAUNCH(64, 2); break; }
+    }
+#undef CREID_DMA_LAUNCH
   } else if (bnred.x) {
     return CREID_E_DTYPE;          // the fused reduction exists only in the bf16 LDS-DMA kernel
   } else if (dtype == CREID_BF16) {

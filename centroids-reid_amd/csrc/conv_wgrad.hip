@@ -169,8 +169,11 @@ __device__ __forceinline__ void tr_load2(unsigned addr, s16x4& lo, s16x4& hi) {
                : "=&v"(lo), "=&v"(hi) : "v"(addr), "i"(OFF_LO), "i"(OFF_HI) : "memory");
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
+template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NS-stage LDS ring (see igemm_bf16_dma_kernel: with two stages the loop runs at global->LDS latency).
+template <int TM, int TN, int NS>
+__global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
                                                                  const unsigned short* __restrict__ x, int NCO,
                                                                  float* __restrict__ ws, int tiles_k, int m_per_split) {
   constexpr int IM = TM / 64, JN = TN / 64;
@@ -178,7 +181,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(IGemmGeom g, con
   constexpr int RPI_A = 64 / LPR_A, RPI_B = 64 / LPR_B;        // rows per wave-instruction
   constexpr int NIA = WKS / (4 * RPI_A), NIB = WKS / (4 * RPI_B);   // DMA instructions per wave per tile
   constexpr int TILE_A = WKS * TM, TILE_B = WKS * TN, STAGE = TILE_A + TILE_B;
-  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * STAGE];
+  constexpr int LPT = NIA + NIB;
+  static_assert((NS - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile = blockIdx.x, split = blockIdx.y;
@@ -258,13 +263,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(IGemmGeom g, con
     fb[j] = lds0 + 2u * (unsigned)(TILE_A + t_row * TN + (((col >> 5) ^ keyB) << 5) + (col & 31));
   }
 
-  issue(m_begin, 0);
-  int it = 0;
-  for (int mb = m_begin; mb < m_end; mb += WKS, ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (mb + WKS < m_end) issue(mb + WKS, (it + 1) & 1);
-    const unsigned sb = (unsigned)((it & 1) * STAGE * 2);
+  const int nt = (m_end - m_begin + WKS - 1) / WKS;
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p)
+    if (p < nt) issue(m_begin + p * WKS, p);
+  int buf = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int younger = min(nt - 1 - t, NS - 2);
+    if constexpr (NS >= 5) { if (younger == 3) wg_wait_vm<3 * LPT>(); }
+    if constexpr (NS >= 4) { if (younger == 2) wg_wait_vm<2 * LPT>(); }
+    if constexpr (NS >= 3) { if (younger == 1) wg_wait_vm<1 * LPT>(); }
+    if (younger == 0) wg_wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");       // bare barrier: a fence would drain the whole ring (vmcnt 0)
+    if (t + NS - 1 < nt) issue(m_begin + (t + NS - 1) * WKS, buf == 0 ? NS - 1 : buf - 1);
+    const unsigned sb = (unsigned)(buf * STAGE * 2);
+    buf = (buf + 1 == NS) ? 0 : buf + 1;
 #define WG_KK(KK)                                                                                        \
     {                                                                                                    \
       s16x4 al[2], ah[2], bl[2], bh[2];                                                                  \
@@ -392,33 +405,64 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(IGemmGeom g, const float
 
 // sum over splits and scatter [NCO][K = (tap, within)] -> OIHW fp32 gradient (accumulating).
 // r = tap / kw_taps; s = tap % kw_taps + within / cpitch; c = within % cpitch.
-// Workgroup = 32 consecutive elements x 8 split lanes (coalesced 128-B reads per split, fixed-order LDS
-// combine -> deterministic), so tiny weight tensors with hundreds of pixel-splits still reduce in parallel.
+// Workgroup = (256/SL) float4 element groups x SL split lanes: every thread streams its 16-byte column slice
+// through the splits it owns (4 loads in flight), the SL partial sums meet in LDS in a FIXED order
+// (deterministic), and lane 0 of each group writes the four results.  The host picks SL from the split count
+// so that the per-thread loop stays <= ~8 deep whether a layer has 4 splits of a 2.4M-element tensor or 512
+// splits of a 4096-element one.
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int NCO, int K,
                                                            int log2span, int kw_taps, int cpitch, int cin, int kh,
                                                            int kw, float* __restrict__ dw_oihw, int accumulate) {
-  __shared__ float red[8][32];
-  const int64_t total = (int64_t)NCO * K;
-  const int span_mask = (1 << log2span) - 1;
-  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  for (int64_t base = (int64_t)blockIdx.x * 32; base < total; base += (int64_t)gridDim.x * 32) {
-    const int64_t i = base + el;
-    float acc = 0.f;
-    if (i < total)
-      for (int sp = sl; sp < splits; sp += 8) acc += ws[(int64_t)sp * total + i];
-    red[sl][el] = acc;
-    __syncthreads();
-    if (sl == 0 && i < total) {
-      acc = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
-      const int co = (int)(i / K), kc = (int)(i - (int64_t)co * K);
-      const int tap = kc >> log2span, within = kc & span_mask;
-      const int r = tap / kw_taps, s = tap % kw_taps + within / cpitch, c = within % cpitch;
-      if (r < kh && s < kw && c < cin) {
-        float* dst = dw_oihw + (((int64_t)co * cin + c) * kh + r) * kw + s;
-        *dst = accumulate ? *dst + acc : acc;
-      }
+  constexpr int EG = 256 / SL;
+  __shared__ float4 red[SL > 1 ? SL : 1][EG];
+  const int64_t total = (int64_t)NCO * K, total4 = total >> 2;      // K % 64 == 0
+  const int eg = threadIdx.x % EG, sl = threadIdx.x / EG;
+  const int64_t i4 = (int64_t)blockIdx.x * EG + eg;
+  const bool live = i4 < total4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float4* p = reinterpret_cast<const float4*>(ws) + i4;
+    int sp = sl;
+    for (; sp + 3 * SL < splits; sp += 4 * SL) {
+      const float4 a = p[(int64_t)sp * total4], b = p[(int64_t)(sp + SL) * total4];
+      const float4 c = p[(int64_t)(sp + 2 * SL) * total4], d = p[(int64_t)(sp + 3 * SL) * total4];
+      acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+      acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
     }
+    for (; sp < splits; sp += SL) {
+      const float4 a = p[(int64_t)sp * total4];
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+  }
+  if constexpr (SL > 1) {
+    red[sl][eg] = acc;
     __syncthreads();
+    if (sl != 0) return;
+#pragma unroll
+    for (int q = 1; q < SL; ++q) { const float4 v = red[q][eg]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+  }
+  if (!live) return;
+  const int64_t i = i4 << 2;
+  if (kh == 1 && kw == 1 && cpitch == cin && (1 << log2span) == cin &&
+      (reinterpret_cast<uintptr_t>(dw_oihw) & 15) == 0) {                  // 1x1: OIHW == [co][c], same index
+    float4* dst = reinterpret_cast<float4*>(dw_oihw + i);
+    if (accumulate) { const float4 o = *dst; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    *dst = acc;
+    return;
+  }
+  const int span_mask = (1 << log2span) - 1;
+  const int co = (int)(i / K), kc0 = (int)(i - (int64_t)co * K);
+  const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int kc = kc0 + e;
+    const int tap = kc >> log2span, within = kc & span_mask;
+    const int r = tap / kw_taps, s = tap % kw_taps + within / cpitch, c = within % cpitch;
+    if (r < kh && s < kw && c < cin) {
+      float* dst = dw_oihw + (((int64_t)co * cin + c) * kh + r) * kw + s;
+      *dst = accumulate ? *dst + v[e] : v[e];
+    }
   }
 }
 
@@ -460,9 +504,18 @@ static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
                            int dtype, hipStream_t s) {
   dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(256);
   static const int use_dma = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
-  if (dtype == CREID_BF16 && use_dma && (1 << g.log2span) >= TN)
-    hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN>), grid, block, 0, s, g, (const unsigned short*)dy,
-                       (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+  static const int stages = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
+  if (dtype == CREID_BF16 && use_dma && (1 << g.log2span) >= TN) {
+    if (stages == 2)
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2>), grid, block, 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+    else if (stages == 3)
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 3>), grid, block, 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+    else
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 4>), grid, block, 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+  }
   else if (dtype == CREID_BF16)
     hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN>), grid, block, 0, s, g, (const unsigned short*)dy,
                        (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
@@ -481,10 +534,15 @@ static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO,
   else if (p.tm == 128 && p.tn == 64) launch_wgrad_t<128, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
   else if (p.tm == 64 && p.tn == 128) launch_wgrad_t<64, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
   else launch_wgrad_t<64, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
-  int64_t blocks = ((int64_t)NCO * g.K + 31) / 32;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, p.splits, NCO,
-                     g.K, g.log2span, kw_taps, cpitch, cin, kh, kw, dw, accumulate);
+  const int64_t total4 = (int64_t)NCO * g.K / 4;
+#define CREID_WRED(SL_)                                                                                              \
+  hipLaunchKernelGGL(wgrad_reduce_kernel<SL_>, dim3((unsigned)((total4 + 256 / SL_ - 1) / (256 / SL_))), dim3(256), 0, s, \
+                     (const float*)ws, p.splits, NCO, g.K, g.log2span, kw_taps, cpitch, cin, kh, kw, dw, accumulate)
+  if (p.splits <= 8) CREID_WRED(1);
+  else if (p.splits <= 32) CREID_WRED(4);
+  else if (p.splits <= 128) CREID_WRED(16);
+  else CREID_WRED(64);
+#undef CREID_WRED
   return (int)hipGetLastError();
 }
 

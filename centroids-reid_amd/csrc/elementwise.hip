@@ -251,7 +251,7 @@ __global__ __launch_bounds__(1024) void bn2d_bwd_finalize_kernel(const float* __
   __syncthreads();
   if (rg == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
-#pragma unroll
+#pragma unroll 8
     for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
     // dx = k1*(dy - a1 - xhat*a2) = A*dy + B*x + Cc  with per-channel A, B, Cc
     const float invM = (float)(1.0 / count);

@@ -15,8 +15,7 @@ from . import _lib as L
 
 def flatten_(params, device):
     """Re-home `params` (list of nn.Parameter) as views of one flat fp32 buffer; returns (flat, gflat)."""
-    n = sum(p.numel() for p in params)
-    n_pad = (n + 3) // 4 * 4
+    n_pad = sum((p.numel() + 3) // 4 * 4 for p in params)     # every tensor starts 16-byte aligned
     flat = torch.zeros(n_pad, dtype=torch.float32, device=device)
     gflat = torch.zeros(n_pad, dtype=torch.float32, device=device)
     off = 0
@@ -26,7 +25,7 @@ def flatten_(params, device):
         flat[off_al:off_al + k].copy_(p.data.reshape(-1))
         p.data = flat[off_al:off_al + k].view(p.shape)
         p.grad = gflat[off_al:off_al + k].view(p.shape)
-        off += k
+        off += (k + 3) // 4 * 4
     return flat, gflat
 
 
