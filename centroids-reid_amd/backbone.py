@@ -10,8 +10,10 @@ wgrad); torch only provides memory, the stream and the autograd hook at the modu
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
+import os
 
 import torch
 from torch import nn
@@ -224,8 +226,12 @@ class BackboneEngine:
                 self.blocks.append(u)
         self.weights_dirty = True
         self._ws = None
+        # weight gradients are off the critical path of backward: run them on a second HIP stream (a parallel
+        # branch of the captured graph) so they fill the CUs the latency-bound dgrad / BN chain leaves idle
+        self.wgrad_stream = os.environ.get("CREID_WGRAD_STREAM", "1") == "1"
+        self._side = None
+        self._keep = []
         self.saved = None
-        import os
         self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
         self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
@@ -240,8 +246,23 @@ class BackboneEngine:
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
+            self._keep.append(self._ws)          # a launch on the side stream may still be reading the old one
             self._ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def _fork_side(self, *tensors):
+        """Side-stream context for work that depends on everything enqueued so far on the current stream; the
+        tensors it reads are kept alive until _join_side()."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        self._keep.extend(tensors)
+        return torch.cuda.stream(self._side)
+
+    def _join_side(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._keep.clear()
 
     def all_units(self):
         yield self.stem
@@ -431,9 +452,16 @@ class BackboneEngine:
         return dx, gm
 
     def _wgrad(self, u, a_in, dy, B, H, W):
-        lib, st = L.lib(), L.stream()
         if not u.conv.weight.requires_grad:
             return
+        if self.wgrad_stream:
+            with self._fork_side(a_in, dy):
+                self._wgrad_launch(u, a_in, dy, B, H, W)
+        else:
+            self._wgrad_launch(u, a_in, dy, B, H, W)
+
+    def _wgrad_launch(self, u, a_in, dy, B, H, W):
+        lib, st = L.lib(), L.stream()
         d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         nbytes = lib.creid_conv2d_wgrad_workspace_bytes(C.byref(d), self.dt)
         ws = self._workspace(nbytes)
@@ -504,10 +532,13 @@ class BackboneEngine:
         L.check(lib.creid_maxpool3x3s2_bwd(L.ptr(g), L.ptr(idx0), B, H1, W1, 64, self.dt, L.ptr(dy0), st), "maxpool_bwd")
         dx0, _ = self._bn_bwd(self.stem, x0, dy0, y0 if self.net.stem_relu else None, mean0, invstd0, B * H1 * W1)
         if self.stem.conv.weight.requires_grad:
-            nbytes = lib.creid_stem_conv_wgrad_workspace_bytes(B, H, W, self.dt)
-            ws = self._workspace(nbytes)
-            L.check(lib.creid_stem_conv_wgrad(B, H, W, L.ptr(xpad), L.ptr(dx0), L.ptr(self._grad_of(self.stem.conv.weight)),
-                                              1, L.ptr(ws), nbytes, self.dt, st), "stem_conv_wgrad")
+            with (self._fork_side(xpad, dx0) if self.wgrad_stream else contextlib.nullcontext()):
+                nbytes = lib.creid_stem_conv_wgrad_workspace_bytes(B, H, W, self.dt)
+                ws = self._workspace(nbytes)
+                L.check(lib.creid_stem_conv_wgrad(B, H, W, L.ptr(xpad), L.ptr(dx0),
+                                                  L.ptr(self._grad_of(self.stem.conv.weight)), 1, L.ptr(ws), nbytes,
+                                                  self.dt, L.stream()), "stem_conv_wgrad")
+        self._join_side()
         self.saved = None
 
 

@@ -32,17 +32,17 @@ static inline void igemm_finish_geom(IGemmGeom& g) {
 }
 
 // Source pixel of output row (oy, ox) under tap (r, s); returns false when it falls outside.
+// stride is 1 or 2 (check_desc / the stem), so the lattice test and the division are a mask and a shift --
+// a runtime `%` and `/` here expand to ~60 VALU instructions per row on the k-loop path of every conv kernel.
 __device__ __forceinline__ bool igemm_src_pixel(const IGemmGeom& g, int oy, int ox, int r, int s, int& iy, int& ix) {
+  const int sh = g.stride - 1;                       // log2(stride); for stride 2 also the parity mask
   if (!g.transposed) {
-    iy = oy * g.stride + r - g.pad;
-    ix = ox * g.stride + s - g.pad;
+    iy = (oy << sh) + r - g.pad;
+    ix = (ox << sh) + s - g.pad;
   } else {
     const int ty = oy + g.pad - r, tx = ox + g.pad - s;
-    if (g.stride == 1) { iy = ty; ix = tx; }
-    else {
-      if (ty < 0 || tx < 0 || (ty % g.stride) != 0 || (tx % g.stride) != 0) return false;
-      iy = ty / g.stride; ix = tx / g.stride;
-    }
+    if (((ty | tx) & sh) != 0) return false;         // not on the stride lattice
+    iy = ty >> sh; ix = tx >> sh;                    // arithmetic shift: negatives stay negative, rejected below
   }
   if (!g.check_bounds) return true;
   return (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;

@@ -306,10 +306,11 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   }
   const unsigned short* aptr[4];
   int amul[4];
-  int cur_tap = -1;
+  int cur_tap = -1, cur_r = 0, cur_s = -1;                     // taps are visited in order: (r, s) advance incrementally
   const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_zero_page);
-  auto set_tap = [&](int tap) {
-    const int r = tap / g.kw, s = tap - r * g.kw;
+  auto set_tap = [&]() {
+    if (++cur_s == g.kw) { cur_s = 0; ++cur_r; }
+    const int r = cur_r, s = cur_s;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int iy, ix;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   typedef void __attribute__((address_space(3)))* lptr_t;
   auto issue = [&](int t, int buf) {
     const int tap = (t * BK) >> g.log2span;
-    if (tap != cur_tap) { set_tap(tap); cur_tap = tap; }
+    if (tap != cur_tap) { set_tap(); cur_tap = tap; }
     const int c = (t * BK) & span_mask;
     unsigned short* la = smem + buf * STAGE + wave * 512;      // + i * 2048 elements (4 KiB) per instruction
     unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
@@ -362,27 +363,33 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     const unsigned short* As = smem + buf * STAGE;
     buf = (buf + 1 == NS) ? 0 : buf + 1;
     const unsigned short* Bs = As + TILE_A;
+    // All fragment reads of the k-tile are issued before the first MFMA (the compiler then waits with
+    // decreasing lgkmcnt): with a read->wait->MFMA chain per 16-wide k slice the LDS latency was exposed four
+    // times per k-tile and a wave kept its MFMA pipe ~16% busy.
+    s16x8 a[4][2], b[4][TNW];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int ch = 2 * kk + kh;
-      s16x8 a[2], b[TNW];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = wm * 64 + i * 32 + l31;
-        a[i] = *reinterpret_cast<const s16x8*>(&As[r * BK + ((ch ^ ((r >> 1) & 7)) << 3)]);
+        a[kk][i] = *reinterpret_cast<const s16x8*>(&As[r * BK + ((ch ^ ((r >> 1) & 7)) << 3)]);
       }
 #pragma unroll
       for (int j = 0; j < TNW; ++j) {
         const int c = wn * (BN / 2) + j * 32 + l31;
-        b[j] = *reinterpret_cast<const s16x8*>(&Bs[c * BK + ((ch ^ ((c >> 1) & 7)) << 3)]);
+        b[kk][j] = *reinterpret_cast<const s16x8*>(&Bs[c * BK + ((ch ^ ((c >> 1) & 7)) << 3)]);
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < TNW; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
-                                                              __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kk][i]),
+                                                              __builtin_bit_cast(bf16x8, b[kk][j]), acc[i][j], 0, 0, 0);
   }
   __syncthreads();
 
@@ -484,6 +491,266 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     }
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, cl = i - which * BN;
+      bn_part[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ bf16, warp-specialised
+// Measured on MI355X (r01, tools/probes/lds_fill_bw_probe.hip + loop ablations): in igemm_bf16_dma_kernel a
+// k-tile costs ~0.5 us of DMA *issue* time (each global_load_lds_dwordx4 holds the issuing wave for 60-180
+// cycles) plus ~0.4 us of ds_read + MFMA time, and because the same four waves do both, the two mostly add up.
+// Here a 512-thread workgroup splits the roles: waves 0-3 (consumers, 2x2 over the 128 x BN tile) only read
+// fragments and issue MFMAs; waves 4-7 (producers) only compute gather addresses and issue the LDS-DMA pieces
+// into an NS-deep LDS ring.  One s_barrier per k-tile couples them:
+//   barrier B_t  <=  producers: their pieces of tile t have landed (vmcnt);  consumers: done reading tile t-1
+//   after B_t    :   producers issue tile t+NS-1 into slot (t-1)%NS, consumers multiply tile t.
+// Tiling, swizzle, zero page and the epilogue maths are those of igemm_bf16_dma_kernel (512 threads copy out).
+template <int BN, int NS>
+__global__ __launch_bounds__(512, 1) void igemm_bf16_ws_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
+                                                                const unsigned short* __restrict__ wgt,
+                                                                unsigned short* __restrict__ out,
+                                                                const unsigned short* __restrict__ add_src,
+                                                                float* __restrict__ bn_part, int tiles_n,
+                                                                BnRedArgs bnred) {
+  constexpr int NT = 512;
+  constexpr int BK = 64, TNW = BN / 64, NBI = BN / 32;
+  constexpr int CP = BN + 8;
+  constexpr int TILE_A = 128 * BK, TILE_B = BN * BK, STAGE = TILE_A + TILE_B;
+  constexpr int CPR = BN / 8, NRG = NT / CPR;
+  constexpr int RED_ELEMS = NRG * 2 * BN * 2;                    // fp32 reduction scratch, in 2-byte units
+  constexpr int LDS0 = (NS * STAGE) > (128 * CP) ? (NS * STAGE) : (128 * CP);
+  constexpr int LDS_ELEMS = LDS0 > RED_ELEMS ? LDS0 : RED_ELEMS;
+  constexpr int LPT = 4 + NBI;
+  static_assert(NS >= 3 && (NS - 2) * LPT <= 63, "ring depth");
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[LDS_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int cw = wave & 3;                                       // role-local wave index
+  const int wm = cw >> 1, wn = cw & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int row0 = tile_m * 128, col0 = tile_n * BN;
+  const int nk = g.K / BK;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[2][TNW];
+  if (producer) {
+    const int span_mask = (1 << g.log2span) - 1;
+    const int lr8 = lane >> 3, lcp = lane & 7;
+    int oy[4], ox[4], bpix[4], gch[4];
+    bool vm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (i * 4 + cw) * 8 + lr8, m = row0 + r;
+      vm[i] = m < g.M;
+      const int mm = vm[i] ? m : 0;
+      int b, rem;
+      fast_divmod(mm, g.OH * g.OW, g.inv_ohow, b, rem);
+      fast_divmod(rem, g.OW, g.inv_ow, oy[i], ox[i]);
+      bpix[i] = b * g.SH * g.SW;
+      gch[i] = (lcp ^ ((r >> 1) & 7)) << 3;
+    }
+    const unsigned short* wp[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+      const int r = (i * 4 + cw) * 8 + lr8;
+      wp[i] = wgt + (int64_t)(col0 + r) * g.K + ((lcp ^ ((r >> 1) & 7)) << 3);
+    }
+    const unsigned short* aptr[4];
+    int amul[4];
+    int cur_tap = -1, cur_r = 0, cur_s = -1;
+    const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_zero_page);
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+    auto issue = [&](int t, int buf) {
+      const int tap = (t * BK) >> g.log2span;
+      if (tap != cur_tap) {
+        cur_tap = tap;
+        if (++cur_s == g.kw) { cur_s = 0; ++cur_r; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int iy, ix;
+          const bool ok = vm[i] && igemm_src_pixel(g, oy[i], ox[i], cur_r, cur_s, iy, ix);
+          aptr[i] = ok ? src + (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + gch[i] : zpage;
+          amul[i] = ok ? 1 : 0;
+        }
+      }
+      const int c = (t * BK) & span_mask;
+      unsigned short* la = smem + buf * STAGE + cw * 512;
+      unsigned short* lb = smem + buf * STAGE + TILE_A + cw * 512;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + c * amul[i]), (lptr_t)(la + i * 2048), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NBI; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wp[i] + t * BK), (lptr_t)(lb + i * 2048), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+      if (p < nk) issue(p, p);
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+      const int younger = min(nk - 1 - t, NS - 2);
+      if constexpr (NS >= 5) { if (younger == 3) wait_vm<3 * LPT>(); }
+      if constexpr (NS >= 4) { if (younger == 2) wait_vm<2 * LPT>(); }
+      if (younger == 1) wait_vm<1 * LPT>();
+      if (younger == 0) wait_vm<0>();
+      asm volatile("s_barrier" ::: "memory");                    // B_t
+      if (t + NS - 1 < nk) issue(t + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+      buf = (buf + 1 == NS) ? 0 : buf + 1;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+      asm volatile("s_barrier" ::: "memory");                    // B_t: tile t is in LDS
+      const unsigned short* As = smem + buf * STAGE;
+      const unsigned short* Bs = As + TILE_A;
+      buf = (buf + 1 == NS) ? 0 : buf + 1;
+      // fragment reads run one 16-wide k slice ahead of the MFMAs (register double buffer): the LDS latency of
+      // slice kk+1 hides behind the MFMAs of slice kk instead of being exposed four times per k-tile
+      s16x8 a[2][2], b[2][TNW];
+      auto load_frags = [&](int kk, int sl) {
+        const int ch = 2 * kk + kh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = wm * 64 + i * 32 + l31;
+          a[sl][i] = *reinterpret_cast<const s16x8*>(&As[r * BK + ((ch ^ ((r >> 1) & 7)) << 3)]);
+        }
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          const int c = wn * (BN / 2) + j * 32 + l31;
+          b[sl][j] = *reinterpret_cast<const s16x8*>(&Bs[c * BK + ((ch ^ ((c >> 1) & 7)) << 3)]);
+        }
+      };
+      auto mma = [&](int sl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TNW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[sl][i]),
+                                                                __builtin_bit_cast(bf16x8, b[sl][j]), acc[i][j], 0, 0, 0);
+      };
+      load_frags(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(1, 1); mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(2, 0); mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(3, 1); mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: consumers stage the C tile (bf16) in LDS, all 512 threads copy it out
+  float s1v[TNW], s2v[TNW];
+  if (!producer) {
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int cl = wn * (BN / 2) + j * 32 + l31;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const float v = acc[i][j][r];
+          s1 += v; s2 = fmaf(v, v, s2);
+          smem[rl * CP + cl] = f32_to_bf16_bits(v);
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      s1v[j] = s1; s2v[j] = s2;
+    }
+  }
+  __syncthreads();
+  const unsigned short* bx = reinterpret_cast<const unsigned short*>(bnred.x);
+  const unsigned short* bact = reinterpret_cast<const unsigned short*>(bnred.act);
+  float rs1[8], rs2[8], rmu[8], ris[8];
+  if (bx) {
+    const int c0 = col0 + (tid % CPR) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(bnred.mean + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(bnred.invstd + c0 + k);
+      rmu[k] = a.x; rmu[k + 1] = a.y; rmu[k + 2] = a.z; rmu[k + 3] = a.w;
+      ris[k] = b.x; ris[k + 1] = b.y; ris[k + 2] = b.z; ris[k + 3] = b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { rs1[k] = 0.f; rs2[k] = 0.f; }
+  }
+#pragma unroll
+  for (int i = 0; i < (128 * CPR) / NT; ++i) {
+    const int id = tid + NT * i, rl = id / CPR, ch = id - rl * CPR;
+    const int rr = row0 + rl;
+    if (rr < g.M) {
+      uint4 v = *reinterpret_cast<const uint4*>(&smem[rl * CP + ch * 8]);
+      const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
+      if (add_src) {
+        const uint4 a = *reinterpret_cast<const uint4*>(add_src + off);
+        unsigned* vw = &v.x; const unsigned* aw = &a.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+          const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+          vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(out + off) = v;
+      if (bx) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(bx + off);
+        uint4 av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
+        const unsigned* vw = &v.x; const unsigned* xw = &xv.x; const unsigned* aw = &av.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float g0 = __uint_as_float(vw[q] << 16), g1 = __uint_as_float(vw[q] & 0xffff0000u);
+          const float a0 = __uint_as_float(aw[q] << 16), a1 = __uint_as_float(aw[q] & 0xffff0000u);
+          const float x0 = __uint_as_float(xw[q] << 16), x1 = __uint_as_float(xw[q] & 0xffff0000u);
+          g0 = a0 > 0.f ? g0 : 0.f; g1 = a1 > 0.f ? g1 : 0.f;
+          rs1[2 * q] += g0; rs1[2 * q + 1] += g1;
+          rs2[2 * q] = fmaf(g0, (x0 - rmu[2 * q]) * ris[2 * q], rs2[2 * q]);
+          rs2[2 * q + 1] = fmaf(g1, (x1 - rmu[2 * q + 1]) * ris[2 * q + 1], rs2[2 * q + 1]);
+        }
+      }
+    }
+  }
+  if (bx) {
+    __syncthreads();
+    float* red2 = reinterpret_cast<float*>(smem);                // [NRG][2][BN]
+    const int rg = tid / CPR, cb = (tid % CPR) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red2[(rg * 2 + 0) * BN + cb + k] = rs1[k]; red2[(rg * 2 + 1) * BN + cb + k] = rs2[k]; }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += NT) {
+      const int which = i / BN, cl = i - which * BN;
+      float a = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < NRG; ++q) a += red2[(q * 2 + which) * BN + cl];
+      bnred.partial[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = a;
+    }
+  }
+  if (bn_part) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (!producer) {
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) {
+        const int cl = wn * (BN / 2) + j * 32 + l31;
+        if (kh == 0) { red[(wm * 2 + 0) * BN + cl] = s1v[j]; red[(wm * 2 + 1) * BN + cl] = s2v[j]; }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += NT) {
       const int which = i / BN, cl = i - which * BN;
       bn_part[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl];
     }
@@ -634,6 +901,23 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
   if (dtype == CREID_BF16 && use_dma && g.log2span >= 6) {
     if (g.K % 64 != 0) return CREID_E_SHAPE;
+    // CREID_IGEMM_WS=1: warp-specialised kernel (512 threads, producer / consumer waves), ring depth
+    // CREID_IGEMM_WS_STAGES (3 or 4)
+    static const int use_ws = [] { const char* e = getenv("CREID_IGEMM_WS"); return e ? atoi(e) : 1; }();
+    static const int ws_stages = [] { const char* e = getenv("CREID_IGEMM_WS_STAGES"); int v = e ? atoi(e) : 0; return v == 4 ? 4 : 3; }();
+    // measured per layer (profiles/r01_igemm_ws_sweep.md): the split wins 8-17% on the long-k 64-wide tiles
+    // (3x3 convs, K >= 1152) and loses wherever its 72-96 KB ring costs a resident workgroup (all 128-wide tiles)
+    if (use_ws == 2 || (use_ws == 1 && bn == 64 && g.K >= 1024)) {
+      const dim3 block_ws(512);
+#define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
+  hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid, block_ws, 0, s, g, (const unsigned short*)src,           \
+                     (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n, \
+                     bnred)
+      if (bn == 128) { if (ws_stages == 4) CREID_WS_LAUNCH(128, 4); else CREID_WS_LAUNCH(128, 3); }
+      else { if (ws_stages == 4) CREID_WS_LAUNCH(64, 4); else CREID_WS_LAUNCH(64, 3); }
+#undef CREID_WS_LAUNCH
+      return (int)hipGetLastError();
+    }
     // LDS ring depth (CREID_IGEMM_STAGES = 2..5, default 2 -- measured r01: deeper rings LOSE, the k-loop is bound
     // by the LDS->MFMA chain and by workgroups/CU, not by DMA latency; 3+ stages cost occupancy)
     static const int stages = [] { const char* e = getenv("CREID_IGEMM_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 5) ? v : 2; }();
