@@ -382,23 +382,40 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------ global average pool
+// 32 channel vectors x 8 row lanes per workgroup; grid (C/V/32, B): HW/8 dependent loads per thread and
+// B*C/(32V) workgroups instead of HW loads and B workgroups; lane partials meet in LDS in a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ out) {
   constexpr int V = Vec16<T>::N;
-  const int b = blockIdx.y, cc = blockIdx.x * 256 + threadIdx.x;
-  if (cc * V >= C) return;
+  __shared__ float red[8][32][V + 1];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int b = blockIdx.y, cc = blockIdx.x * 32 + cl;
+  const bool live = cc * V < C;
   float acc[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) acc[k] = 0.f;
-  const T* p = x + (int64_t)b * HW * C + cc * V;
-  for (int i = 0; i < HW; ++i) {
-    float v[V];
-    Vec16<T>::load(p + (int64_t)i * C, v);
+  if (live) {
+    const T* p = x + (int64_t)b * HW * C + cc * V;
+    for (int i = rl; i < HW; i += 8) {
+      float v[V];
+      Vec16<T>::load(p + (int64_t)i * C, v);
 #pragma unroll
-    for (int k = 0; k < V; ++k) acc[k] += v[k];
+      for (int k = 0; k < V; ++k) acc[k] += v[k];
+    }
   }
 #pragma unroll
-  for (int k = 0; k < V; ++k) out[(int64_t)b * C + cc * V + k] = acc[k] / (float)HW;
+  for (int k = 0; k < V; ++k) red[rl][cl][k] = acc[k];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * V; e += 256) {
+    const int c2 = e / V, k = e - c2 * V;
+    const int ch = (blockIdx.x * 32 + c2) * V + k;
+    if (ch < C) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a += red[q][c2][k];
+      out[(int64_t)b * C + ch] = a / (float)HW;
+    }
+  }
 }
 
 template <typename T>
@@ -629,9 +646,9 @@ int creid_gap_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, fl
   CREID_CHECK_ARG(x && feat && B > 0 && HW > 0 && C % 8 == 0);
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((unsigned)((C / 4 + 255) / 256), (unsigned)B), dim3(256), 0, s,
+             hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), (unsigned)B), dim3(256), 0, s,
                                 (const float*)x, (int)HW, (int)C, feat),
-             hipLaunchKernelGGL(gap_fwd_kernel<unsigned short>, dim3((unsigned)((C / 8 + 255) / 256), (unsigned)B),
+             hipLaunchKernelGGL(gap_fwd_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), (unsigned)B),
                                 dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, feat));
   CREID_LAUNCH_RET();
 }

@@ -54,10 +54,12 @@ __global__ __launch_bounds__(256) void loo_centroids_bwd_kernel(const float* __r
 }
 
 // ======================================================================================
-// C1-C3: triplet.  One workgroup per anchor: distances to all N rows (wave per row, 16-B
-// loads, wave reduction), then hardest-positive / hardest-negative mining by wave 0.
+// C1-C3: triplet.  One 1024-thread workgroup per anchor: distances to all N rows (wave per row, 16-B
+// loads, wave reduction; 16 waves because N is only 32..128 and the kernel is pure latency), then
+// hardest-positive / hardest-negative mining by wave 0.
 // ======================================================================================
-__global__ __launch_bounds__(256) void triplet_mine_kernel(const float* __restrict__ x,
+constexpr int TM_T = 1024, TM_W = TM_T / 64;
+__global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restrict__ x,
                                                            const int64_t* __restrict__ labels, int N, int D,
                                                            float* __restrict__ dist_ap, float* __restrict__ dist_an,
                                                            int32_t* __restrict__ p_idx, int32_t* __restrict__ n_idx,
@@ -68,11 +70,11 @@ __global__ __launch_bounds__(256) void triplet_mine_kernel(const float* __restri
   const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xap = x + (int64_t)a * D;
   float saa = 0.f;
-  for (int d = tid; d < D; d += 256) { float v = xap[d]; xa[d] = v; }
+  for (int d = tid; d < D; d += TM_T) { float v = xap[d]; xa[d] = v; }
   __syncthreads();
   for (int d = lane; d < D; d += 64) saa = fmaf(xa[d], xa[d], saa);
   saa = wave_sum(saa);
-  for (int j = wave; j < N; j += 4) {
+  for (int j = wave; j < N; j += TM_W) {
     const float* xj = x + (int64_t)j * D;
     float dot = 0.f, sjj = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void triplet_mine_kernel(const float* __restri
   }
   __syncthreads();
   if (dist_row_out)
-    for (int j = tid; j < N; j += 256) dist_row_out[(int64_t)a * N + j] = drow[j];
+    for (int j = tid; j < N; j += TM_T) dist_row_out[(int64_t)a * N + j] = drow[j];
   if (wave == 0) {
     const int64_t la = labels[a];
     float bp = -INFINITY, bn = INFINITY;
@@ -336,32 +338,53 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict_
 // ======================================================================================
 // A4: BNNeck = BatchNorm1d over [B, D] (B small): thread per feature, loop over rows (coalesced).
 // ======================================================================================
+// 32 channels x 8 row lanes per workgroup (the [B, D] problem is tiny: D/32 workgroups instead of D/256, B/8
+// dependent steps per thread instead of B); row-lane partials meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int B, int D,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        float* __restrict__ rmean, float* __restrict__ rvar,
                                                        int training, float momentum, float eps,
                                                        float* __restrict__ y, float* __restrict__ save_mean,
                                                        float* __restrict__ save_invstd) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  float mean, invstd;
+  __shared__ float red[8][32];
+  __shared__ float s_mean[32], s_inv[32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + cl;
+  const bool live = d < D;
   if (training) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += x[(int64_t)b * D + d];
-    mean = s / (float)B;
+    if (live) for (int b = rl; b < B; b += 8) s += x[(int64_t)b * D + d];
+    red[rl][cl] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mean += red[q][cl];
+    mean /= (float)B;
+    __syncthreads();
     float m2 = 0.f;
-    for (int b = 0; b < B; ++b) { const float t = x[(int64_t)b * D + d] - mean; m2 = fmaf(t, t, m2); }
-    const float var = m2 / (float)B;
-    invstd = 1.0f / sqrtf(var + eps);
-    if (rmean) rmean[d] = (1.f - momentum) * rmean[d] + momentum * mean;
-    if (rvar) rvar[d] = (1.f - momentum) * rvar[d] + momentum * (B > 1 ? m2 / (float)(B - 1) : var);
-    if (save_mean) { save_mean[d] = mean; save_invstd[d] = invstd; }
-  } else {
-    mean = rmean[d];
-    invstd = 1.0f / sqrtf(rvar[d] + eps);
+    if (live) for (int b = rl; b < B; b += 8) { const float t = x[(int64_t)b * D + d] - mean; m2 = fmaf(t, t, m2); }
+    red[rl][cl] = m2;
+    __syncthreads();
+    if (rl == 0 && live) {
+      m2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) m2 += red[q][cl];
+      const float var = m2 / (float)B;
+      const float invstd = 1.0f / sqrtf(var + eps);
+      if (rmean) rmean[d] = (1.f - momentum) * rmean[d] + momentum * mean;
+      if (rvar) rvar[d] = (1.f - momentum) * rvar[d] + momentum * (B > 1 ? m2 / (float)(B - 1) : var);
+      if (save_mean) { save_mean[d] = mean; save_invstd[d] = invstd; }
+      s_mean[cl] = mean; s_inv[cl] = invstd;
+    }
+  } else if (rl == 0 && live) {
+    s_mean[cl] = rmean[d];
+    s_inv[cl] = 1.0f / sqrtf(rvar[d] + eps);
   }
+  __syncthreads();
+  if (!live) return;
+  const float mean = s_mean[cl], invstd = s_inv[cl];
   const float g = w ? w[d] : 1.f, be = bias ? bias[d] : 0.f;
-  for (int b = 0; b < B; ++b) y[(int64_t)b * D + d] = (x[(int64_t)b * D + d] - mean) * invstd * g + be;
+  for (int b = rl; b < B; b += 8) y[(int64_t)b * D + d] = (x[(int64_t)b * D + d] - mean) * invstd * g + be;
 }
 
 __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -370,18 +393,29 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ save_invstd,
                                                        float* __restrict__ dx, float* __restrict__ dw,
                                                        float* __restrict__ dbias) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  const float mean = save_mean[d], invstd = save_invstd[d], g = w ? w[d] : 1.f;
+  __shared__ float red[8][2][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + cl;
+  const bool live = d < D;
+  const float mean = live ? save_mean[d] : 0.f, invstd = live ? save_invstd[d] : 0.f, g = (live && w) ? w[d] : 1.f;
   float sdy = 0.f, sdyx = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float t = dy[(int64_t)b * D + d];
-    sdy += t; sdyx = fmaf(t, (x[(int64_t)b * D + d] - mean) * invstd, sdyx);
+  if (live)
+    for (int b = rl; b < B; b += 8) {
+      const float t = dy[(int64_t)b * D + d];
+      sdy += t; sdyx = fmaf(t, (x[(int64_t)b * D + d] - mean) * invstd, sdyx);
+    }
+  red[rl][0][cl] = sdy; red[rl][1][cl] = sdyx;
+  __syncthreads();
+  sdy = 0.f; sdyx = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { sdy += red[q][0][cl]; sdyx += red[q][1][cl]; }
+  if (!live) return;
+  if (rl == 0) {
+    if (dw) dw[d] += sdyx;
+    if (dbias) dbias[d] += sdy;
   }
-  if (dw) dw[d] += sdyx;
-  if (dbias) dbias[d] += sdy;
   const float k = g * invstd / (float)B;
-  for (int b = 0; b < B; ++b) {
+  for (int b = rl; b < B; b += 8) {
     const float xh = (x[(int64_t)b * D + d] - mean) * invstd;
     dx[(int64_t)b * D + d] += k * ((float)B * dy[(int64_t)b * D + d] - sdy - xh * sdyx);
   }
@@ -511,7 +545,7 @@ int creid_triplet_fwd(const float* x, const int64_t* labels, const uint8_t* anch
   const size_t smem = (size_t)(D + N) * sizeof(float);
   if (smem > 64 * 1024) return CREID_E_SHAPE;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(triplet_mine_kernel, dim3((unsigned)N), dim3(256), smem, s, x, labels, (int)N, (int)D, dist_ap,
+  hipLaunchKernelGGL(triplet_mine_kernel, dim3((unsigned)N), dim3(TM_T), smem, s, x, labels, (int)N, (int)D, dist_ap,
                      dist_an, p_idx, n_idx, dist_mat);
   hipLaunchKernelGGL(triplet_loss_kernel, dim3(1), dim3(256), 0, s, dist_ap, dist_an, anchor_mask, (int)N, margin,
                      out4, coef);
@@ -561,7 +595,7 @@ int creid_bn1d_fwd(const float* x, int64_t B, int64_t D, const float* weight, co
                    float* save_invstd, void* stream) {
   CREID_CHECK_ARG(x && y && B > 0 && D > 0);
   CREID_CHECK_ARG(training || (running_mean && running_var));
-  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, as_stream(stream), x, (int)B,
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)((D + 31) / 32)), dim3(256), 0, as_stream(stream), x, (int)B,
                      (int)D, weight, bias, running_mean, running_var, training, momentum, eps, y, save_mean,
                      save_invstd);
   CREID_LAUNCH_RET();
@@ -571,7 +605,7 @@ int creid_bn1d_bwd(const float* x, const float* dy, int64_t B, int64_t D, const 
                    const float* save_invstd, float* dx_accum, float* dweight_accum, float* dbias_accum,
                    void* stream) {
   CREID_CHECK_ARG(x && dy && save_mean && save_invstd && dx_accum && B > 0 && D > 0);
-  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, as_stream(stream), x, dy,
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((D + 31) / 32)), dim3(256), 0, as_stream(stream), x, dy,
                      (int)B, (int)D, weight, save_mean, save_invstd, dx_accum, dweight_accum, dbias_accum);
   CREID_LAUNCH_RET();
 }

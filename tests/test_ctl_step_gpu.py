@@ -106,3 +106,48 @@ def test_full_model_fp32_vs_oracle():
     close(model.backbone.base.layer2[0].conv2.weight.grad, params["layer2.0.conv2.weight"].grad)
     close(model.backbone.base.conv1.weight.grad, params["conv1.weight"].grad)
     close(model.backbone.base.layer1[0].bn1.weight.grad, params["layer1.0.bn1.weight"].grad)
+
+
+def test_fused_heads_match_autograd_path():
+    """All-real batch: the hand-scheduled head pass (train_ctl_model._forward_backward_fused) against the
+    autograd path of the same model -- same losses, same gradients (fp32 backbone, identical kernels)."""
+    from oracle import backbone_oracle as bo
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    P, K, C, H, W = 4, 4, 20, 64, 32
+    sd = bo.make_state_dict("resnet50", 1, seed=78)
+    x = bo.synthetic_images(P * K, H, W, seed=4).cuda()
+    labels = torch.from_numpy(np.repeat(np.arange(P) * 3 % C, K).astype(np.int64)).cuda()
+    batch = (x, labels, torch.zeros(P * K, dtype=torch.int64), torch.ones(P * K, dtype=torch.bool))
+    res = []
+    for fused in (True, False):
+        cfg = _cfg(2048, K, 0.5)
+        cfg.SOLVER.QUERY_CONTRASTIVE_WEIGHT = 0.7      # non-default weights: every gscale must be honoured
+        cfg.SOLVER.CENTROID_CONTRASTIVE_WEIGHT = 1.3
+        model = CTLModel(cfg, num_classes=C, num_query=0, compute_dtype=torch.float32)
+        model.backbone.base.load_state_dict(sd)
+        rng = np.random.default_rng(6)
+        with torch.no_grad():
+            model.center_loss.centers.copy_(torch.from_numpy(rng.standard_normal((C, 2048)).astype(np.float32)) * 0.3)
+            model.fc_query.weight.copy_(torch.from_numpy((rng.standard_normal((C, 2048)) * 0.01).astype(np.float32)))
+        model = model.cuda().train()
+        model.configure_optimizers()
+        model.fused_heads = fused
+        out = model.forward_backward(batch, 0)
+        g = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        res.append((out, {k: float(v[-1]) for k, v in model.losses_dict.items()}, g,
+                    model.bn.running_mean.detach().cpu().clone(), int(model.bn.num_batches_tracked)))
+    (o1, l1, g1, rm1, nb1), (o0, l0, g0, rm0, nb0) = res
+    assert abs(float(o1["loss"]) - float(o0["loss"])) < 1e-5
+    for n in l0:
+        assert abs(l1[n] - l0[n]) < 1e-5, n
+    for n in ("step_dist_ap", "step_dist_an", "l2_mean_centroid"):
+        assert abs(float(o1["other"][n]) - float(o0["other"][n])) < 1e-4, n
+    assert nb1 == nb0 == 1
+    np.testing.assert_allclose(rm1.numpy(), rm0.numpy(), rtol=0, atol=1e-6)
+    assert set(g1) == set(g0)
+    for n in g0:
+        den = float(g0[n].norm())
+        err = float((g1[n] - g0[n]).norm())
+        # classifier GEMMs use split-K atomics: last-bit differences, nothing more.  Analytically-zero
+        # gradients (a BN bias feeding another train-mode BN) hold ~1e-5 of rounding noise in both runs.
+        assert err < 2e-4 * den + 5e-5, (n, err, den)
