@@ -38,6 +38,11 @@ __device__ __forceinline__ void tr_wait8(s16x4& a, s16x4& b, s16x4& c, s16x4& d,
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)::"memory");
 }
 
+template <int NW>
+__device__ __forceinline__ void tr_wait8_n(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(NW) : "memory");
+}
+
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
                                                          const unsigned short* __restrict__ x, int NCO,
@@ -213,6 +218,19 @@ __global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) v
   }
   typedef const void __attribute__((address_space(1)))* gptr_t;
   typedef void __attribute__((address_space(3)))* lptr_t;
+  // Pixel coordinates of this lane's B rows.  A k-step advances every row by WKS = 64 pixels: when 64 is a
+  // multiple of OW (all ResNet shapes) that is "ox unchanged, oy += 64/OW, carry into the image index", a
+  // handful of integer ops instead of two reciprocal divmods per DMA instruction per k-step.
+  const bool inc_ok = (WKS % g.OW) == 0 && (WKS / g.OW) <= g.OH && g.check_bounds != 2;
+  const int dy_rows = inc_ok ? WKS / g.OW : 0;
+  int pb[NIB], poy[NIB], pox[NIB];
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int m = min(m_begin + brow[i], g.M - 1);
+    int rem;
+    fast_divmod(m, g.OH * g.OW, g.inv_ohow, pb[i], rem);
+    fast_divmod(rem, g.OW, g.inv_ow, poy[i], pox[i]);
+  }
   auto issue = [&](int mb, int buf) {
     unsigned short* la = smem + buf * STAGE + wave * 512;
     unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
@@ -226,10 +244,18 @@ __global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) v
     for (int i = 0; i < NIB; ++i) {
       const int m = mb + brow[i];
       const unsigned short* p = zpage;
-      if (m < m_end) {
-        int b, rem, oy, ox, iy, ix;
-        fast_divmod(m, g.OH * g.OW, g.inv_ohow, b, rem);
+      int b, oy, ox;
+      if (inc_ok) {
+        b = pb[i]; oy = poy[i]; ox = pox[i];
+        poy[i] += dy_rows;
+        if (poy[i] >= g.OH) { poy[i] -= g.OH; ++pb[i]; }
+      } else {
+        int rem;
+        fast_divmod(min(m, g.M - 1), g.OH * g.OW, g.inv_ohow, b, rem);
         fast_divmod(rem, g.OW, g.inv_ow, oy, ox);
+      }
+      if (m < m_end) {
+        int iy, ix;
         if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))
           p = x + (int64_t)((b * g.SH + iy) * g.SW + ix) * g.pitch + cc + bcol[i];
       }
@@ -278,25 +304,34 @@ __global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) v
     if (t + NS - 1 < nt) issue(m_begin + (t + NS - 1) * WKS, buf == 0 ? NS - 1 : buf - 1);
     const unsigned sb = (unsigned)(buf * STAGE * 2);
     buf = (buf + 1 == NS) ? 0 : buf + 1;
-#define WG_KK(KK)                                                                                        \
+    // fragment reads run one 16-pixel slice ahead of the MFMAs (two register sets): `s_waitcnt lgkmcnt(8)`
+    // retires the older slice's eight transposing reads while the younger slice's eight stay in flight
+    s16x4 al[2][2], ah[2][2], bl[2][2], bh[2][2];
+#define WG_LOAD(KK, S)                                                                                   \
+    tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[0] + sb, al[S][0], ah[S][0]);              \
+    tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[IM - 1] + sb, al[S][1], ah[S][1]);         \
+    tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[0] + sb, bl[S][0], bh[S][0]);              \
+    tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[JN - 1] + sb, bl[S][1], bh[S][1]);
+#define WG_MMA(S, NWAIT)                                                                                 \
     {                                                                                                    \
-      s16x4 al[2], ah[2], bl[2], bh[2];                                                                  \
-      tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[0] + sb, al[0], ah[0]);                  \
-      tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[IM - 1] + sb, al[1], ah[1]);             \
-      tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[0] + sb, bl[0], bh[0]);                  \
-      tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[JN - 1] + sb, bl[1], bh[1]);             \
-      tr_wait8(al[0], ah[0], al[1], ah[1], bl[0], bh[0], bl[1], bh[1]);                                  \
+      tr_wait8_n<NWAIT>(al[S][0], ah[S][0], al[S][1], ah[S][1], bl[S][0], bh[S][0], bl[S][1], bh[S][1]); \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
       s16x8 a[IM], b[JN];                                                                                \
-      _Pragma("unroll") for (int i = 0; i < IM; ++i) a[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7); \
-      _Pragma("unroll") for (int j = 0; j < JN; ++j) b[j] = __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7); \
+      _Pragma("unroll") for (int i = 0; i < IM; ++i) a[i] = __builtin_shufflevector(al[S][i], ah[S][i], 0, 1, 2, 3, 4, 5, 6, 7); \
+      _Pragma("unroll") for (int j = 0; j < JN; ++j) b[j] = __builtin_shufflevector(bl[S][j], bh[S][j], 0, 1, 2, 3, 4, 5, 6, 7); \
       _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                     \
         _Pragma("unroll") for (int j = 0; j < JN; ++j)                                                   \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),          \
                                                               __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
     }
-    WG_KK(0) WG_KK(1) WG_KK(2) WG_KK(3)
-#undef WG_KK
+    WG_LOAD(0, 0)
+    WG_LOAD(1, 1) WG_MMA(0, 8)
+    WG_LOAD(2, 0) WG_MMA(1, 8)
+    WG_LOAD(3, 1) WG_MMA(0, 8)
+    WG_MMA(1, 0)
+#undef WG_LOAD
+#undef WG_MMA
   }
   const int l31 = lane & 31, kh = lane >> 5;
   float* wsp = ws + (int64_t)split * NCO * g.K;
@@ -564,6 +599,7 @@ int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void*
   g.SH = (int)d->in_h; g.SW = (int)d->in_w; g.pitch = (int)d->in_c; g.log2span = ilog2x(d->in_c);
   g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 0;
   g.K = (int)(d->kh * d->kw * d->in_c); g.N = (int)d->out_c; g.check_bounds = 1;
+  { static const int noinc = [] { const char* e = getenv("CREID_WGRAD_NOINC"); return e ? atoi(e) : 0; }(); if (noinc) g.check_bounds = 2; }
   igemm_finish_geom(g);
   return run_wgrad(g, dy, x, (int)d->out_c, dw_oihw, d->kw, (int)d->in_c, (int)d->in_c, d->kh, d->kw, accumulate, ws,
                    ws_bytes, dtype, as_stream(stream));
