@@ -38,8 +38,14 @@ def ddp_setup(n_gpus):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("CREID_DIST_BACKEND", "nccl")      # "gloo" + CREID_SINGLE_DEVICE=1: control-flow
+        if os.environ.get("CREID_SINGLE_DEVICE", "0") == "1":        # test of the N>1 path on a one-GPU box
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
@@ -142,7 +148,7 @@ def run_eval(args, rank, world):
         t_rank = time_kernel(lambda: rm.rank_rows(d), 5)
         idx = rm.rank_rows(d)
         t_norm = time_kernel(lambda: rm.l2_normalize(feats, return_sqnorm=True), 10)
-        t_cmc = time_kernel(lambda: rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50), 10, graph=False)  # H2D of the id vectors
+        t_cmc = time_kernel(lambda: rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50), 10)
         flops = 2.0 * nq * ng * D
         res["roofline"] = {"kernel": "sqdist_f32_kernel", "bound": "mfma", "achieved": flops / (t_dist * 1e-3) / 1e12,
                            "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s",

@@ -8,6 +8,7 @@
 // Stability makes ties resolve by gallery index.  The row (n x 16 B of scratch) stays
 // L2-resident; HBM traffic is the 4 B/pair read of the matrix and the 8 B/pair index write.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 constexpr int RT = 1024;          // threads per workgroup
@@ -23,7 +24,8 @@ __device__ __forceinline__ unsigned orderable(float d) {
 
 __global__ __launch_bounds__(RT) void rank_rows_kernel(const float* __restrict__ dist, int64_t m, int64_t n,
                                                        int64_t ld, int64_t* __restrict__ out_idx,
-                                                       unsigned* __restrict__ ws) {
+                                                       unsigned* __restrict__ ws,
+                                                       const uint8_t* __restrict__ only_flagged) {
   __shared__ unsigned hist[RW][256];   // per-wave digit counts, then per-wave scatter offsets
   __shared__ unsigned total[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(RT) void rank_rows_kernel(const float* __restrict__
   const unsigned long long lt = lanemask_lt();
 
   for (int64_t row = blockIdx.x; row < m; row += gridDim.x) {
+    if (only_flagged && !only_flagged[row]) continue;     // (uniform) rows the LDS bucket kernel already ranked
     const float* drow = dist + row * ld;
     int64_t* orow = out_idx + row * n;
 #pragma unroll 1
@@ -106,6 +109,153 @@ __global__ __launch_bounds__(RT) void rank_rows_kernel(const float* __restrict__
       __syncthreads();  // all scatters visible (same CU, L1 write-through to L2 + block barrier)
       __threadfence_block();
     }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// rank_rows for rows that fit in LDS (n <= ~22k: Market-1501 / DukeMTMC galleries): ONE pass over the row
+// instead of four global radix passes.  The row's keys are mapped MONOTONICALLY onto 4096 buckets between the
+// row's min and max key (bucket order == key order across buckets), counted, scattered into LDS grouped by
+// bucket (order inside a bucket arbitrary), and every element then finds its rank inside its bucket by counting
+// the members that precede it in (key, index) order -- a total order, so the result is exactly the stable
+// argsort.  Buckets hold ~n/4096 elements (x5 at the mode of a bell-shaped row; members are compared four at a
+// time with 16-byte LDS reads); a row whose largest bucket exceeds RL_MAX_BUCKET (pathological ties)
+// is flagged and left to rank_rows_kernel.  HBM/L2 traffic: the 4 B/pair read (x3, L2-hot) and the 8 B/pair
+// index write, nothing else.
+// ----------------------------------------------------------------------------------------
+constexpr int RL_NB = 4096, RL_MAX_BUCKET = 512, RL_KPT = 21;     // RL_KPT x 1024 threads >= n
+
+__device__ __forceinline__ unsigned rl_bucket(unsigned k, unsigned kmin, float inv) {
+  const unsigned b = (unsigned)((float)(k - kmin) * inv);       // float ops are monotone: bucket(k) non-decreasing in k
+  return b < (unsigned)RL_NB ? b : (unsigned)(RL_NB - 1);
+}
+
+__global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restrict__ dist, int64_t m, int n, int64_t ld,
+                                                           int64_t* __restrict__ out_idx,
+                                                           uint8_t* __restrict__ fallback) {
+  extern __shared__ __attribute__((aligned(16))) unsigned rl_smem[];
+  const int n4 = (n + 3) & ~3;
+  unsigned* keys2 = rl_smem;                                    // [n4] keys grouped by bucket
+  unsigned* off = keys2 + n4;                                   // [RL_NB + 1] bucket start offsets
+  unsigned* cnt = off + RL_NB + 4;                              // [RL_NB] counters / cursors (16-B aligned)
+  unsigned* red = cnt + RL_NB;                                  // [3 * RW] reduction scratch
+  unsigned short* idx2 = reinterpret_cast<unsigned short*>(red + 3 * RW);   // [n] gallery index of each slot
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int64_t row = blockIdx.x; row < m; row += gridDim.x) {
+    const float* drow = dist + row * ld;
+    // ---- A: the row's keys go into registers once (RL_KPT independent loads in flight per thread; the three
+    //         passes below would otherwise each pay ~n/1024 dependent L2 round trips), min / max key
+    unsigned kreg[RL_KPT];
+#pragma unroll
+    for (int j = 0; j < RL_KPT; ++j) {
+      const int i = tid + j * RT;
+      kreg[j] = i < n ? orderable(drow[i]) : 0u;
+    }
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int j = 0; j < RL_KPT; ++j)
+      if (tid + j * RT < n) { kmin = min(kmin, kreg[j]); kmax = max(kmax, kreg[j]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o, 64));
+      kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
+    }
+    if (lane == 0) { red[wave] = kmin; red[RW + wave] = kmax; }
+    for (int i = tid; i < RL_NB; i += RT) cnt[i] = 0;
+    __syncthreads();
+    kmin = red[0]; kmax = red[RW];
+#pragma unroll
+    for (int w = 1; w < RW; ++w) { kmin = min(kmin, red[w]); kmax = max(kmax, red[RW + w]); }
+    const float inv = (float)RL_NB / ((float)(kmax - kmin) + 1.0f);
+    // ---- B: bucket histogram
+#pragma unroll
+    for (int j = 0; j < RL_KPT; ++j)
+      if (tid + j * RT < n) atomicAdd(&cnt[rl_bucket(kreg[j], kmin, inv)], 1u);
+    __syncthreads();
+    // ---- exclusive scan of the 4096 counts (4 per thread), largest bucket
+    const uint4 c4 = *reinterpret_cast<const uint4*>(&cnt[4 * tid]);
+    const unsigned csum = (c4.x + c4.y) + (c4.z + c4.w);
+    unsigned incl = csum, big = max(max(c4.x, c4.y), max(c4.z, c4.w));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = (unsigned)__shfl_up((int)incl, o, 64); if (lane >= o) incl += v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o, 64));
+    __syncthreads();                                             // red[] reads above are done
+    if (lane == 63) red[wave] = incl;
+    if (lane == 0) red[2 * RW + wave] = big;
+    __syncthreads();
+    unsigned base = 0;
+    big = 0;
+#pragma unroll
+    for (int w = 0; w < RW; ++w) { if (w < wave) base += red[w]; big = max(big, red[2 * RW + w]); }
+    const unsigned ex = base + incl - csum;
+    off[4 * tid] = ex; off[4 * tid + 1] = ex + c4.x; off[4 * tid + 2] = ex + c4.x + c4.y;
+    off[4 * tid + 3] = ex + c4.x + c4.y + c4.z;
+    if (tid == RT - 1) off[RL_NB] = ex + csum;
+    *reinterpret_cast<uint4*>(&cnt[4 * tid]) = make_uint4(0u, 0u, 0u, 0u);     // becomes the scatter cursor
+    __syncthreads();
+    if (big > (unsigned)RL_MAX_BUCKET) {                         // uniform: leave the row to the radix kernel
+      if (tid == 0) fallback[row] = 1;
+      continue;
+    }
+    if (tid == 0) fallback[row] = 0;
+    // ---- C: scatter (key, index) into bucket-grouped LDS
+#pragma unroll
+    for (int j = 0; j < RL_KPT; ++j) {
+      const int i = tid + j * RT;
+      if (i < n) {
+        const unsigned k = kreg[j];
+        const unsigned b = rl_bucket(k, kmin, inv);
+        const unsigned p = off[b] + atomicAdd(&cnt[b], 1u);
+        keys2[p] = k; idx2[p] = (unsigned short)i;
+      }
+    }
+    __syncthreads();
+    // ---- D: rank inside the bucket by (key, index) -> final position (kept in registers) ...
+    unsigned fpos[RL_KPT], fid[RL_KPT];
+#pragma unroll
+    for (int j = 0; j < RL_KPT; ++j) {
+      const int p = tid + j * RT;
+      fpos[j] = 0; fid[j] = 0;
+      if (p < n) {
+        const unsigned k = keys2[p];
+        const unsigned id = idx2[p];
+        const unsigned b = rl_bucket(k, kmin, inv);
+        const unsigned lo = off[b], hi = off[b + 1];
+        unsigned r = 0;
+        for (unsigned q = lo & ~3u; q < hi; q += 4) {           // four members per step (16-B + 8-B LDS reads)
+          const uint4 kq = *reinterpret_cast<const uint4*>(&keys2[q]);
+          const uint2 iq = *reinterpret_cast<const uint2*>(&idx2[q]);
+          const unsigned i0 = iq.x & 0xffffu, i1 = iq.x >> 16, i2 = iq.y & 0xffffu, i3 = iq.y >> 16;
+          r += (q + 0 >= lo && q + 0 < hi && (kq.x < k || (kq.x == k && i0 < id))) ? 1u : 0u;
+          r += (q + 1 >= lo && q + 1 < hi && (kq.y < k || (kq.y == k && i1 < id))) ? 1u : 0u;
+          r += (q + 2 >= lo && q + 2 < hi && (kq.z < k || (kq.z == k && i2 < id))) ? 1u : 0u;
+          r += (q + 3 >= lo && q + 3 < hi && (kq.w < k || (kq.w == k && i3 < id))) ? 1u : 0u;
+        }
+        fpos[j] = lo + r; fid[j] = id;
+      }
+    }
+    __syncthreads();                                             // every read of keys2 / idx2 is done
+    // ---- ... the ranked indices are assembled in LDS (over keys2) and leave as full 16-byte stores: the
+    //      index matrix is 8 B per pair, the largest stream of the whole evaluation
+#pragma unroll
+    for (int j = 0; j < RL_KPT; ++j)
+      if (tid + j * RT < n) keys2[fpos[j]] = fid[j];
+    __syncthreads();
+    int64_t* orow = out_idx + row * (int64_t)n;
+    if ((reinterpret_cast<uintptr_t>(orow) & 15) == 0) {
+      const int pairs = n >> 1;
+      for (int i = tid; i < pairs; i += RT) {
+        const unsigned a = keys2[2 * i], b2 = keys2[2 * i + 1];
+        longlong2 v; v.x = (long long)a; v.y = (long long)b2;
+        *reinterpret_cast<longlong2*>(orow + 2 * i) = v;
+      }
+      if ((n & 1) && tid == 0) orow[n - 1] = (int64_t)keys2[n - 1];
+    } else {
+      for (int i = tid; i < n; i += RT) orow[i] = (int64_t)keys2[i];
+    }
+    __syncthreads();                                             // LDS is reused by the next row
   }
 }
 
@@ -184,6 +334,77 @@ __global__ __launch_bounds__(256) void cmc_ap_ranked_kernel(const int64_t* __res
   }
 }
 
+// Same scan, 16 waves per query and ONE pass over the gallery gathers: the (keep, match) ballots of every
+// 64-position group are parked in LDS (16 B per group), so the AP pass touches no global memory.  The kernel is
+// pure dependent-load latency (ranked index -> pid / camera gathers): 4x the waves = 4x fewer serial steps.
+template <bool CAMSETS>
+__global__ __launch_bounds__(1024) void cmc_ap_ranked_wide_kernel(const int64_t* __restrict__ idx, int64_t m, int64_t n,
+                                                                  const int64_t* __restrict__ q_pids,
+                                                                  const int64_t* __restrict__ g_pids,
+                                                                  const int64_t* __restrict__ q_cams,
+                                                                  const int64_t* __restrict__ g_cams,
+                                                                  uint8_t* __restrict__ out_valid,
+                                                                  double* __restrict__ out_ap,
+                                                                  int32_t* __restrict__ out_first) {
+  constexpr int CW = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned long long cm_masks[];    // [groups][2]
+  __shared__ int s_keep[CW], s_match[CW], s_first[CW];
+  __shared__ double s_ap[CW];
+  const int64_t qi = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t qp = q_pids[qi], qc = q_cams[qi];
+  const int64_t* row = idx + qi * n;
+  const int64_t groups = (n + 63) / 64;
+  const int64_t gseg = (groups + CW - 1) / CW;
+  const int64_t g0 = min((int64_t)wave * gseg, groups), g1 = min(g0 + gseg, groups);
+  const unsigned long long lt = lanemask_lt();
+  int nkeep = 0, nmatch = 0;
+  for (int64_t gidx = g0; gidx < g1; ++gidx) {
+    const int64_t k = gidx * 64 + lane;
+    bool keep = false, mk = false;
+    if (k < n) {
+      const int64_t gi = row[k];
+      const bool match = g_pids[gi] == qp;
+      keep = !(match && (CAMSETS ? (((unsigned long long)g_cams[gi] >> qc) & 1ull) != 0 : g_cams[gi] == qc));
+      mk = match && keep;
+    }
+    const unsigned long long km = __ballot(keep), mm = __ballot(mk);
+    if (lane == 0) { cm_masks[2 * gidx] = km; cm_masks[2 * gidx + 1] = mm; }
+    nkeep += __popcll(km); nmatch += __popcll(mm);
+  }
+  if (lane == 0) { s_keep[wave] = nkeep; s_match[wave] = nmatch; }
+  __syncthreads();
+  int bk = 0, bm = 0, tot_match = 0;
+#pragma unroll
+  for (int w = 0; w < CW; ++w) { if (w < wave) { bk += s_keep[w]; bm += s_match[w]; } tot_match += s_match[w]; }
+  double ap = 0.0;
+  int first = 0x7fffffff;
+  for (int64_t gidx = g0; gidx < g1; ++gidx) {
+    const unsigned long long km = cm_masks[2 * gidx], mm = cm_masks[2 * gidx + 1];
+    if ((mm >> lane) & 1ull) {
+      const int p = bk + __popcll(km & lt) + 1;        // 1-based kept position
+      const int c = bm + __popcll(mm & lt) + 1;        // matches up to and including this one
+      ap += (double)c / (double)p;
+      first = min(first, p - 1);
+    }
+    bk += __popcll(km); bm += __popcll(mm);
+  }
+  ap = wave_sum_d(ap);
+  first = wave_min_i(first);
+  if (lane == 0) { s_ap[wave] = ap; s_first[wave] = first; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0;
+    int f = 0x7fffffff;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) { a += s_ap[w]; f = min(f, s_first[w]); }
+    const bool valid = tot_match > 0;
+    out_valid[qi] = valid ? 1 : 0;
+    out_ap[qi] = valid ? a / (double)tot_match : 0.0;
+    out_first[qi] = valid ? f : -1;
+  }
+}
+
 // means over valid queries: single workgroup
 __global__ __launch_bounds__(256) void eval_reduce_kernel(const uint8_t* __restrict__ valid,
                                                           const double* __restrict__ ap,
@@ -230,10 +451,14 @@ __global__ __launch_bounds__(256) void eval_reduce_kernel(const uint8_t* __restr
 
 extern "C" {
 
-size_t creid_rank_rows_workspace_bytes(int64_t m, int64_t n) {
-  if (m <= 0 || n <= 0) return 0;
+static size_t rank_radix_ws_bytes(int64_t m, int64_t n) {
   const int64_t slots = m < MAX_SLOTS ? m : MAX_SLOTS;
   return (size_t)slots * (size_t)n * 4 * sizeof(unsigned);
+}
+
+size_t creid_rank_rows_workspace_bytes(int64_t m, int64_t n) {
+  if (m <= 0 || n <= 0) return 0;
+  return rank_radix_ws_bytes(m, n) + (((size_t)m + 255) & ~(size_t)255);     // + per-row fallback flags
 }
 
 int creid_rank_rows(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t* out_idx, void* ws,
@@ -244,8 +469,28 @@ int creid_rank_rows(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t
   if (n > 0xfffffff0LL) return CREID_E_SHAPE;
   if (ws_bytes < creid_rank_rows_workspace_bytes(m, n)) return CREID_E_WS;
   const int64_t slots = m < MAX_SLOTS ? m : MAX_SLOTS;
-  hipLaunchKernelGGL(rank_rows_kernel, dim3((unsigned)slots), dim3(RT), 0, as_stream(stream), dist, m, n, ld,
-                     out_idx, (unsigned*)ws);
+  hipStream_t s = as_stream(stream);
+  uint8_t* flags = reinterpret_cast<uint8_t*>(ws) + rank_radix_ws_bytes(m, n);
+  // rows that fit in LDS next to the bucket tables take the one-pass bucket kernel (CREID_RANK_LDS=0 disables)
+  static const int use_lds = [] { const char* e = getenv("CREID_RANK_LDS"); return e ? atoi(e) : 1; }();
+  const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+  const size_t lds_bytes = n4 * 4 + (size_t)(2 * RL_NB + 4 + 3 * RW) * 4 + n4 * 2;
+  const uint8_t* only_flagged = nullptr;
+  if (use_lds && n >= 512 && n <= (int64_t)RL_KPT * RT && lds_bytes <= 156 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(rank_rows_lds_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        return (int)hipGetLastError();
+      attr_set = true;
+    }
+    const int64_t wgs = m < 1024 ? m : 1024;
+    hipLaunchKernelGGL(rank_rows_lds_kernel, dim3((unsigned)wgs), dim3(RT), lds_bytes, s, dist, m, (int)n, ld, out_idx,
+                       flags);
+    only_flagged = flags;
+  }
+  hipLaunchKernelGGL(rank_rows_kernel, dim3((unsigned)slots), dim3(RT), 0, s, dist, m, n, ld, out_idx, (unsigned*)ws,
+                     only_flagged);
   CREID_LAUNCH_RET();
 }
 
@@ -256,8 +501,13 @@ int creid_cmc_ap_ranked(const int64_t* idx, int64_t m, int64_t n, const int64_t*
   if (m == 0) return 0;
   CREID_CHECK_ARG(idx && q_pids && g_pids && q_camids && g_camids && out_valid && out_ap && out_first);
   if (m > 0x7fffffffLL || n > 0x7fffff00LL) return CREID_E_SHAPE;
-  hipLaunchKernelGGL(cmc_ap_ranked_kernel<false>, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
-                     g_pids, q_camids, g_camids, out_valid, out_ap, out_first);
+  const size_t mask_bytes = (size_t)((n + 63) / 64) * 16;
+  if (mask_bytes <= 48 * 1024)
+    hipLaunchKernelGGL(cmc_ap_ranked_wide_kernel<false>, dim3((unsigned)m), dim3(1024), mask_bytes, as_stream(stream), idx,
+                       m, n, q_pids, g_pids, q_camids, g_camids, out_valid, out_ap, out_first);
+  else
+    hipLaunchKernelGGL(cmc_ap_ranked_kernel<false>, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
+                       g_pids, q_camids, g_camids, out_valid, out_ap, out_first);
   CREID_LAUNCH_RET();
 }
 
@@ -268,8 +518,13 @@ int creid_cmc_ap_ranked_camsets(const int64_t* idx, int64_t m, int64_t n, const 
   if (m == 0) return 0;
   CREID_CHECK_ARG(idx && q_pids && g_pids && q_camids && g_cam_masks && out_valid && out_ap && out_first);
   if (m > 0x7fffffffLL || n > 0x7fffff00LL) return CREID_E_SHAPE;
-  hipLaunchKernelGGL(cmc_ap_ranked_kernel<true>, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
-                     g_pids, q_camids, g_cam_masks, out_valid, out_ap, out_first);
+  const size_t mask_bytes = (size_t)((n + 63) / 64) * 16;
+  if (mask_bytes <= 48 * 1024)
+    hipLaunchKernelGGL(cmc_ap_ranked_wide_kernel<true>, dim3((unsigned)m), dim3(1024), mask_bytes, as_stream(stream), idx,
+                       m, n, q_pids, g_pids, q_camids, g_cam_masks, out_valid, out_ap, out_first);
+  else
+    hipLaunchKernelGGL(cmc_ap_ranked_kernel<true>, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
+                       g_pids, q_camids, g_cam_masks, out_valid, out_ap, out_first);
   CREID_LAUNCH_RET();
 }
 

@@ -80,6 +80,22 @@ def test_rank_rows_matches_stable_argsort(rm, m, n):
     np.testing.assert_array_equal(idx, np.argsort(d + 0.0, axis=1, kind="stable"))
 
 
+def test_rank_rows_lds_path_and_radix_fallback(rm):
+    """n in the LDS-bucket range: ordinary rows, rows with heavy exact ties, all-equal rows (largest bucket over
+    the limit -> flagged -> radix kernel), an outlier that stretches the key range, +-inf."""
+    rng = np.random.default_rng(77)
+    m, n = 37, 6000
+    d = (2.0 + 0.1 * rng.standard_normal((m, n))).astype(np.float32)       # unit-vector-like distances
+    d[1] = 1.25                                                            # all equal -> fallback
+    d[2, : n // 2] = 0.5                                                   # half the row tied -> fallback
+    d[3] = np.round(d[3], 2)                                               # many small tie groups -> LDS path
+    d[4, 17] = 1e-3; d[4, 18] = 3.9                                        # outliers stretch the bucket range
+    d[5, 5] = np.inf; d[5, 6] = -np.inf
+    d[6] = np.sort(d[6]); d[7] = np.sort(d[7])[::-1]
+    idx = rm.rank_rows(torch.from_numpy(d).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(idx, np.argsort(d + 0.0, axis=1, kind="stable"))
+
+
 def test_eval_func_integer_exact_vs_oracle(rm):
     """CMC/AP scan is integer work: fed the SAME ranked indices it must equal the oracle exactly."""
     from oracle import reid_oracle as ro
