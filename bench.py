@@ -100,6 +100,17 @@ def eval_inputs(nq, ng, D, rank, world):
     return feats, pids, cams
 
 
+def pmc_traffic(key):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE + WRITE_SIZE collected in separate counter-only runs); None if the file is absent."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            e = json.load(f)[key]
+        return (e["fetch_bytes"] + e["write_bytes"]) / e["launches"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def run_eval(args, rank, world):
     from centroids_reid_amd import reid_metric as rm
     nq, ng, D = 2228, 17661, 2048
@@ -152,8 +163,8 @@ def run_eval(args, rank, world):
         flops = 2.0 * nq * ng * D
         res["roofline"] = {"kernel": "sqdist_f32_kernel", "bound": "mfma", "achieved": flops / (t_dist * 1e-3) / 1e12,
                            "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": flops / (t_dist * 1e-3) / 1e12 / MFMA_F32_TFLOPS, "traffic": None,
-                           "ms": t_dist}
+                           "frac": flops / (t_dist * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
+                           "traffic": pmc_traffic("sqdist_f32_kernel"), "ms": t_dist}
         rank_bytes = nq * ng * (4 + 8)
         res["stages_ms"] = {"l2norm": t_norm, "sqdist": t_dist, "rank_rows": t_rank, "cmc_ap": t_cmc}
         res["roofline_hbm_stages"] = {

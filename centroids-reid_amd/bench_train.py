@@ -75,6 +75,19 @@ def igemm_roofline(B, H, W, time_kernel, reps=5):
     return tot_flop / (tot_ms * 1e-3) / 1e12, tot_ms, worst[:3], worst[-3:]
 
 
+def pmc_traffic(key):
+    """Average HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, collected in their own runs); None if absent."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            e = json.load(f)[key]
+        return (e["fetch_bytes"] + e["write_bytes"]) / e["launches"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
     P, K, H, W = 16, 4, 256, 128
     model = make_model()
@@ -158,10 +171,10 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
         tf_step = R50_FWD_BWD_GFLOP_PER_IMG * P * K / (ms * 1e-3) / 1e3
         res["step_mfma_frac"] = tf_step / MFMA_BF16_TFLOPS     # all conv FLOPs / whole-step time (incl. HBM-bound BN etc.)
         tf, ig_ms, slow, fast = igemm_roofline(P * K, H, W, time_kernel)
-        res["roofline"] = {"kernel": "igemm_bf16_kernel (conv fwd + dgrad, 105 launches/step, real layer mix)",
+        res["roofline"] = {"kernel": "igemm_bf16_{dma,ws}_kernel (conv fwd + dgrad, 104 launches/step, real layer mix)",
                            "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": tf / MFMA_BF16_TFLOPS, "traffic": None, "ms_per_step": ig_ms,
-                           "slowest_TFs": slow, "fastest_TFs": fast}
+                           "frac": tf / MFMA_BF16_TFLOPS, "traffic": pmc_traffic("igemm_family"),
+                           "ms_per_step": ig_ms, "slowest_TFs": slow, "fastest_TFs": fast}
         if cpu_baseline_fn is not None:
             res["cpu_baseline"] = cpu_baseline_fn(P, K, H, W)
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
