@@ -165,6 +165,16 @@ def run_eval(args, rank, world):
                            "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                            "frac": flops / (t_dist * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
                            "traffic": pmc_traffic("sqdist_f32_kernel"), "ms": t_dist}
+        # BASELINE configs[4] asks for fp16 vs fp32: the same distance stage on f16-rounded embeddings (MFMA f16,
+        # fp32 accumulate) and what the rounding does to the ranking metric
+        fn16 = fn.half()
+        t_dist16 = time_kernel(lambda: rm.get_euclidean(fn16[:nq], fn16[nq:]), 10)
+        idx16 = rm.rank_rows(rm.get_euclidean(fn16[:nq], fn16[nq:]))
+        _, map16, _, _, _, _, _ = rm.eval_func_device(idx16, q_pids, g_pids, q_cams, g_cams, 50)
+        _, map32, _, _, _, _, _ = rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50)
+        res["f16_vs_f32"] = {"sqdist_f16_ms": t_dist16, "sqdist_f16_TFLOPs": flops / (t_dist16 * 1e-3) / 1e12,
+                             "sqdist_f32_ms": t_dist, "mAP_f16_minus_f32": float(map16.item() - map32.item()),
+                             "rank_index_agreement": float((idx16 == idx).float().mean().item())}
         rank_bytes = nq * ng * (4 + 8)
         res["stages_ms"] = {"l2norm": t_norm, "sqdist": t_dist, "rank_rows": t_rank, "cmc_ap": t_cmc}
         res["roofline_hbm_stages"] = {

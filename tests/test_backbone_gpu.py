@@ -323,3 +323,31 @@ def test_dgrad_fused_bn_reduction(case):
     np.testing.assert_allclose(got[1].cpu().numpy(), s2.cpu().numpy(), rtol=1e-4, atol=2e-2)
     dx2, part2 = ly.conv2d_dgrad_bnred(gy, crsk, (H, W), stride, pad, bn_x, None, mean, invstd)    # no mask, no add
     np.testing.assert_allclose(part2.sum(0)[0].cpu().numpy(), dx2.float().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("arch,H,W,B", [("resnet50", 96, 80, 3), ("resnet50_ibn_a", 160, 96, 2)])
+def test_non_power_of_two_feature_maps_vs_oracle(arch, H, W, B):
+    """Spatial sizes whose feature maps are not powers of two (24x20 / 40x24 after the stem: the incremental
+    pixel stepping of the wgrad gather must fall back, tiles straddle image rows, M % 128 != 0) -- the
+    Street2Shop config of BASELINE.json runs at 320x320.  fp32 engine vs the CPU oracle, forward and backward."""
+    from oracle import backbone_oracle as bo
+    torch.set_num_threads(32)
+    net, eng, sd = _build(arch, torch.float32, seed=4321)
+    x = bo.synthetic_images(B, H, W, seed=11)
+    _, feat = eng.forward(x.cuda(), training=True)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+    sd2 = {**{k: v.clone() for k, v in sd.items()}, **params}
+    _, feat_o = bo.backbone_forward(x, sd2, arch, 1, training=True)
+    np.testing.assert_allclose(feat.cpu().numpy(), feat_o.detach().numpy(), rtol=0, atol=1e-4)
+    coef = torch.from_numpy(np.random.default_rng(5).standard_normal((B, 2048)).astype(np.float32))
+    eng.backward(coef.cuda())
+    (feat_o * coef).sum().backward()
+
+    def close(name, rel=3e-2):
+        a = dict(net.named_parameters())[name].grad.detach().cpu().double().numpy().ravel()
+        ref = params[name].grad.double().numpy().ravel()
+        assert np.linalg.norm(a - ref) <= rel * np.linalg.norm(ref), (name, np.linalg.norm(a - ref) / np.linalg.norm(ref))
+    for n in ("layer4.2.conv3.weight", "layer3.0.conv2.weight", "layer2.0.downsample.0.weight", "layer1.0.conv1.weight",
+              "conv1.weight", "layer4.0.bn2.weight"):
+        close(n)
