@@ -68,6 +68,7 @@ struct BnRedArgs {
   const float* mean;
   const float* invstd;
   float* partial;
+  int prefetch;          // fetch x / act before the C tile is staged (A/B knob CREID_BNRED_PREFETCH, default 1)
 };
 
 // XCD-aware bijective remap of the linear workgroup id (consecutive ids land on different XCDs;

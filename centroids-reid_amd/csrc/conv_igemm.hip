@@ -394,6 +394,26 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   __syncthreads();
 
   // ---- epilogue (identical to igemm_bf16_kernel)
+  // fused BN-backward reduction: its two operand tiles (x, act) are fetched NOW, so the loads fly while the
+  // accumulators are staged through LDS (they used to start only after the C tile had been stored)
+  constexpr int NPRE = (128 * (BN / 8)) / 256;
+  uint4 pre_x[NPRE], pre_a[NPRE];
+  if (bnred.x && bnred.prefetch) {
+    const unsigned short* bx0 = reinterpret_cast<const unsigned short*>(bnred.x);
+    const unsigned short* ba0 = reinterpret_cast<const unsigned short*>(bnred.act);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int id = tid + 256 * i, rl = id / (BN / 8), ch = id - rl * (BN / 8);
+      const int rr = row0 + rl;
+      pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
+      pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      if (rr < g.M) {
+        const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
+        pre_x[i] = *reinterpret_cast<const uint4*>(bx0 + off);
+        if (ba0) pre_a[i] = *reinterpret_cast<const uint4*>(ba0 + off);
+      }
+    }
+  }
   float s1v[TNW], s2v[TNW];
 #pragma unroll
   for (int j = 0; j < TNW; ++j) {
@@ -449,9 +469,12 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       }
       *reinterpret_cast<uint4*>(out + off) = v;
       if (bx) {                                                // fused BN-backward column reduction
-        const uint4 xv = *reinterpret_cast<const uint4*>(bx + off);
-        uint4 av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-        if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
+        uint4 xv = pre_x[i], av = pre_a[i];
+        if (!bnred.prefetch) {
+          xv = *reinterpret_cast<const uint4*>(bx + off);
+          av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+          if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
+        }
         const unsigned* vw = &v.x; const unsigned* xw = &xv.x; const unsigned* aw = &av.x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -652,6 +675,26 @@ __global__ __launch_bounds__(512, 1) void igemm_bf16_ws_kernel(IGemmGeom g, cons
   __syncthreads();
 
   // ---- epilogue: consumers stage the C tile (bf16) in LDS, all 512 threads copy it out
+  // fused BN-backward reduction: its two operand tiles (x, act) are fetched NOW, so the loads fly while the
+  // accumulators are staged through LDS (they used to start only after the C tile had been stored)
+  constexpr int NPRE = (128 * (BN / 8)) / 512;
+  uint4 pre_x[NPRE], pre_a[NPRE];
+  if (bnred.x && bnred.prefetch) {
+    const unsigned short* bx0 = reinterpret_cast<const unsigned short*>(bnred.x);
+    const unsigned short* ba0 = reinterpret_cast<const unsigned short*>(bnred.act);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int id = tid + 512 * i, rl = id / (BN / 8), ch = id - rl * (BN / 8);
+      const int rr = row0 + rl;
+      pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
+      pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      if (rr < g.M) {
+        const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
+        pre_x[i] = *reinterpret_cast<const uint4*>(bx0 + off);
+        if (ba0) pre_a[i] = *reinterpret_cast<const uint4*>(ba0 + off);
+      }
+    }
+  }
   float s1v[TNW], s2v[TNW];
   if (!producer) {
 #pragma unroll
@@ -707,9 +750,12 @@ __global__ __launch_bounds__(512, 1) void igemm_bf16_ws_kernel(IGemmGeom g, cons
       }
       *reinterpret_cast<uint4*>(out + off) = v;
       if (bx) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(bx + off);
-        uint4 av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-        if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
+        uint4 xv = pre_x[i], av = pre_a[i];
+        if (!bnred.prefetch) {
+          xv = *reinterpret_cast<const uint4*>(bx + off);
+          av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+          if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
+        }
         const unsigned* vw = &v.x; const unsigned* xw = &xv.x; const unsigned* aw = &av.x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -889,7 +935,7 @@ static int ilog2_exact(int64_t v) {
 }
 
 static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src,
-                        float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+                        float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   const int tiles_m = (g.M + 127) / 128;
   // pick the N tile: 128 unless that leaves the chip (256 CUs) under-filled or N is only 64
   int bn = 128;
@@ -1019,7 +1065,8 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
   g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 1;
   g.K = (int)(d->kh * d->kw * d->out_c); g.N = (int)d->in_c; g.check_bounds = 1;
   igemm_finish_geom(g);
-  BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial};
+  static const int prefetch = [] { const char* e = getenv("CREID_BNRED_PREFETCH"); return e ? atoi(e) : 1; }();
+  BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial, prefetch};
   return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream), br);
 }
 
