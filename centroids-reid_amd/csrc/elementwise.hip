@@ -341,22 +341,23 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// one workgroup per input row (b, iy): no 64-bit index divisions on the per-element path (they were ~3/4 of the
+// kernel's time), the 8 argmax bytes of a window come in one 8-byte load
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           int B, int H, int W, int C, T* __restrict__ dx) {
   constexpr int V = Vec16<T>::N;
   const int OH = H / 2, OW = W / 2, cpr = C / V;
-  const int64_t total = (int64_t)B * H * W * cpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    int64_t p = i / cpr;
-    const int ix = (int)(p % W); p /= W;
-    const int iy = (int)(p % H);
-    const int b = (int)(p / H);
+  const int row = blockIdx.x;                       // b * H + iy
+  const int b = row / H, iy = row - b * H;
+  const int nvec = W * cpr;
+  T* drow = dx + (int64_t)row * W * C;
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    const int ix = v / cpr, cc = v - ix * cpr;
     float acc[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) acc[k] = 0.f;
-    // output windows containing (iy, ix): oy in {(iy+1)/2 - ...}: oy*2 + r - 1 == iy, r in 0..2
+    // output windows containing (iy, ix): oy*2 + r - 1 == iy, r in 0..2
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int t = iy + 1 - r;
@@ -372,12 +373,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         const int64_t o = ((((int64_t)b * OH + oy) * OW + ox) * cpr + cc) * V;
         float g[V];
         Vec16<T>::load(dy + o, g);
-        const uint8_t* ip = idx + o;
+        uint8_t tap[V];
+        if constexpr (V == 8) *reinterpret_cast<uint2*>(tap) = *reinterpret_cast<const uint2*>(idx + o);
+        else *reinterpret_cast<unsigned*>(tap) = *reinterpret_cast<const unsigned*>(idx + o);
 #pragma unroll
-        for (int k = 0; k < V; ++k) acc[k] += (ip[k] == (uint8_t)(r * 3 + s)) ? g[k] : 0.f;
+        for (int k = 0; k < V; ++k) acc[k] += (tap[k] == (uint8_t)(r * 3 + s)) ? g[k] : 0.f;
       }
     }
-    Vec16<T>::store(dx + i * V, acc);
+    Vec16<T>::store(drow + (int64_t)v * V, acc);
   }
 }
 
@@ -635,9 +638,9 @@ int creid_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, int64_t B, int64_
   CREID_CHECK_ARG(dy && dx && idx && B > 0 && H > 0 && W > 0 && C % 8 == 0);
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_blocks(B * H * W * C / 4, 1)), dim3(256), 0, s,
+             hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((unsigned)(B * H)), dim3(256), 0, s,
                                 (const float*)dy, idx, (int)B, (int)H, (int)W, (int)C, (float*)dx),
-             hipLaunchKernelGGL(maxpool_bwd_kernel<unsigned short>, dim3(ew_blocks(B * H * W * C / 8, 1)), dim3(256), 0, s,
+             hipLaunchKernelGGL(maxpool_bwd_kernel<unsigned short>, dim3((unsigned)(B * H)), dim3(256), 0, s,
                                 (const unsigned short*)dy, idx, (int)B, (int)H, (int)W, (int)C, (unsigned short*)dx));
   CREID_LAUNCH_RET();
 }
