@@ -320,27 +320,34 @@ class BackboneEngine:
         M = B * oh * ow
         x = self._empty(M, u.cout)
         if u.ibn is not None:
-            L.check(lib.creid_conv2d_fwd_nhwc(C.byref(d), L.ptr(a_in), L.ptr(u.w_krsc), L.ptr(x), None, self.dt, st),
+            # the conv epilogue's per-128-row (sum, sumsq) partials are per-image row blocks when HW % 128 == 0:
+            # IBN then needs no statistics pass of its own (InstanceNorm uses instance statistics in eval too)
+            part = None
+            if (oh * ow) % 128 == 0:
+                part = self._empty(lib.creid_conv2d_bn_partial_rows(C.byref(d)) * 2, u.cout, dtype=torch.float32)
+            L.check(lib.creid_conv2d_fwd_nhwc(C.byref(d), L.ptr(a_in), L.ptr(u.w_krsc), L.ptr(x), L.ptr(part), self.dt, st),
                     "conv2d_fwd")
-            return (x,) + self._ibn_tail(u, x, B, oh * ow, training, relu) + (oh, ow)
+            return (x,) + self._ibn_tail(u, x, B, oh * ow, training, relu, part) + (oh, ow)
         rows = lib.creid_conv2d_bn_partial_rows(C.byref(d)) if training else 0
         part = self._empty(rows * 2, u.cout, dtype=torch.float32) if training else None
         L.check(lib.creid_conv2d_fwd_nhwc(C.byref(d), L.ptr(a_in), L.ptr(u.w_krsc), L.ptr(x), L.ptr(part), self.dt, st),
                 "conv2d_fwd")
         return (x,) + self._bn_tail(u, x, part, rows, M, training, relu, residual) + (oh, ow)
 
-    def _ibn_tail(self, u, x, B, HW, training, relu):
+    def _ibn_tail(self, u, x, B, HW, training, relu, part=None):
         lib, st = L.lib(), L.stream()
         ibn, bn = u.ibn, u.bn
         rpi = lib.creid_ibn_rows_per_image(HW)
-        part = self._empty(B * rpi * 2, u.cout, dtype=torch.float32)
+        ready = 1 if part is not None else 0
+        if part is None:
+            part = self._empty(B * rpi * 2, u.cout, dtype=torch.float32)
         mean = self._empty(B, u.cout, dtype=torch.float32)
         invstd = self._empty(B, u.cout, dtype=torch.float32)
         ss = self._empty(B * 2, u.cout, dtype=torch.float32)
         a = self._empty(B * HW, u.cout)
         L.check(lib.creid_ibn_fwd(L.ptr(x), B, HW, u.cout, ibn.half, L.ptr(ibn.IN.weight), L.ptr(ibn.IN.bias),
                                   L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean), L.ptr(bn.running_var),
-                                  1 if training else 0, bn.momentum, bn.eps, 1 if relu else 0, self.dt, L.ptr(part),
+                                  1 if training else 0, bn.momentum, bn.eps, 1 if relu else 0, self.dt, L.ptr(part), ready,
                                   L.ptr(mean), L.ptr(invstd), L.ptr(ss), L.ptr(a), st), "ibn_fwd")
         return a, mean, invstd
 

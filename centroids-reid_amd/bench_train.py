@@ -90,7 +90,8 @@ def pmc_traffic(key):
 
 def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
     P, K, H, W = 16, 4, 256, 128
-    model = make_model()
+    arch = os.environ.get("CREID_BENCH_ARCH", "resnet50")      # resnet50_ibn_a: side measurement, not the headline config
+    model = make_model(arch=arch)
     if world > 1:
         # identical initial weights on every rank, then data-parallel gradient all-reduce over RCCL
         opt, _ = model.optimizers()
@@ -179,7 +180,8 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
             res["cpu_baseline"] = cpu_baseline_fn(P, K, H, W)
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
             "ms_per_step": dt / args.steps * 1e3, "dtype": "bf16",
-            "config": {"workload": "ResNet50 256x128 CTL training step: fwd+bwd, centroid-triplet + center + xent, "
+            "config": {"workload": ("ResNet50" if arch == "resnet50" else arch) +
+                                   " 256x128 CTL training step: fwd+bwd, centroid-triplet + center + xent, "
                                    "Adam + center SGD (BASELINE configs[1])",
                        "P": P, "K": K, "global_batch": P * K * world, "num_classes": 751,
                        "parallelism": f"dp{world}" if world > 1 else "single"}, **res}

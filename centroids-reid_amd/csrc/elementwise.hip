@@ -769,73 +769,102 @@ __global__ __launch_bounds__(256) void ibn_col_stats_kernel(const T* __restrict_
   }
 }
 
-// one thread per (image, channel): mean/invstd [B][C], scale_shift [B][2][C]; BN-half running stats by n == 0
-__global__ __launch_bounds__(256) void ibn_finalize_kernel(const float* __restrict__ partial, int B, int rpi, int HW,
-                                                           int C, int c_in, const float* __restrict__ in_w,
-                                                           const float* __restrict__ in_b,
-                                                           const float* __restrict__ bn_w,
-                                                           const float* __restrict__ bn_b, float* __restrict__ rmean,
-                                                           float* __restrict__ rvar, int training, float momentum,
-                                                           float eps, float* __restrict__ mean_out,
-                                                           float* __restrict__ invstd_out,
-                                                           float* __restrict__ scale_shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0, cnt;
-  float g, b;
-  bool use_running = false;
-  if (c < c_in) {                                  // InstanceNorm: this image only (always batch statistics)
-    for (int r = 0; r < rpi; ++r) {
-      s1 += (double)partial[(((int64_t)n * rpi + r) * 2) * C + c];
-      s2 += (double)partial[(((int64_t)n * rpi + r) * 2 + 1) * C + c];
+// 16 channels x 64 lanes per workgroup (the bn2d_finalize layout).  InstanceNorm channels: lane rg owns images
+// rg, rg+64, ... and sums that image's rpi row blocks.  BatchNorm channels: the 64 lanes share the B*rpi row
+// blocks, meet in LDS (fp64, fixed order) and then write the same statistics for every image.
+// Outputs: mean/invstd [B][C], scale_shift [B][2][C].
+__global__ __launch_bounds__(1024) void ibn_finalize_kernel(const float* __restrict__ partial, int B, int rpi, int HW,
+                                                            int C, int c_in, const float* __restrict__ in_w,
+                                                            const float* __restrict__ in_b,
+                                                            const float* __restrict__ bn_w,
+                                                            const float* __restrict__ bn_b, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, int training, float momentum,
+                                                            float eps, float* __restrict__ mean_out,
+                                                            float* __restrict__ invstd_out,
+                                                            float* __restrict__ scale_shift) {
+  __shared__ double red[64][2][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool live = c < C, is_in = live && c < c_in, is_bn = live && c >= c_in;
+  double s1 = 0.0, s2 = 0.0;
+  if (is_bn && training)
+    for (int r = rg; r < B * rpi; r += 64) {
+      s1 += (double)partial[((int64_t)r * 2) * C + c];
+      s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
-    cnt = (double)HW; g = in_w[c]; b = in_b[c];
-  } else {
-    g = bn_w[c - c_in]; b = bn_b[c - c_in];
-    if (training) {
-      for (int r = 0; r < B * rpi; ++r) {
-        s1 += (double)partial[((int64_t)r * 2) * C + c];
-        s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
+  red[rg][0][cl] = s1; red[rg][1][cl] = s2;
+  __syncthreads();
+  if (is_in) {
+    const float g = in_w[c], b = in_b[c];
+    for (int n = rg; n < B; n += 64) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int r = 0; r < rpi; ++r) {
+        t1 += (double)partial[(((int64_t)n * rpi + r) * 2) * C + c];
+        t2 += (double)partial[(((int64_t)n * rpi + r) * 2 + 1) * C + c];
       }
-      cnt = (double)B * HW;
-    } else { use_running = true; cnt = 1.0; }
-  }
-  float mu, is;
-  if (use_running) { mu = rmean[c - c_in]; is = 1.0f / sqrtf(rvar[c - c_in] + eps); }
-  else {
-    const double mean = s1 / cnt;
-    double var = s2 / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mu = (float)mean; is = (float)(1.0 / sqrt(var + (double)eps));
-    if (c >= c_in && n == 0) {
-      rmean[c - c_in] = (1.f - momentum) * rmean[c - c_in] + momentum * mu;
-      rvar[c - c_in] = (1.f - momentum) * rvar[c - c_in] + momentum * (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
+      const double mean = t1 / (double)HW;
+      double var = t2 / (double)HW - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float mu = (float)mean, is = (float)(1.0 / sqrt(var + (double)eps));
+      mean_out[(int64_t)n * C + c] = mu; invstd_out[(int64_t)n * C + c] = is;
+      const float sc = is * g;
+      scale_shift[((int64_t)n * 2) * C + c] = sc;
+      scale_shift[((int64_t)n * 2 + 1) * C + c] = b - mu * sc;
+    }
+  } else if (is_bn) {
+    const float g = bn_w[c - c_in], b = bn_b[c - c_in];
+    float mu, is;
+    if (training) {
+      s1 = 0.0; s2 = 0.0;
+#pragma unroll 8
+      for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+      const double cnt = (double)B * HW;
+      const double mean = s1 / cnt;
+      double var = s2 / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      mu = (float)mean; is = (float)(1.0 / sqrt(var + (double)eps));
+      if (rg == 0) {
+        rmean[c - c_in] = (1.f - momentum) * rmean[c - c_in] + momentum * mu;
+        rvar[c - c_in] = (1.f - momentum) * rvar[c - c_in] + momentum * (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
+      }
+    } else {
+      mu = rmean[c - c_in]; is = 1.0f / sqrtf(rvar[c - c_in] + eps);
+    }
+    const float sc = is * g, sh = b - mu * sc;
+    for (int n = rg; n < B; n += 64) {
+      mean_out[(int64_t)n * C + c] = mu; invstd_out[(int64_t)n * C + c] = is;
+      scale_shift[((int64_t)n * 2) * C + c] = sc;
+      scale_shift[((int64_t)n * 2 + 1) * C + c] = sh;
     }
   }
-  mean_out[(int64_t)n * C + c] = mu; invstd_out[(int64_t)n * C + c] = is;
-  const float sc = is * g;
-  scale_shift[((int64_t)n * 2) * C + c] = sc;
-  scale_shift[((int64_t)n * 2 + 1) * C + c] = b - mu * sc;
 }
 
+// grid (blocks, B): one image per blockIdx.y; a thread keeps ONE channel vector for its whole loop (stride a
+// multiple of C/V), so its per-(image, channel) coefficients are loaded once and no index division remains
 template <typename T>
 __global__ __launch_bounds__(256) void ibn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift,
                                                         int relu, int64_t M, int HW, int C, T* __restrict__ y) {
   constexpr int V = Vec16<T>::N;
-  const int cpr = C / V;
-  const int64_t total = M * cpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / cpr;
-    const int c0 = (int)(i - row * cpr) * V;
-    const int64_t n = row / HW;
+  const int cpr = C / V, n = blockIdx.y;
+  const int total = HW * cpr, nthreads = gridDim.x * 256;       // 256 % cpr == 0 (host-checked)
+  const int gtid = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (gtid % cpr) * V;
+  float sc[V], sh[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    sc[k] = scale_shift[((int64_t)n * 2) * C + c0 + k];
+    sh[k] = scale_shift[((int64_t)n * 2 + 1) * C + c0 + k];
+  }
+  const int64_t base = (int64_t)n * total;
+  for (int i = gtid; i < total; i += nthreads) {
     float v[V];
-    Vec16<T>::load(x + i * V, v);
+    Vec16<T>::load(x + (base + i) * V, v);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      v[k] = fmaf(v[k], scale_shift[(n * 2) * C + c0 + k], scale_shift[(n * 2 + 1) * C + c0 + k]);
+      v[k] = fmaf(v[k], sc[k], sh[k]);
       if (relu) v[k] = fmaxf(v[k], 0.f);
     }
-    Vec16<T>::store(y + i * V, v);
+    Vec16<T>::store(y + (base + i) * V, v);
   }
 }
 
@@ -887,40 +916,59 @@ __global__ __launch_bounds__(256) void ibn_bwd_reduce_kernel(const T* __restrict
   }
 }
 
-// coef [B][3][C]; d(in_w, in_b) += sum over images of per-image sums; d(bn_w, bn_b) += batch sums (by n == 0)
-__global__ __launch_bounds__(256) void ibn_bwd_finalize_kernel(const float* __restrict__ partial, int B, int rpi, int HW,
-                                                               int C, int c_in, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd,
-                                                               const float* __restrict__ in_w,
-                                                               const float* __restrict__ bn_w,
-                                                               float* __restrict__ coef, float* __restrict__ per_img,
-                                                               float* __restrict__ d_bn_w, float* __restrict__ d_bn_b) {
-  const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0, cnt;
-  float g;
-  if (c < c_in) {
-    for (int r = 0; r < rpi; ++r) {
-      s1 += (double)partial[(((int64_t)n * rpi + r) * 2) * C + c];
-      s2 += (double)partial[(((int64_t)n * rpi + r) * 2 + 1) * C + c];
-    }
-    cnt = (double)HW; g = in_w[c];
-    per_img[((int64_t)n * 2) * c_in + c] = (float)s1;         // reduced over images by ibn_in_grad_kernel
-    per_img[((int64_t)n * 2 + 1) * c_in + c] = (float)s2;
-  } else {
-    for (int r = 0; r < B * rpi; ++r) {
+// coef [B][3][C]; d(in_w, in_b) += sum over images of per-image sums (ibn_in_grad_kernel); d(bn_w, bn_b) += batch
+// sums.  Same 16-channel x 64-lane layout as ibn_finalize_kernel.
+__global__ __launch_bounds__(1024) void ibn_bwd_finalize_kernel(const float* __restrict__ partial, int B, int rpi, int HW,
+                                                                int C, int c_in, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ in_w,
+                                                                const float* __restrict__ bn_w,
+                                                                float* __restrict__ coef, float* __restrict__ per_img,
+                                                                float* __restrict__ d_bn_w, float* __restrict__ d_bn_b) {
+  __shared__ double red[64][2][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool live = c < C, is_in = live && c < c_in, is_bn = live && c >= c_in;
+  double s1 = 0.0, s2 = 0.0;
+  if (is_bn)
+    for (int r = rg; r < B * rpi; r += 64) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
-    cnt = (double)B * HW; g = bn_w[c - c_in];
-    if (n == 0) { if (d_bn_b) d_bn_b[c - c_in] += (float)s1; if (d_bn_w) d_bn_w[c - c_in] += (float)s2; }
+  red[rg][0][cl] = s1; red[rg][1][cl] = s2;
+  __syncthreads();
+  if (is_in) {
+    const float g = in_w[c];
+    const float invM = 1.0f / (float)HW;
+    for (int n = rg; n < B; n += 64) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int r = 0; r < rpi; ++r) {
+        t1 += (double)partial[(((int64_t)n * rpi + r) * 2) * C + c];
+        t2 += (double)partial[(((int64_t)n * rpi + r) * 2 + 1) * C + c];
+      }
+      per_img[((int64_t)n * 2) * c_in + c] = (float)t1;         // reduced over images by ibn_in_grad_kernel
+      per_img[((int64_t)n * 2 + 1) * c_in + c] = (float)t2;
+      const float mu = mean[(int64_t)n * C + c], is = invstd[(int64_t)n * C + c], k1 = g * is;
+      const float a1 = (float)t1 * invM, a2 = (float)t2 * invM;
+      coef[((int64_t)n * 3) * C + c] = k1;
+      coef[((int64_t)n * 3 + 1) * C + c] = -k1 * is * a2;
+      coef[((int64_t)n * 3 + 2) * C + c] = -k1 * a1 + k1 * is * a2 * mu;
+    }
+  } else if (is_bn) {
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    if (rg == 0) { if (d_bn_b) d_bn_b[c - c_in] += (float)s1; if (d_bn_w) d_bn_w[c - c_in] += (float)s2; }
+    const float invM = (float)(1.0 / ((double)B * HW));
+    const float mu = mean[c], is = invstd[c], k1 = bn_w[c - c_in] * is;      // same for every image: read image 0
+    const float a1 = (float)s1 * invM, a2 = (float)s2 * invM;
+    const float cA = k1, cB = -k1 * is * a2, cC = -k1 * a1 + k1 * is * a2 * mu;
+    for (int n = rg; n < B; n += 64) {
+      coef[((int64_t)n * 3) * C + c] = cA;
+      coef[((int64_t)n * 3 + 1) * C + c] = cB;
+      coef[((int64_t)n * 3 + 2) * C + c] = cC;
+    }
   }
-  const float invM = (float)(1.0 / cnt);
-  const float mu = mean[(int64_t)n * C + c], is = invstd[(int64_t)n * C + c], k1 = g * is;
-  const float a1 = (float)s1 * invM, a2 = (float)s2 * invM;
-  coef[((int64_t)n * 3) * C + c] = k1;
-  coef[((int64_t)n * 3 + 1) * C + c] = -k1 * is * a2;
-  coef[((int64_t)n * 3 + 2) * C + c] = -k1 * a1 + k1 * is * a2 * mu;
 }
 
 __global__ __launch_bounds__(256) void ibn_in_grad_kernel(const float* __restrict__ per_img, int B, int c_in,
@@ -938,52 +986,67 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(const T* __restrict_
                                                             const T* __restrict__ act, const float* __restrict__ coef,
                                                             int64_t M, int HW, int C, T* __restrict__ dx) {
   constexpr int V = Vec16<T>::N;
-  const int cpr = C / V;
-  const int64_t total = M * cpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / cpr;
-    const int c0 = (int)(i - row * cpr) * V;
-    const int64_t n = row / HW;
+  const int cpr = C / V, n = blockIdx.y;
+  const int total = HW * cpr, nthreads = gridDim.x * 256;       // 256 % cpr == 0 (host-checked)
+  const int gtid = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (gtid % cpr) * V;
+  float ca[V], cb[V], cc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    ca[k] = coef[((int64_t)n * 3) * C + c0 + k];
+    cb[k] = coef[((int64_t)n * 3 + 1) * C + c0 + k];
+    cc[k] = coef[((int64_t)n * 3 + 2) * C + c0 + k];
+  }
+  const int64_t base = (int64_t)n * total;
+  for (int i = gtid; i < total; i += nthreads) {
     float xv[V], gv[V], o[V];
-    Vec16<T>::load(x + i * V, xv);
-    Vec16<T>::load(g + i * V, gv);
+    Vec16<T>::load(x + (base + i) * V, xv);
+    Vec16<T>::load(g + (base + i) * V, gv);
     if (act) {
       float av[V];
-      Vec16<T>::load(act + i * V, av);
+      Vec16<T>::load(act + (base + i) * V, av);
 #pragma unroll
       for (int k = 0; k < V; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < V; ++k)
-      o[k] = fmaf(coef[(n * 3) * C + c0 + k], gv[k], fmaf(coef[(n * 3 + 1) * C + c0 + k], xv[k], coef[(n * 3 + 2) * C + c0 + k]));
-    Vec16<T>::store(dx + i * V, o);
+    for (int k = 0; k < V; ++k) o[k] = fmaf(ca[k], gv[k], fmaf(cb[k], xv[k], cc[k]));
+    Vec16<T>::store(dx + (base + i) * V, o);
   }
 }
 
 extern "C" {
 
+// workgroups per image for the IBN apply passes: ~4 vectors per thread, at most 64 per image
+static unsigned ibn_img_blocks(int64_t vecs_per_image) {
+  int64_t b = (vecs_per_image + 1023) / 1024;
+  return (unsigned)(b < 1 ? 1 : (b > 64 ? 64 : b));
+}
+
 int64_t creid_ibn_rows_per_image(int64_t HW) { int64_t r = (HW + 127) / 128; return r < 1 ? 1 : r; }
 
 int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* in_b,
                   const float* bn_w, const float* bn_b, float* running_mean, float* running_var, int training,
-                  float momentum, float eps, int relu, int dtype, float* partial, float* mean_out, float* invstd_out,
-                  float* scale_shift, void* y, void* stream) {
+                  float momentum, float eps, int relu, int dtype, float* partial, int partial_ready, float* mean_out,
+                  float* invstd_out, float* scale_shift, void* y, void* stream) {
   CREID_CHECK_ARG(x && y && in_w && in_b && bn_w && bn_b && running_mean && running_var && partial && mean_out &&
                   invstd_out && scale_shift && B > 0 && HW > 0 && C % 8 == 0 && c_in > 0 && c_in < C);
+  if (256 % (C / 8) != 0 || 256 % (C / 4) != 0) return CREID_E_SHAPE;      // a thread keeps one channel vector
+  if (partial_ready && HW % 128 != 0) return CREID_E_SHAPE;                 // conv tiles must not straddle images
   const int rpi = (int)creid_ibn_rows_per_image(HW);
   hipStream_t s = as_stream(stream);
+  if (!partial_ready)
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(ibn_col_stats_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rpi, (unsigned)B), dim3(256),
                                 0, s, (const float*)x, (int)HW, (int)C, 128, rpi, partial),
              hipLaunchKernelGGL(ibn_col_stats_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
                                 dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, 128, rpi, partial));
-  hipLaunchKernelGGL(ibn_finalize_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, partial, (int)B,
+  hipLaunchKernelGGL(ibn_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, (int)B,
                      rpi, (int)HW, (int)C, (int)c_in, in_w, in_b, bn_w, bn_b, running_mean, running_var, training, momentum,
                      eps, mean_out, invstd_out, scale_shift);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(ibn_apply_kernel<float>, dim3(ew_blocks(B * HW * C / 4, 1)), dim3(256), 0, s, (const float*)x,
+             hipLaunchKernelGGL(ibn_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4), (unsigned)B), dim3(256), 0, s, (const float*)x,
                                 scale_shift, relu, B * HW, (int)HW, (int)C, (float*)y),
-             hipLaunchKernelGGL(ibn_apply_kernel<unsigned short>, dim3(ew_blocks(B * HW * C / 8, 1)), dim3(256), 0, s,
+             hipLaunchKernelGGL(ibn_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (unsigned short*)y));
   CREID_LAUNCH_RET();
 }
@@ -994,6 +1057,7 @@ int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* me
                   void* stream) {
   CREID_CHECK_ARG(x && g && mean && invstd && in_w && bn_w && partial && coef && per_img && dx && B > 0 && HW > 0 &&
                   C % 8 == 0 && c_in > 0 && c_in < C);
+  if (256 % (C / 8) != 0 || 256 % (C / 4) != 0) return CREID_E_SHAPE;
   const int rpi = (int)creid_ibn_rows_per_image(HW);
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
@@ -1003,14 +1067,14 @@ int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* me
              hipLaunchKernelGGL(ibn_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
                                 dim3(256), 0, s, (const unsigned short*)x, (const unsigned short*)g,
                                 (const unsigned short*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial));
-  hipLaunchKernelGGL(ibn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL(ibn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial,
                      (int)B, rpi, (int)HW, (int)C, (int)c_in, mean, invstd, in_w, bn_w, coef, per_img, d_bn_w, d_bn_b);
   hipLaunchKernelGGL(ibn_in_grad_kernel, dim3((unsigned)((c_in + 255) / 256)), dim3(256), 0, s, per_img, (int)B, (int)c_in,
                      d_in_w, d_in_b);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(ibn_bwd_apply_kernel<float>, dim3(ew_blocks(B * HW * C / 4, 1)), dim3(256), 0, s,
+             hipLaunchKernelGGL(ibn_bwd_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4), (unsigned)B), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, coef, B * HW, (int)HW, (int)C, (float*)dx),
-             hipLaunchKernelGGL(ibn_bwd_apply_kernel<unsigned short>, dim3(ew_blocks(B * HW * C / 8, 1)), dim3(256), 0, s,
+             hipLaunchKernelGGL(ibn_bwd_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
                                 (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, coef, B * HW,
                                 (int)HW, (int)C, (unsigned short*)dx));
   CREID_LAUNCH_RET();

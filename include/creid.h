@@ -250,15 +250,17 @@ int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* m
 /* IBN of ResNet50-IBN-a (modelling/backbones/resnet_ibn_a.py:18-32): channels [0, c_in) InstanceNorm2d
  * (affine, per-(image, channel) statistics over H*W, eps 1e-5, no running stats), channels [c_in, C)
  * BatchNorm2d; then ReLU if relu.  x, y NHWC [B*HW, C]; partial = float[B*creid_ibn_rows_per_image(HW)][2][C]
- * scratch; mean_out/invstd_out float[B][C]; scale_shift float[B][2][C] (saved for the backward).
+ * scratch -- or, with partial_ready = 1 and HW % 128 == 0, the (sum, sumsq) partials the producing
+ * creid_conv2d_fwd_nhwc already wrote (its 128-row tiles are then whole row blocks of one image);
+ * mean_out/invstd_out float[B][C]; scale_shift float[B][2][C] (saved for the backward).
  * bwd: dy = g*[act>0]; coef float[B][3][C] and per_img float[B][2][c_in] scratch; parameter
  * gradients are accumulated. */
 int64_t creid_ibn_rows_per_image(int64_t HW);
 int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w,
                   const float* in_b, const float* bn_w, const float* bn_b, float* running_mean,
                   float* running_var, int training, float momentum, float eps, int relu, int dtype,
-                  float* partial, float* mean_out, float* invstd_out, float* scale_shift, void* y,
-                  void* stream);
+                  float* partial, int partial_ready, float* mean_out, float* invstd_out, float* scale_shift,
+                  void* y, void* stream);
 int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
                   int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* bn_w,
                   int dtype, float* partial, float* coef, float* per_img, float* d_in_w, float* d_in_b,

@@ -257,7 +257,7 @@ def test_ibn_layer_vs_torch(dtype):
     rmg, rvg = torch.zeros(half, **f32), torch.ones(half, **f32)
     t = [a.to(dev) for a in (inw, inb, bnw, bnb)]
     L.check(lib.creid_ibn_fwd(L.ptr(xg), B, HW, Cc, half, L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.ptr(t[3]), L.ptr(rmg), L.ptr(rvg),
-                              1, 0.1, 1e-5, 1, L._DT[dtype], L.ptr(part), L.ptr(mean), L.ptr(invstd), L.ptr(ss), L.ptr(yg), L.stream()), "ibn_fwd")
+                              1, 0.1, 1e-5, 1, L._DT[dtype], L.ptr(part), 0, L.ptr(mean), L.ptr(invstd), L.ptr(ss), L.ptr(yg), L.stream()), "ibn_fwd")
     tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(yg.float().cpu().permute(0, 3, 1, 2).numpy(), y.detach().float().numpy(), **tol)
     np.testing.assert_allclose(rvg.cpu().numpy(), rv.float().numpy(), rtol=1e-5, atol=1e-6)
