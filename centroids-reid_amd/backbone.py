@@ -351,16 +351,18 @@ class BackboneEngine:
                                   L.ptr(mean), L.ptr(invstd), L.ptr(ss), L.ptr(a), st), "ibn_fwd")
         return a, mean, invstd
 
-    def _ibn_bwd(self, u, x, g, act, mean, invstd, B, HW):
+    def _ibn_bwd(self, u, x, g, act, mean, invstd, B, HW, part=None):
         lib, st = L.lib(), L.stream()
         ibn, bn = u.ibn, u.bn
         rpi = lib.creid_ibn_rows_per_image(HW)
-        part = self._empty(B * rpi * 2, u.cout, dtype=torch.float32)
+        ready = 1 if part is not None else 0
+        if part is None:
+            part = self._empty(B * rpi * 2, u.cout, dtype=torch.float32)
         coef = self._empty(B * 3, u.cout, dtype=torch.float32)
         per_img = self._empty(B * 2, ibn.half, dtype=torch.float32)
         dx = self._empty(B * HW, u.cout)
         L.check(lib.creid_ibn_bwd(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mean), L.ptr(invstd), B, HW, u.cout, ibn.half,
-                                  L.ptr(ibn.IN.weight), L.ptr(bn.weight), self.dt, L.ptr(part), L.ptr(coef), L.ptr(per_img),
+                                  L.ptr(ibn.IN.weight), L.ptr(bn.weight), self.dt, L.ptr(part), ready, L.ptr(coef), L.ptr(per_img),
                                   L.ptr(self._grad_of(ibn.IN.weight)), L.ptr(self._grad_of(ibn.IN.bias)),
                                   L.ptr(self._grad_of(bn.weight)), L.ptr(self._grad_of(bn.bias)), L.ptr(dx), st), "ibn_bwd")
         return dx, None
@@ -475,9 +477,10 @@ class BackboneEngine:
         L.check(lib.creid_conv2d_wgrad_nhwc(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(self._grad_of(u.conv.weight)), 1,
                                             L.ptr(ws), nbytes, self.dt, st), "conv2d_wgrad")
 
-    def _dgrad(self, u, dy, B, H, W, add_src=None, bnred=None):
+    def _dgrad(self, u, dy, B, H, W, add_src=None, bnred=None, stat_image_rows=0):
         """Data gradient.  bnred = (x, act, mean, invstd) of the BN layer that consumes the result: its column
-        reduction is fused into the epilogue (bf16) and the partials are returned."""
+        reduction is fused into the epilogue (bf16) and the partials are returned.  stat_image_rows = H*W when
+        mean / invstd are per-(image, channel) (IBN), 0 for BatchNorm."""
         lib, st = L.lib(), L.stream()
         d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         M = B * H * W
@@ -486,8 +489,8 @@ class BackboneEngine:
             x, act, mean, invstd = bnred
             part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32)
             L.check(lib.creid_conv2d_dgrad_bnred_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src),
-                                                      L.ptr(x), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(part), self.dt,
-                                                      st), "conv2d_dgrad_bnred")
+                                                      L.ptr(x), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(part),
+                                                      stat_image_rows, self.dt, st), "conv2d_dgrad_bnred")
             return dx, part
         L.check(lib.creid_conv2d_dgrad_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src), self.dt, st),
                 "conv2d_dgrad")
@@ -515,11 +518,14 @@ class BackboneEngine:
             dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3, part=p2)
             self._wgrad(b["c2"], s["a1"], dx2, B, s["h1"], s["w1"])
             ibn1 = b["c1"].ibn is not None
+            hw1 = s["h1"] * s["w1"]
+            ibn_fused = ibn1 and hw1 % 128 == 0          # per-image statistics: the 128-row tiles must not straddle images
             da1, p1 = self._dgrad(b["c2"], dx2, B, s["h1"], s["w1"],
-                                  bnred=None if ibn1 else (s["x1"], s["a1"], s["m1"], s["i1"]))
+                                  bnred=None if (ibn1 and not ibn_fused) else (s["x1"], s["a1"], s["m1"], s["i1"]),
+                                  stat_image_rows=hw1 if ibn_fused else 0)
             M1 = B * s["h1"] * s["w1"]
             if ibn1:
-                dx1, _ = self._ibn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], B, s["h1"] * s["w1"])
+                dx1, _ = self._ibn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], B, hw1, part=p1)
             else:
                 dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1, part=p1)
             self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"])

@@ -442,8 +442,9 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     const int c0 = col0 + (tid % CPR) * 8;
 #pragma unroll
     for (int k = 0; k < 8; k += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(bnred.mean + c0 + k);
-      const float4 b = *reinterpret_cast<const float4*>(bnred.invstd + c0 + k);
+      const int64_t so = bnred.tiles_per_image ? (int64_t)(tile_m / bnred.tiles_per_image) * g.N : 0;   // per-image statistics (IBN)
+      const float4 a = *reinterpret_cast<const float4*>(bnred.mean + so + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(bnred.invstd + so + c0 + k);
       rmu[k] = a.x; rmu[k + 1] = a.y; rmu[k + 2] = a.z; rmu[k + 3] = a.w;
       ris[k] = b.x; ris[k + 1] = b.y; ris[k + 2] = b.z; ris[k + 3] = b.w;
     }
@@ -723,8 +724,9 @@ __global__ __launch_bounds__(512, 1) void igemm_bf16_ws_kernel(IGemmGeom g, cons
     const int c0 = col0 + (tid % CPR) * 8;
 #pragma unroll
     for (int k = 0; k < 8; k += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(bnred.mean + c0 + k);
-      const float4 b = *reinterpret_cast<const float4*>(bnred.invstd + c0 + k);
+      const int64_t so = bnred.tiles_per_image ? (int64_t)(tile_m / bnred.tiles_per_image) * g.N : 0;   // per-image statistics (IBN)
+      const float4 a = *reinterpret_cast<const float4*>(bnred.mean + so + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(bnred.invstd + so + c0 + k);
       rmu[k] = a.x; rmu[k + 1] = a.y; rmu[k + 2] = a.z; rmu[k + 3] = a.w;
       ris[k] = b.x; ris[k + 1] = b.y; ris[k + 2] = b.z; ris[k + 3] = b.w;
     }
@@ -935,7 +937,7 @@ static int ilog2_exact(int64_t v) {
 }
 
 static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src,
-                        float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
+                        float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}) {
   const int tiles_m = (g.M + 127) / 128;
   // pick the N tile: 128 unless that leaves the chip (256 CUs) under-filled or N is only 64
   int bn = 128;
@@ -1053,10 +1055,12 @@ int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void
 /* dgrad with the NEXT BatchNorm-backward's column reduction fused into the epilogue (bf16 only). */
 int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
                                   const void* add_src, const void* bn_x, const void* bn_act, const float* bn_mean,
-                                  const float* bn_invstd, float* bn_partial, int dtype, void* stream) {
+                                  const float* bn_invstd, float* bn_partial, int64_t bn_stat_image_rows, int dtype,
+                                  void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  CREID_CHECK_ARG(dy && w_crsk && dx && bn_x && bn_mean && bn_invstd && bn_partial);
+  CREID_CHECK_ARG(dy && w_crsk && dx && bn_x && bn_mean && bn_invstd && bn_partial && bn_stat_image_rows >= 0);
+  if (bn_stat_image_rows % 128 != 0) return CREID_E_SHAPE;
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
   if (dtype != CREID_BF16 || !use_dma) return CREID_E_DTYPE;
   IGemmGeom g;
@@ -1066,7 +1070,7 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
   g.K = (int)(d->kh * d->kw * d->out_c); g.N = (int)d->in_c; g.check_bounds = 1;
   igemm_finish_geom(g);
   static const int prefetch = [] { const char* e = getenv("CREID_BNRED_PREFETCH"); return e ? atoi(e) : 1; }();
-  BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial, prefetch};
+  BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial, prefetch, (int)(bn_stat_image_rows / 128)};
   return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream), br);
 }
 

@@ -1053,13 +1053,15 @@ int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in,
 
 int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd, int64_t B,
                   int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* bn_w, int dtype, float* partial,
-                  float* coef, float* per_img, float* d_in_w, float* d_in_b, float* d_bn_w, float* d_bn_b, void* dx,
-                  void* stream) {
+                  int partial_ready, float* coef, float* per_img, float* d_in_w, float* d_in_b, float* d_bn_w,
+                  float* d_bn_b, void* dx, void* stream) {
   CREID_CHECK_ARG(x && g && mean && invstd && in_w && bn_w && partial && coef && per_img && dx && B > 0 && HW > 0 &&
                   C % 8 == 0 && c_in > 0 && c_in < C);
   if (256 % (C / 8) != 0 || 256 % (C / 4) != 0) return CREID_E_SHAPE;
+  if (partial_ready && HW % 128 != 0) return CREID_E_SHAPE;
   const int rpi = (int)creid_ibn_rows_per_image(HW);
   hipStream_t s = as_stream(stream);
+  if (!partial_ready)
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(ibn_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rpi, (unsigned)B), dim3(256),
                                 0, s, (const float*)x, (const float*)g, (const float*)act, mean, invstd, (int)HW, (int)C, 128,

@@ -192,11 +192,13 @@ int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void
                             const void* add_src, int dtype, void* stream);
 /* The same data gradient with the column reduction of the NEXT BatchNorm backward fused into the epilogue
  * (bf16 only): dx is g = dL/da of the layer whose raw conv output is bn_x and post-ReLU activation bn_act
- * (nullable); bn_partial[ceil(M/128)][2][in_c] receives (sum dy, sum dy*xhat), dy = g*[bn_act > 0]. */
+ * (nullable); bn_partial[ceil(M/128)][2][in_c] receives (sum dy, sum dy*xhat), dy = g*[bn_act > 0].
+ * bn_stat_image_rows = 0: bn_mean/bn_invstd are float[in_c] (BatchNorm); = in_h*in_w (a multiple of 128): they
+ * are float[batch][in_c], per-(image, channel) statistics of an IBN layer (creid_ibn_bwd, partial_ready). */
 int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
                                   const void* add_src, const void* bn_x, const void* bn_act,
-                                  const float* bn_mean, const float* bn_invstd, float* bn_partial, int dtype,
-                                  void* stream);
+                                  const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                                  int64_t bn_stat_image_rows, int dtype, void* stream);
 /* weight gradient into the fp32 OIHW tensor (the reference's nn.Parameter layout), optionally
  * accumulating; the pixel reduction is split over workgroups through `ws`. */
 size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype);
@@ -254,7 +256,8 @@ int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* m
  * creid_conv2d_fwd_nhwc already wrote (its 128-row tiles are then whole row blocks of one image);
  * mean_out/invstd_out float[B][C]; scale_shift float[B][2][C] (saved for the backward).
  * bwd: dy = g*[act>0]; coef float[B][3][C] and per_img float[B][2][c_in] scratch; parameter
- * gradients are accumulated. */
+ * gradients are accumulated; partial_ready = 1: `partial` was filled by creid_conv2d_dgrad_bnred_nhwc
+ * (bn_stat_image_rows = HW, HW % 128 == 0) and the column pass is skipped. */
 int64_t creid_ibn_rows_per_image(int64_t HW);
 int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w,
                   const float* in_b, const float* bn_w, const float* bn_b, float* running_mean,
@@ -263,8 +266,8 @@ int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in,
                   void* y, void* stream);
 int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
                   int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* bn_w,
-                  int dtype, float* partial, float* coef, float* per_img, float* d_in_w, float* d_in_b,
-                  float* d_bn_w, float* d_bn_b, void* dx, void* stream);
+                  int dtype, float* partial, int partial_ready, float* coef, float* per_img, float* d_in_w,
+                  float* d_in_b, float* d_bn_w, float* d_bn_b, void* dx, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:98) NHWC, with the argmax tap saved for the backward. */
 int creid_maxpool3x3s2_fwd(const void* x, int64_t B, int64_t H, int64_t W, int64_t C, int dtype, void* y,

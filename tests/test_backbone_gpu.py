@@ -264,7 +264,7 @@ def test_ibn_layer_vs_torch(dtype):
     coef = torch.empty((B * 3, Cc), **f32); per_img = torch.empty((B * 2, half), **f32); dx = torch.empty_like(xg)
     d = [torch.zeros(half, **f32) for _ in range(4)]
     L.check(lib.creid_ibn_bwd(L.ptr(xg), L.ptr(gg), L.ptr(yg), L.ptr(mean), L.ptr(invstd), B, HW, Cc, half, L.ptr(t[0]), L.ptr(t[2]),
-                              L._DT[dtype], L.ptr(part), L.ptr(coef), L.ptr(per_img), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), L.ptr(d[3]),
+                              L._DT[dtype], L.ptr(part), 0, L.ptr(coef), L.ptr(per_img), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), L.ptr(d[3]),
                               L.ptr(dx), L.stream()), "ibn_bwd")
     if ((yg.float().cpu().permute(0, 3, 1, 2) > 0) == (y.detach() > 0)).all():
         t2 = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
@@ -273,15 +273,17 @@ def test_ibn_layer_vs_torch(dtype):
             np.testing.assert_allclose(got.cpu().numpy(), ref.grad.float().numpy(), rtol=2e-3, atol=2e-2 if dtype == torch.bfloat16 else 1e-4)
 
 
-def test_fused_bn_reduce_matches_separate_pass():
+@pytest.mark.parametrize("arch", ["resnet50", "resnet50_ibn_a"])
+def test_fused_bn_reduce_matches_separate_pass(arch):
     """bf16: the BN-backward column reduction fused into the dgrad epilogue gives the same gradients as the
-    separate reduction pass (identical bf16 inputs, only the fp32 summation order differs)."""
+    separate reduction pass (identical bf16 inputs, only the fp32 summation order differs).  For IBN-a the
+    fused epilogue indexes per-(image, channel) statistics (layers 1-2 here; layer3's 8x4 maps fall back)."""
     from oracle import backbone_oracle as bo
     x = bo.synthetic_images(4, 128, 64, seed=21).cuda()
     coef = torch.from_numpy(np.random.default_rng(3).standard_normal((4, 2048)).astype(np.float32)).cuda()
     grads = []
     for fuse in (True, False):
-        net, eng, _ = _build("resnet50", torch.bfloat16)
+        net, eng, _ = _build(arch, torch.bfloat16)
         eng.fuse_bn_reduce = fuse
         _, feat = eng.forward(x, training=True)
         eng.backward(coef)
