@@ -2,10 +2,14 @@
 // (replaces nn.Conv2d fwd + dgrad of modelling/backbones/resnet.py:56-61,94,109 and
 //  resnet_ibn_a.py:40-48,83,110 -- bias-free 7x7 s2, 3x3 (s1/s2), 1x1 (s1/s2) convolutions.)
 //
-// bf16: 128 x BN x 64 tile, 256 threads (2x2 waves, 64 x BN/2 per wave) on
-//       v_mfma_f32_32x32x16_bf16, fp32 accumulate; LDS row-major [row][64] with the 16-B chunk
-//       index XOR-swizzled by (row>>1)&7 (conflict-free ds_read_b128), double-buffered,
-//       register-staged gather (the A rows come from different image rows / taps).
+// bf16: 128 x BN x 64 tile (2x2 waves, 64 x BN/2 per wave) on v_mfma_f32_32x32x16_bf16, fp32 accumulate; LDS
+//       row-major [row][64] with the 16-B chunk index XOR-swizzled by (row>>1)&7 (conflict-free ds_read_b128).
+//       Three kernels share that tiling and the epilogue:
+//         igemm_bf16_dma_kernel  global->LDS DMA gather (the A rows come from different image rows / taps),
+//                                NS-stage ring, 256 threads -- the default for every 1x1 / 3x3 layer;
+//         igemm_bf16_ws_kernel   512 threads, producer waves issue the DMA, consumer waves multiply -- long-k
+//                                128 x 64 tiles;
+//         igemm_bf16_kernel      register-staged gather -- the stem (32-element taps).
 // f32 : 128 x BN x 16 tile on v_mfma_f32_32x32x2_f32 (exact f32; parity mode), K-major LDS.
 // Epilogue (both): optional "+ add_src" (residual-gradient accumulation in dgrad), store in the
 // activation dtype, and optional per-tile per-channel (sum, sum of squares) partials of the fp32

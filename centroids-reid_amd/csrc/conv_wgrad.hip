@@ -2,14 +2,17 @@
 // (replaces nn.Conv2d wgrad of modelling/backbones/resnet.py:56-61,94,109).
 //
 // Both operands are stored PIXEL-major (the reduction index m is the row index of dY and X), so
-// this is a "TN" GEMM.  bf16: the tiles are copied to LDS exactly as they lie in memory
-// ([pixel][channel], 16-B stores) and the MFMA fragments (8 consecutive pixels of one channel
-// per lane) come out of gfx950's transposing LDS read `ds_read_b64_tr_b16` -- no register or
-// memory transpose.  Row pitch = tile width + 32 elements puts the four 32-B row segments of a
-// 16-lane group (and both groups of a 32-lane service half) on distinct banks.
+// this is a "TN" GEMM.  bf16: the tiles land in LDS exactly as they lie in memory ([pixel][channel])
+// and the MFMA fragments (8 consecutive pixels of one channel per lane) come out of gfx950's
+// transposing LDS read `ds_read_b64_tr_b16` -- no register or memory transpose.
+//   wgrad_bf16_dma_kernel (all 1x1 / 3x3 layers): both tiles are fetched with the global->LDS DMA into linear
+//     rows, bank conflicts avoided by an XOR swizzle of 64-byte units applied on the DMA source column; the
+//     gathered operand's pixel coordinates advance incrementally (64 pixels per k-step); fragment reads run one
+//     16-pixel slice ahead of the MFMAs.
+//   wgrad_bf16_kernel (stem, span 32): register-staged 16-B stores, row pitch = tile width + 32 elements.
 // f32 (parity mode): K-major LDS is the natural layout for v_mfma_f32_32x32x2_f32.
 // The pixel range is split over gridDim.y workgroups; fp32 partial tiles go to the workspace and
-// wgrad_reduce sums them (deterministic) and scatters into the OIHW fp32 gradient.
+// wgrad_reduce_kernel<SL> sums them in a fixed order (deterministic) and scatters into the OIHW fp32 gradient.
 #include "conv_common.hpp"
 #include <stdlib.h>
 
