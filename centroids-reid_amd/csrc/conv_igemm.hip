@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
 //   after B_t    :   producers issue tile t+NS-1 into slot (t-1)%NS, consumers multiply tile t.
 // Tiling, swizzle, zero page and the epilogue maths are those of igemm_bf16_dma_kernel (512 threads copy out).
 template <int BN, int NS>
-__global__ __launch_bounds__(512, 1) void igemm_bf16_ws_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
+__global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) void igemm_bf16_ws_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
                                                                 const unsigned short* __restrict__ wgt,
                                                                 unsigned short* __restrict__ out,
                                                                 const unsigned short* __restrict__ add_src,
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512, 1) void igemm_bf16_ws_kernel(IGemmGeom g, cons
   constexpr int LDS0 = (NS * STAGE) > (128 * CP) ? (NS * STAGE) : (128 * CP);
   constexpr int LDS_ELEMS = LDS0 > RED_ELEMS ? LDS0 : RED_ELEMS;
   constexpr int LPT = 4 + NBI;
-  static_assert(NS >= 3 && (NS - 2) * LPT <= 63, "ring depth");
+  static_assert(NS >= 2 && (NS - 2) * LPT <= 63, "ring depth");
   __shared__ __attribute__((aligned(1024))) unsigned short smem[LDS_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = wave >= 4;
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(512, 1) void igemm_bf16_ws_kernel(IGemmGeom g, cons
       const int younger = min(nk - 1 - t, NS - 2);
       if constexpr (NS >= 5) { if (younger == 3) wait_vm<3 * LPT>(); }
       if constexpr (NS >= 4) { if (younger == 2) wait_vm<2 * LPT>(); }
-      if (younger == 1) wait_vm<1 * LPT>();
+      if constexpr (NS >= 3) { if (younger == 1) wait_vm<1 * LPT>(); }
       if (younger == 0) wait_vm<0>();
       asm volatile("s_barrier" ::: "memory");                    // B_t
       if (t + NS - 1 < nk) issue(t + NS - 1, buf == 0 ? NS - 1 : buf - 1);
@@ -956,7 +956,7 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
     // CREID_IGEMM_WS=1: warp-specialised kernel (512 threads, producer / consumer waves), ring depth
     // CREID_IGEMM_WS_STAGES (3 or 4)
     static const int use_ws = [] { const char* e = getenv("CREID_IGEMM_WS"); return e ? atoi(e) : 1; }();
-    static const int ws_stages = [] { const char* e = getenv("CREID_IGEMM_WS_STAGES"); int v = e ? atoi(e) : 0; return v == 4 ? 4 : 3; }();
+    static const int ws_stages = [] { const char* e = getenv("CREID_IGEMM_WS_STAGES"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 3; }();
     // measured per layer (profiles/r01_igemm_ws_sweep.md): the split wins 8-17% on the long-k 64-wide tiles
     // (3x3 convs, K >= 1152) and loses wherever its 72-96 KB ring costs a resident workgroup (all 128-wide tiles)
     if (use_ws == 2 || (use_ws == 1 && bn == 64 && g.K >= 1024)) {
@@ -965,8 +965,8 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid, block_ws, 0, s, g, (const unsigned short*)src,           \
                      (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n, \
                      bnred)
-      if (bn == 128) { if (ws_stages == 4) CREID_WS_LAUNCH(128, 4); else CREID_WS_LAUNCH(128, 3); }
-      else { if (ws_stages == 4) CREID_WS_LAUNCH(64, 4); else CREID_WS_LAUNCH(64, 3); }
+      if (bn == 128) { if (ws_stages == 4) CREID_WS_LAUNCH(128, 4); else if (ws_stages == 2) CREID_WS_LAUNCH(128, 2); else CREID_WS_LAUNCH(128, 3); }
+      else { if (ws_stages == 4) CREID_WS_LAUNCH(64, 4); else if (ws_stages == 2) CREID_WS_LAUNCH(64, 2); else CREID_WS_LAUNCH(64, 3); }
 #undef CREID_WS_LAUNCH
       return (int)hipGetLastError();
     }
