@@ -75,6 +75,38 @@ def igemm_roofline(B, H, W, time_kernel, reps=5):
     return tot_flop / (tot_ms * 1e-3) / 1e12, tot_ms, worst[:3], worst[-3:]
 
 
+def hbm_stage_rates(time_kernel, B, H, W):
+    """Achieved GB/s of the bandwidth-bound passes of the step on their largest instance (layer1 block output,
+    [B*H/4*W/4, 256] bf16): BN apply (+residual, ReLU), BN backward (reduce + finalize + apply), and Adam over the
+    flat parameter buffer -- the HBM side of the roofline report (peak 8 TB/s spec, ~6.3 TB/s achievable)."""
+    from . import layers as ly
+    from . import _lib as L
+    M, Cc = B * (H // 4) * (W // 4), 256
+    dev = "cuda"
+    x = torch.randn((M, Cc), device=dev).to(torch.bfloat16)
+    res = torch.randn((M, Cc), device=dev).to(torch.bfloat16)
+    g = torch.randn((M, Cc), device=dev).to(torch.bfloat16)
+    gamma, beta = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    y, mean, invstd = ly.bn2d_train_fwd(x, gamma, beta, rm, rv, residual=res, relu=True)
+    ss = torch.stack([gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    out = torch.empty_like(x)
+    lib = L.lib()
+    t_apply = time_kernel(lambda: L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(ss), L.ptr(res), 1, M, Cc, 1, L.ptr(out),
+                                                                  L.stream()), "bn2d_apply"), 20)
+    t_bwd = time_kernel(lambda: ly.bn2d_bwd(x, g, y, mean, invstd, gamma, want_gm=True), 20)
+    n = 25_600_000
+    p, gr, m1, v1 = (torch.zeros(n, device=dev) for _ in range(4))
+    hyper = torch.tensor([3.5e-4, 1.0, 0.1, 0.03], device=dev)
+    t_adam = time_kernel(lambda: L.check(lib.creid_adam_step_dev(L.ptr(p), L.ptr(gr), L.ptr(m1), L.ptr(v1), n, L.ptr(hyper),
+                                                                    0.9, 0.999, 1e-8, 5e-4, 1.0, L.stream()), "adam"), 10)
+    e = M * Cc * 2
+    return {"bn2d_apply_GBs": 3 * e / (t_apply * 1e-3) / 1e9,                 # read x, residual; write y
+            "bn2d_bwd_GBs": (3 * e + 3 * e + 2 * e) / (t_bwd * 1e-3) / 1e9,     # reduce: x,g,act; apply: x,g,act -> dx,gm
+            "adam_GBs": 7 * n * 4 / (t_adam * 1e-3) / 1e9,                     # read p,g,m,v; write p,m,v
+            "peak_GBs": 8000.0}
+
+
 def pmc_traffic(key):
     """Average HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc passes
     (profiles/r01_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, collected in their own runs); None if absent."""
@@ -176,6 +208,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
                            "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": tf / MFMA_BF16_TFLOPS, "traffic": pmc_traffic("igemm_family"),
                            "ms_per_step": ig_ms, "slowest_TFs": slow, "fastest_TFs": fast}
+        res["roofline_hbm_stages"] = hbm_stage_rates(time_kernel, P * K, H, W)
         if cpu_baseline_fn is not None:
             res["cpu_baseline"] = cpu_baseline_fn(P, K, H, W)
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
