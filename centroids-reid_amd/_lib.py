@@ -35,6 +35,8 @@ SIGNATURES = {
     "creid_loo_centroids_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "creid_triplet_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_triplet_bwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _f32, _p, _p]),
+    "creid_triplet_fwd_batched": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_triplet_bwd_batched": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _f32, _p, _p]),
     "creid_center_loss_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "creid_center_loss_bwd": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _f32, _p, _p, _p]),
     "creid_xent_ls": (C.c_int, [_p, _p, _i64, _i64, _f32, _f32, _p, _p, _p, _p]),

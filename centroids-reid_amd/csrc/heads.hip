@@ -67,6 +67,11 @@ __global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restr
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [D] anchor row, then [N] distances
   float* xa = sm;
   float* drow = sm + D;
+  {                                                            // blockIdx.y = independent problem (centroid round)
+    const int64_t bo = (int64_t)blockIdx.y * N;
+    x += bo * D; labels += bo; dist_ap += bo; dist_an += bo; p_idx += bo; n_idx += bo;
+    if (dist_row_out) dist_row_out += bo * N;
+  }
   const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xap = x + (int64_t)a * D;
   float saa = 0.f;
@@ -121,6 +126,12 @@ __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restri
                                                            const uint8_t* __restrict__ mask, int N, float margin,
                                                            float* __restrict__ out, float* __restrict__ coef) {
   __shared__ float s[4][4];
+  {
+    const int64_t bo = (int64_t)blockIdx.y * N;
+    dist_ap += bo; dist_an += bo; out += (int64_t)blockIdx.y * 4;
+    if (mask) mask += bo;
+    if (coef) coef += bo;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float cnt = 0.f;
   for (int a = tid; a < N; a += 256) cnt += (!mask || mask[a]) ? 1.f : 0.f;
@@ -174,6 +185,10 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
   int* t_other = reinterpret_cast<int*>(sm);           // [<= 4N] capacity 4 terms per anchor
   float* t_w = sm + 4 * N;
   __shared__ int n_terms;
+  {
+    const int64_t bo = (int64_t)blockIdx.y * N;
+    x += bo * D; dist_ap += bo; dist_an += bo; p_idx += bo; n_idx += bo; coef += bo; dx += bo * D;
+  }
   const int r = blockIdx.x;
   if (threadIdx.x == 0) {
     int k = 0;
@@ -259,15 +274,40 @@ __global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict
   const bool on = row_loss[b] >= 1e-12f && row_loss[b] <= 1e12f;
   const float* c = centers + y * D;
   const float* xb = x + (int64_t)b * D;
+  // members of this row's class (in batch order) are listed once in LDS instead of being re-discovered by every
+  // thread for every feature: [0] = first occurrence decides which workgroup owns the class's center gradient
+  __shared__ int s_members[1024];
+  __shared__ unsigned char s_flag[1024];
+  __shared__ int s_nmem, s_first;
+  const bool listed = B <= 1024;
+  if (listed) {
+    for (int t = threadIdx.x; t < B; t += 256)
+      s_flag[t] = (labels[t] == y) ? ((row_loss[t] >= 1e-12f && row_loss[t] <= 1e12f) ? 2 : 1) : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int n = 0, first = -1;
+      for (int t = 0; t < B; ++t) {
+        if (s_flag[t] && first < 0) first = t;
+        if (s_flag[t] == 2) s_members[n++] = t;
+      }
+      s_nmem = n; s_first = first;
+    }
+    __syncthreads();
+  }
   bool first = true;
-  for (int t = 0; t < b; ++t) first = first && (labels[t] != y);
+  if (listed) first = s_first == b;
+  else for (int t = 0; t < b; ++t) first = first && (labels[t] != y);
   for (int d = threadIdx.x; d < D; d += 256) {
     const float cv = c[d];
     if (dx) dx[(int64_t)b * D + d] += on ? g * (xb[d] - cv) : 0.f;
     if (first && dcenters) {
       float acc = 0.f;
-      for (int t = b; t < B; ++t)
-        if (labels[t] == y && row_loss[t] >= 1e-12f && row_loss[t] <= 1e12f) acc += cv - x[(int64_t)t * D + d];
+      if (listed) {
+        for (int k = 0; k < s_nmem; ++k) acc += cv - x[(int64_t)s_members[k] * D + d];
+      } else {
+        for (int t = b; t < B; ++t)
+          if (labels[t] == y && row_loss[t] >= 1e-12f && row_loss[t] <= 1e12f) acc += cv - x[(int64_t)t * D + d];
+      }
       dcenters[y * D + d] += g * acc;
     }
   }
@@ -537,29 +577,42 @@ int creid_loo_centroids_bwd(const float* dcentroids, const uint8_t* is_real, int
   CREID_LAUNCH_RET();
 }
 
-int creid_triplet_fwd(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t N, int64_t D,
-                      float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx, float* coef,
-                      float* out4, float* dist_mat, void* stream) {
-  CREID_CHECK_ARG(x && labels && dist_ap && dist_an && p_idx && n_idx && out4 && N > 0 && D > 0);
-  if (D % 4 != 0) return CREID_E_SHAPE;
+int creid_triplet_fwd_batched(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t nb, int64_t N,
+                              int64_t D, float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx,
+                              float* coef, float* out4, float* dist_mat, void* stream) {
+  CREID_CHECK_ARG(x && labels && dist_ap && dist_an && p_idx && n_idx && out4 && N > 0 && D > 0 && nb > 0);
+  if (D % 4 != 0 || nb > 65535) return CREID_E_SHAPE;
   const size_t smem = (size_t)(D + N) * sizeof(float);
   if (smem > 64 * 1024) return CREID_E_SHAPE;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(triplet_mine_kernel, dim3((unsigned)N), dim3(TM_T), smem, s, x, labels, (int)N, (int)D, dist_ap,
-                     dist_an, p_idx, n_idx, dist_mat);
-  hipLaunchKernelGGL(triplet_loss_kernel, dim3(1), dim3(256), 0, s, dist_ap, dist_an, anchor_mask, (int)N, margin,
-                     out4, coef);
+  hipLaunchKernelGGL(triplet_mine_kernel, dim3((unsigned)N, (unsigned)nb), dim3(TM_T), smem, s, x, labels, (int)N, (int)D,
+                     dist_ap, dist_an, p_idx, n_idx, dist_mat);
+  hipLaunchKernelGGL(triplet_loss_kernel, dim3(1, (unsigned)nb), dim3(256), 0, s, dist_ap, dist_an, anchor_mask, (int)N,
+                     margin, out4, coef);
+  CREID_LAUNCH_RET();
+}
+
+int creid_triplet_fwd(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t N, int64_t D,
+                      float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx, float* coef,
+                      float* out4, float* dist_mat, void* stream) {
+  return creid_triplet_fwd_batched(x, labels, anchor_mask, 1, N, D, margin, dist_ap, dist_an, p_idx, n_idx, coef, out4,
+                                   dist_mat, stream);
+}
+
+int creid_triplet_bwd_batched(const float* x, int64_t nb, int64_t N, int64_t D, const float* dist_ap, const float* dist_an,
+                              const int32_t* p_idx, const int32_t* n_idx, const float* coef, const float* gscale_dev,
+                              float gscale, float* dx_accum, void* stream) {
+  CREID_CHECK_ARG(x && dist_ap && dist_an && p_idx && n_idx && coef && dx_accum && N > 0 && D > 0 && nb > 0);
+  if ((size_t)N * 8 * sizeof(float) > 48 * 1024 || nb > 65535) return CREID_E_SHAPE;
+  hipLaunchKernelGGL(triplet_bwd_kernel, dim3((unsigned)N, (unsigned)nb), dim3(256), (size_t)N * 8 * sizeof(float),
+                     as_stream(stream), x, (int)N, (int)D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum);
   CREID_LAUNCH_RET();
 }
 
 int creid_triplet_bwd(const float* x, int64_t N, int64_t D, const float* dist_ap, const float* dist_an,
                       const int32_t* p_idx, const int32_t* n_idx, const float* coef, const float* gscale_dev,
                       float gscale, float* dx_accum, void* stream) {
-  CREID_CHECK_ARG(x && dist_ap && dist_an && p_idx && n_idx && coef && dx_accum && N > 0 && D > 0);
-  if ((size_t)N * 8 * sizeof(float) > 48 * 1024) return CREID_E_SHAPE;
-  hipLaunchKernelGGL(triplet_bwd_kernel, dim3((unsigned)N), dim3(256), (size_t)N * 8 * sizeof(float), as_stream(stream), x,
-                     (int)N, (int)D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum);
-  CREID_LAUNCH_RET();
+  return creid_triplet_bwd_batched(x, 1, N, D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum, stream);
 }
 
 int creid_center_loss_fwd(const float* x, const int64_t* labels, const float* centers, int64_t B, int64_t C,

@@ -167,16 +167,19 @@ class CTLModel(ModelBase):
                 p.grad = torch.zeros_like(p)
             return p.grad
 
-        def triplet(emb, lab, N, o4, gscale, demb):
-            dap, dan, coef = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, **f32)
-            pi, ni = torch.empty(N, **i32), torch.empty(N, **i32)
-            L.check(lib.creid_triplet_fwd(L.ptr(emb), L.ptr(lab), None, N, D, margin, L.ptr(dap), L.ptr(dan), L.ptr(pi),
-                                          L.ptr(ni), L.ptr(coef), L.ptr(o4), None, st), "creid_triplet_fwd")
-            L.check(lib.creid_triplet_bwd(L.ptr(emb), N, D, L.ptr(dap), L.ptr(dan), L.ptr(pi), L.ptr(ni), L.ptr(coef), None,
-                                          float(gscale), L.ptr(demb), st), "creid_triplet_bwd")
+        def triplet(emb, lab, nb, N, o4, gscale, demb):
+            """nb stacked problems [nb, N, D] in one launch per kernel (mining, loss, backward)."""
+            dap, dan, coef = torch.empty(nb * N, **f32), torch.empty(nb * N, **f32), torch.empty(nb * N, **f32)
+            pi, ni = torch.empty(nb * N, **i32), torch.empty(nb * N, **i32)
+            L.check(lib.creid_triplet_fwd_batched(L.ptr(emb), L.ptr(lab), None, nb, N, D, margin, L.ptr(dap), L.ptr(dan),
+                                                  L.ptr(pi), L.ptr(ni), L.ptr(coef), L.ptr(o4), None, st),
+                    "creid_triplet_fwd_batched")
+            L.check(lib.creid_triplet_bwd_batched(L.ptr(emb), nb, N, D, L.ptr(dap), L.ptr(dan), L.ptr(pi), L.ptr(ni),
+                                                  L.ptr(coef), None, float(gscale), L.ptr(demb), st),
+                    "creid_triplet_bwd_batched")
             return dap, dan, pi, ni, coef                                       # keep alive until the caller returns
 
-        keep = [triplet(feat, labels, B, out4[0], hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT, dfeat)]       # :62-67
+        keep = [triplet(feat, labels, 1, B, out4[0], hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT, dfeat)]       # :62-67
 
         centers = self.center_loss.centers                                     # :71-73
         C_cent = centers.shape[0]
@@ -218,8 +221,7 @@ class CTLModel(ModelBase):
         lab = torch.cat((lt, lt), dim=1).contiguous()                          # [K, 2P]
         demb = torch.zeros((K, 2 * P, D), **f32)
         g_round = hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT / K
-        for i in range(K):
-            keep.append(triplet(emb[i], lab[i], 2 * P, out4[1 + i], g_round, demb[i]))
+        keep.append(triplet(emb, lab, K, 2 * P, out4[1:], g_round, demb))      # the K rounds: one launch per kernel
         dfeat.view(P, K, D).add_(demb[:, :P].transpose(0, 1))
         dcent = demb[:, P:].contiguous()
         L.check(lib.creid_loo_centroids_bwd(L.ptr(dcent), L.ptr(self._all_real_u8(B, dev)), P, K, D, L.ptr(dfeat), st),

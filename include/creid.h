@@ -115,6 +115,18 @@ int creid_triplet_bwd(const float* x, int64_t N, int64_t D, const float* dist_ap
                       const int32_t* p_idx, const int32_t* n_idx, const float* coef,
                       const float* gscale_dev, float gscale, float* dx_accum, void* stream);
 
+/* nb independent problems of the same size in one launch each (the K centroid rounds of
+ * train_ctl_model.py:112-148): every array of creid_triplet_fwd / _bwd gains a leading [nb] dimension
+ * (x [nb][N][D], labels / dist_* / *_idx / coef / anchor_mask [nb][N], out4 [nb][4], dx_accum [nb][N][D]). */
+int creid_triplet_fwd_batched(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t nb,
+                              int64_t N, int64_t D, float margin, float* dist_ap, float* dist_an,
+                              int32_t* p_idx, int32_t* n_idx, float* coef, float* out4, float* dist_mat,
+                              void* stream);
+int creid_triplet_bwd_batched(const float* x, int64_t nb, int64_t N, int64_t D, const float* dist_ap,
+                              const float* dist_an, const int32_t* p_idx, const int32_t* n_idx,
+                              const float* coef, const float* gscale_dev, float gscale, float* dx_accum,
+                              void* stream);
+
 /* losses/center_loss.py:26-46.  row_sq[b] = |x_b|^2 + |c_y|^2 - 2 x_b.c_y (unclamped, saved for bwd);
  * loss[0] = (sum_b clamp(row_sq[b],1e-12,1e12) + B*(C-1)*1e-12) / B. */
 int creid_center_loss_fwd(const float* x, const int64_t* labels, const float* centers, int64_t B,
