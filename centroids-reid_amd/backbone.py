@@ -477,7 +477,7 @@ class BackboneEngine:
         L.check(lib.creid_conv2d_wgrad_nhwc(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(self._grad_of(u.conv.weight)), 1,
                                             L.ptr(ws), nbytes, self.dt, st), "conv2d_wgrad")
 
-    def _dgrad(self, u, dy, B, H, W, add_src=None, bnred=None, stat_image_rows=0):
+    def _dgrad(self, u, dy, B, H, W, add_src=None, bnred=None, stat_image_rows=0, add_src_stride=1):
         """Data gradient.  bnred = (x, act, mean, invstd) of the BN layer that consumes the result: its column
         reduction is fused into the epilogue (bf16) and the partials are returned.  stat_image_rows = H*W when
         mean / invstd are per-(image, channel) (IBN), 0 for BatchNorm."""
@@ -490,7 +490,7 @@ class BackboneEngine:
             part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32)
             L.check(lib.creid_conv2d_dgrad_bnred_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src),
                                                       L.ptr(x), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(part),
-                                                      stat_image_rows, self.dt, st), "conv2d_dgrad_bnred")
+                                                      stat_image_rows, add_src_stride, self.dt, st), "conv2d_dgrad_bnred")
             return dx, part
         L.check(lib.creid_conv2d_dgrad_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src), self.dt, st),
                 "conv2d_dgrad")
@@ -533,8 +533,19 @@ class BackboneEngine:
             if b["ds"] is not None:
                 dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3)
                 self._wgrad(b["ds"], s["a_in"], dxd, B, s["hin"], s["win"])
-                tmp, _ = self._dgrad(b["ds"], dxd, B, s["hin"], s["win"])
-                g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt)
+                dsu = b["ds"]
+                if (dsu.stride == 2 and dsu.k == 1 and nxt is not None and self.fuse_bn_reduce
+                        and s["hin"] % 2 == 0 and s["win"] % 2 == 0):
+                    # stride-2 1x1 downsample: its data gradient lives on the even pixels only -- compute it as a
+                    # plain 1x1 GEMM over the OUTPUT grid and let the c1 dgrad epilogue scatter-add it
+                    dd, _, _ = _desc(B, s["h2"], s["w2"], dsu.cin, dsu.cout, 1, 1, 0)
+                    tmp = self._empty(B * s["h2"] * s["w2"], dsu.cin)
+                    L.check(lib.creid_conv2d_dgrad_nhwc(C.byref(dd), L.ptr(dxd), L.ptr(dsu.w_crsk), L.ptr(tmp), None,
+                                                        self.dt, st), "conv2d_dgrad(ds compact)")
+                    g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt, add_src_stride=2)
+                else:
+                    tmp, _ = self._dgrad(dsu, dxd, B, s["hin"], s["win"])
+                    g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt)
             else:
                 g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm, bnred=nxt)
         # stem

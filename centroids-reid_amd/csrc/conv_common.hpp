@@ -24,11 +24,13 @@ struct IGemmGeom {
   int N;              // output channels
   int check_bounds;   // 0: source is pre-padded (stem)
   float inv_ohow, inv_ow;   // 1/(OH*OW), 1/OW for fast_divmod (M < 2^24)
+  int add_compact;          // epilogue add_src is a stride-2 COMPACT tensor [B, OH/2, OW/2, N]: added at even (y, x) only
 };
 
 static inline void igemm_finish_geom(IGemmGeom& g) {
   g.inv_ohow = 1.0f / (float)(g.OH * g.OW);
   g.inv_ow = 1.0f / (float)g.OW;
+  g.add_compact = 0;
 }
 
 // Source pixel of output row (oy, ox) under tap (r, s); returns false when it falls outside.

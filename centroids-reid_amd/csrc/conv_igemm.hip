@@ -463,13 +463,24 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       uint4 v = *reinterpret_cast<const uint4*>(&smem[rl * CP + ch * 8]);
       const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
       if (add_src) {
-        const uint4 a = *reinterpret_cast<const uint4*>(add_src + off);
-        unsigned* vw = &v.x; const unsigned* aw = &a.x;
+        int64_t aoff = off;
+        bool has = true;
+        if (g.add_compact) {                                     // the stride-2 downsample branch's gradient, compact
+          int ab, arem, ay, ax;
+          fast_divmod(rr, g.OH * g.OW, g.inv_ohow, ab, arem);
+          fast_divmod(arem, g.OW, g.inv_ow, ay, ax);
+          has = ((ay | ax) & 1) == 0;
+          aoff = (int64_t)((ab * (g.OH >> 1) + (ay >> 1)) * (g.OW >> 1) + (ax >> 1)) * g.N + col0 + ch * 8;
+        }
+        if (has) {
+          const uint4 a = *reinterpret_cast<const uint4*>(add_src + aoff);
+          unsigned* vw = &v.x; const unsigned* aw = &a.x;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
-          const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
-          vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+            vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+          }
         }
       }
       *reinterpret_cast<uint4*>(out + off) = v;
@@ -745,13 +756,24 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       uint4 v = *reinterpret_cast<const uint4*>(&smem[rl * CP + ch * 8]);
       const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
       if (add_src) {
-        const uint4 a = *reinterpret_cast<const uint4*>(add_src + off);
-        unsigned* vw = &v.x; const unsigned* aw = &a.x;
+        int64_t aoff = off;
+        bool has = true;
+        if (g.add_compact) {                                     // the stride-2 downsample branch's gradient, compact
+          int ab, arem, ay, ax;
+          fast_divmod(rr, g.OH * g.OW, g.inv_ohow, ab, arem);
+          fast_divmod(arem, g.OW, g.inv_ow, ay, ax);
+          has = ((ay | ax) & 1) == 0;
+          aoff = (int64_t)((ab * (g.OH >> 1) + (ay >> 1)) * (g.OW >> 1) + (ax >> 1)) * g.N + col0 + ch * 8;
+        }
+        if (has) {
+          const uint4 a = *reinterpret_cast<const uint4*>(add_src + aoff);
+          unsigned* vw = &v.x; const unsigned* aw = &a.x;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
-          const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
-          vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+            vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+          }
         }
       }
       *reinterpret_cast<uint4*>(out + off) = v;
@@ -1059,12 +1081,14 @@ int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void
 /* dgrad with the NEXT BatchNorm-backward's column reduction fused into the epilogue (bf16 only). */
 int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
                                   const void* add_src, const void* bn_x, const void* bn_act, const float* bn_mean,
-                                  const float* bn_invstd, float* bn_partial, int64_t bn_stat_image_rows, int dtype,
-                                  void* stream) {
+                                  const float* bn_invstd, float* bn_partial, int64_t bn_stat_image_rows,
+                                  int add_src_stride, int dtype, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   CREID_CHECK_ARG(dy && w_crsk && dx && bn_x && bn_mean && bn_invstd && bn_partial && bn_stat_image_rows >= 0);
   if (bn_stat_image_rows % 128 != 0) return CREID_E_SHAPE;
+  if (add_src_stride != 1 && add_src_stride != 2) return CREID_E_ARG;
+  if (add_src_stride == 2 && (!add_src || d->in_h % 2 || d->in_w % 2)) return CREID_E_SHAPE;
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
   if (dtype != CREID_BF16 || !use_dma) return CREID_E_DTYPE;
   IGemmGeom g;
@@ -1074,6 +1098,7 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
   g.K = (int)(d->kh * d->kw * d->out_c); g.N = (int)d->in_c; g.check_bounds = 1;
   igemm_finish_geom(g);
   static const int prefetch = [] { const char* e = getenv("CREID_BNRED_PREFETCH"); return e ? atoi(e) : 1; }();
+  g.add_compact = add_src_stride == 2;
   BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial, prefetch, (int)(bn_stat_image_rows / 128)};
   return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream), br);
 }

@@ -148,7 +148,7 @@ def bn2d_bwd(x, g, act, mean, invstd, gamma, want_gm=False):
     return dx, dgamma, dbeta, gm
 
 
-def conv2d_dgrad_bnred(dy, w_crsk, in_hw, stride, pad, bn_x, bn_act, mean, invstd, add_src=None):
+def conv2d_dgrad_bnred(dy, w_crsk, in_hw, stride, pad, bn_x, bn_act, mean, invstd, add_src=None, add_src_stride=1):
     """dgrad + fused column reduction of the next BN backward -> (dx, partial [rows, 2, Cin])."""
     L.require_gpu(dy, w_crsk, bn_x)
     B, oh, ow, cout = dy.shape
@@ -159,6 +159,6 @@ def conv2d_dgrad_bnred(dy, w_crsk, in_hw, stride, pad, bn_x, bn_act, mean, invst
     rows = L.lib().creid_bn2d_bwd_rows(B * H * W)
     part = torch.empty((rows, 2, cin), dtype=torch.float32, device=dy.device)
     L.check(L.lib().creid_conv2d_dgrad_bnred_nhwc(C.byref(d), L.ptr(dy), L.ptr(w_crsk), L.ptr(dx), L.ptr(add_src), L.ptr(bn_x),
-                                                  L.ptr(bn_act), L.ptr(mean), L.ptr(invstd), L.ptr(part), 0, _dt(dy), L.stream()),
+                                                  L.ptr(bn_act), L.ptr(mean), L.ptr(invstd), L.ptr(part), 0, add_src_stride, _dt(dy), L.stream()),
             "conv2d_dgrad_bnred")
     return dx, part

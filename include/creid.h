@@ -206,11 +206,14 @@ int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void
  * (bf16 only): dx is g = dL/da of the layer whose raw conv output is bn_x and post-ReLU activation bn_act
  * (nullable); bn_partial[ceil(M/128)][2][in_c] receives (sum dy, sum dy*xhat), dy = g*[bn_act > 0].
  * bn_stat_image_rows = 0: bn_mean/bn_invstd are float[in_c] (BatchNorm); = in_h*in_w (a multiple of 128): they
- * are float[batch][in_c], per-(image, channel) statistics of an IBN layer (creid_ibn_bwd, partial_ready). */
+ * are float[batch][in_c], per-(image, channel) statistics of an IBN layer (creid_ibn_bwd, partial_ready).
+ * add_src_stride = 1: add_src is [batch, in_h, in_w, in_c]; = 2: add_src is the COMPACT gradient of a stride-2
+ * 1x1 downsample branch, [batch, in_h/2, in_w/2, in_c], added at even (y, x) only (Bottleneck with stride,
+ * resnet.py:87-88: its full-resolution data gradient is never materialised). */
 int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
                                   const void* add_src, const void* bn_x, const void* bn_act,
                                   const float* bn_mean, const float* bn_invstd, float* bn_partial,
-                                  int64_t bn_stat_image_rows, int dtype, void* stream);
+                                  int64_t bn_stat_image_rows, int add_src_stride, int dtype, void* stream);
 /* weight gradient into the fp32 OIHW tensor (the reference's nn.Parameter layout), optionally
  * accumulating; the pixel reduction is split over workgroups through `ws`. */
 size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype);

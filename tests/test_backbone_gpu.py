@@ -325,6 +325,15 @@ def test_dgrad_fused_bn_reduction(case):
     np.testing.assert_allclose(got[1].cpu().numpy(), s2.cpu().numpy(), rtol=1e-4, atol=2e-2)
     dx2, part2 = ly.conv2d_dgrad_bnred(gy, crsk, (H, W), stride, pad, bn_x, None, mean, invstd)    # no mask, no add
     np.testing.assert_allclose(part2.sum(0)[0].cpu().numpy(), dx2.float().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-2)
+    if H % 2 == 0 and W % 2 == 0:
+        # compact stride-2 add_src (the downsample branch's gradient on the even pixels) == dense add of its zero-upsampling
+        comp = torch.from_numpy(rng.standard_normal((B, H // 2, W // 2, cin)).astype(np.float32)).to(torch.bfloat16).cuda()
+        dense = torch.zeros((B, H, W, cin), dtype=torch.bfloat16, device="cuda")
+        dense[:, ::2, ::2] = comp
+        ref3, pref3 = ly.conv2d_dgrad_bnred(gy, crsk, (H, W), stride, pad, bn_x, act, mean, invstd, add_src=dense)
+        dx3, part3 = ly.conv2d_dgrad_bnred(gy, crsk, (H, W), stride, pad, bn_x, act, mean, invstd, add_src=comp,
+                                           add_src_stride=2)
+        assert torch.equal(dx3, ref3) and torch.equal(part3, pref3)
 
 
 @pytest.mark.parametrize("arch,H,W,B", [("resnet50", 96, 80, 3), ("resnet50_ibn_a", 160, 96, 2)])
