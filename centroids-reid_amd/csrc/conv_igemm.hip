@@ -325,10 +325,27 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   };
   typedef const void __attribute__((address_space(1)))* gptr_t;
   typedef void __attribute__((address_space(3)))* lptr_t;
+  // The stem (7x7 s2 on the pre-padded NHWC4 image): a tap is one kernel row = 32 elements = 64 bytes, so a
+  // 64-wide k-tile holds TWO taps; source chunk sc of the 128-byte tile row comes from kernel row 2t + (sc >> 2)
+  // at byte offset (sc & 3) * 16.  No bounds checks (padding), the pointer just advances two image rows per k-tile.
+  const bool stem = g.log2span == 5;
+  const int stem_step = 2 * g.SW * g.pitch;
+  if (stem) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sc = gch[i] >> 3;
+      aptr[i] = vm[i] ? src + (int64_t)(bpix[i] + (oy[i] * 2 + (sc >> 2)) * g.SW + ox[i] * 2) * g.pitch + (sc & 3) * 8 : zpage;
+      amul[i] = vm[i] ? 1 : 0;
+    }
+  }
   auto issue = [&](int t, int buf) {
-    const int tap = (t * BK) >> g.log2span;
-    if (tap != cur_tap) { set_tap(); cur_tap = tap; }
-    const int c = (t * BK) & span_mask;
+    int c;
+    if (stem) c = t * stem_step;
+    else {
+      const int tap = (t * BK) >> g.log2span;
+      if (tap != cur_tap) { set_tap(); cur_tap = tap; }
+      c = (t * BK) & span_mask;
+    }
     unsigned short* la = smem + buf * STAGE + wave * 512;      // + i * 2048 elements (4 KiB) per instruction
     unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
 #pragma unroll
@@ -973,7 +990,9 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   const int tiles_n = g.N / bn;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
-  if (dtype == CREID_BF16 && use_dma && g.log2span >= 6) {
+  const bool stem_geom = g.log2span == 5 && !g.transposed && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0;
+  static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
+  if (dtype == CREID_BF16 && use_dma && (g.log2span >= 6 || (stem_geom && stem_dma))) {
     if (g.K % 64 != 0) return CREID_E_SHAPE;
     // CREID_IGEMM_WS=1: warp-specialised kernel (512 threads, producer / consumer waves), ring depth
     // CREID_IGEMM_WS_STAGES (3 or 4)
@@ -981,7 +1000,7 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
     static const int ws_stages = [] { const char* e = getenv("CREID_IGEMM_WS_STAGES"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 3; }();
     // measured per layer (profiles/r01_igemm_ws_sweep.md): the split wins 8-17% on the long-k 64-wide tiles
     // (3x3 convs, K >= 1152) and loses wherever its 72-96 KB ring costs a resident workgroup (all 128-wide tiles)
-    if (use_ws == 2 || (use_ws == 1 && bn == 64 && g.K >= 1024)) {
+    if (g.log2span >= 6 && (use_ws == 2 || (use_ws == 1 && bn == 64 && g.K >= 1024))) {
       const dim3 block_ws(512);
 #define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
   hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid, block_ws, 0, s, g, (const unsigned short*)src,           \
