@@ -259,7 +259,12 @@ __global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) v
       }
       if (m < m_end) {
         int iy, ix;
-        if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))
+        if (g.log2span == 5) {
+          // stem: a tap is one 32-element kernel row, so the TN-wide tile spans TN/32 taps: column col of the
+          // tile row lies in kernel row tr + (col >> 5) at element (col & 31); pre-padded image, no bounds checks
+          const int col = cc + bcol[i];
+          p = x + (int64_t)((b * g.SH + oy * 2 + tr + (col >> 5)) * g.SW + ox * 2) * g.pitch + (col & 31);
+        } else if (igemm_src_pixel(g, oy, ox, tr, ts, iy, ix))
           p = x + (int64_t)((b * g.SH + iy) * g.SW + ix) * g.pitch + cc + bcol[i];
       }
       __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(lb + i * 2048), 16, 0, 0);
@@ -543,7 +548,9 @@ static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
   dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(256);
   static const int use_dma = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
   static const int stages = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
-  if (dtype == CREID_BF16 && use_dma && (1 << g.log2span) >= TN) {
+  static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
+  const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0 && stem_dma;
+  if (dtype == CREID_BF16 && use_dma && ((1 << g.log2span) >= TN || stem_geom)) {
     if (stages == 2)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2>), grid, block, 0, s, g, (const unsigned short*)dy,
                          (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
