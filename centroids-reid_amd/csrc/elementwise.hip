@@ -73,22 +73,33 @@ __global__ __launch_bounds__(1024) void bn2d_finalize_kernel(const float* __rest
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
   }
-  red[rg][0][cl] = s1; red[rg][1][cl] = s2;
+  // a wave holds 4 row groups x 16 channels: fold them with two shuffles, then 16 per-wave partials meet in LDS
+  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+  if ((threadIdx.x & 63) < 16) { red[threadIdx.x >> 6][0][cl] = s1; red[threadIdx.x >> 6][1][cl] = s2; }
+  // per-channel parameters are fetched before the barrier (off the dependent tail of this latency-bound kernel)
+  float p_gamma = 1.f, p_beta = 0.f, p_rm = 0.f, p_rv = 0.f;
+  if (rg == 0 && c < C) {
+    if (gamma) p_gamma = gamma[c];
+    if (beta) p_beta = beta[c];
+    if (rmean) p_rm = rmean[c];
+    if (rvar) p_rv = rvar[c];
+  }
   __syncthreads();
   if (rg == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    for (int q = 0; q < 16; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float mu = (float)mean, is = (float)(1.0 / sqrt(var + (double)eps));
     mean_out[c] = mu;
     invstd_out[c] = is;
-    const float sc = is * (gamma ? gamma[c] : 1.f);          // y = x * scale + shift
-    scale_shift[c] = sc; scale_shift[C + c] = (beta ? beta[c] : 0.f) - mu * sc;
-    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+    const float sc = is * p_gamma;                           // y = x * scale + shift
+    scale_shift[c] = sc; scale_shift[C + c] = p_beta - mu * sc;
+    if (rmean) rmean[c] = (1.f - momentum) * p_rm + momentum * (float)mean;
+    if (rvar) rvar[c] = (1.f - momentum) * p_rv + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
   }
 }
 
@@ -247,21 +258,30 @@ __global__ __launch_bounds__(1024) void bn2d_bwd_finalize_kernel(const float* __
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
   }
-  red[rg][0][cl] = s1; red[rg][1][cl] = s2;
+  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+  if ((threadIdx.x & 63) < 16) { red[threadIdx.x >> 6][0][cl] = s1; red[threadIdx.x >> 6][1][cl] = s2; }
+  float p_mu = 0.f, p_is = 0.f, p_g = 1.f, p_db = 0.f, p_dg = 0.f;
+  if (rg == 0 && c < C) {
+    p_mu = mean[c]; p_is = invstd[c];
+    if (gamma) p_g = gamma[c];
+    if (dbeta) p_db = dbeta[c];
+    if (dgamma) p_dg = dgamma[c];
+  }
   __syncthreads();
   if (rg == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
-#pragma unroll 8
-    for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
     // dx = k1*(dy - a1 - xhat*a2) = A*dy + B*x + Cc  with per-channel A, B, Cc
     const float invM = (float)(1.0 / count);
-    const float mu = mean[c], is = invstd[c], k1 = (gamma ? gamma[c] : 1.f) * is;
+    const float mu = p_mu, is = p_is, k1 = p_g * is;
     const float a1 = (float)s1 * invM, a2 = (float)s2 * invM;
     sums[c] = k1;
     sums[C + c] = -k1 * is * a2;
     sums[2 * C + c] = -k1 * a1 + k1 * is * a2 * mu;
-    if (dbeta) dbeta[c] += (float)s1;
-    if (dgamma) dgamma[c] += (float)s2;
+    if (dbeta) dbeta[c] = p_db + (float)s1;
+    if (dgamma) dgamma[c] = p_dg + (float)s2;
   }
 }
 
