@@ -1000,7 +1000,8 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
     static const int ws_stages = [] { const char* e = getenv("CREID_IGEMM_WS_STAGES"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 3; }();
     // measured per layer (profiles/r01_igemm_ws_sweep.md): the split wins 8-17% on the long-k 64-wide tiles
     // (3x3 convs, K >= 1152) and loses wherever its 72-96 KB ring costs a resident workgroup (all 128-wide tiles)
-    if (g.log2span >= 6 && (use_ws == 2 || (use_ws == 1 && bn == 64 && g.K >= 1024))) {
+    static const int ws_min_k = [] { const char* e = getenv("CREID_IGEMM_WS_MIN_K"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    if (g.log2span >= 6 && (use_ws == 2 || (use_ws == 1 && bn == 64 && g.K >= ws_min_k))) {
       const dim3 block_ws(512);
 #define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
   hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid, block_ws, 0, s, g, (const unsigned short*)src,           \
