@@ -234,9 +234,57 @@ __global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) v
     fast_divmod(m, g.OH * g.OW, g.inv_ohow, pb[i], rem);
     fast_divmod(rem, g.OW, g.inv_ow, poy[i], pox[i]);
   }
+  // LINEAR fast path (every 1x1 / 3x3 layer of the backbone): with 64 | OW-steps and SH == OH*stride the gathered
+  // source pixel of a row advances by a CONSTANT number of elements per k-step -- image wrap included -- so both
+  // operands keep running pointers (one 64-bit add per DMA instruction) and only the row's validity
+  // (split end, vertical bound; the horizontal bound never changes) is re-evaluated.  PMC before this change:
+  // 150 VALU + 164 SALU per k-step and wave against 16 MFMAs.
+  const bool linear = inc_ok && g.log2span >= 6 && !g.transposed && g.SH == g.OH * g.stride && g.SW == g.OW * g.stride;
+  const unsigned short* pa[NIA];
+  const unsigned short* pbx[NIB];
+  int ma[NIA], mbr[NIB], iy0[NIB];
+  bool xok[NIB];
+  const int a_inc = WKS * NCO, b_inc = dy_rows * g.stride * g.SW * g.pitch;
+  if (linear) {
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      ma[i] = m_begin + arow[i];
+      pa[i] = dy + (int64_t)ma[i] * NCO + co0 + acol[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      mbr[i] = m_begin + brow[i];
+      int bb, rem, oy, ox;                                      // un-clamped coordinates of the (possibly virtual) row
+      fast_divmod(mbr[i], g.OH * g.OW, g.inv_ohow, bb, rem);
+      fast_divmod(rem, g.OW, g.inv_ow, oy, ox);
+      poy[i] = oy;
+      iy0[i] = tr - g.pad;                                      // iy = poy*stride + iy0
+      const int ix = ox * g.stride + ts - g.pad;
+      xok[i] = (unsigned)ix < (unsigned)g.SW;
+      pbx[i] = x + ((int64_t)(bb * g.SH + oy * g.stride + iy0[i]) * g.SW + ix) * g.pitch + cc + bcol[i];
+    }
+  }
   auto issue = [&](int mb, int buf) {
     unsigned short* la = smem + buf * STAGE + wave * 512;
     unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
+    if (linear) {
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        const unsigned short* p = (ma[i] < m_end) ? pa[i] : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(la + i * 2048), 16, 0, 0);
+        pa[i] += a_inc; ma[i] += WKS;
+      }
+#pragma unroll
+      for (int i = 0; i < NIB; ++i) {
+        const bool ok = mbr[i] < m_end && xok[i] && (unsigned)(poy[i] * g.stride + iy0[i]) < (unsigned)g.SH;
+        const unsigned short* p = ok ? pbx[i] : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(lb + i * 2048), 16, 0, 0);
+        pbx[i] += b_inc; mbr[i] += WKS;
+        poy[i] += dy_rows;
+        if (poy[i] >= g.OH) poy[i] -= g.OH;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
       const int m = mb + arow[i];
