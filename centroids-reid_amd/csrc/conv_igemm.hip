@@ -339,21 +339,25 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     }
   }
   auto issue = [&](int t, int buf) {
-    int c;
-    if (stem) c = t * stem_step;
-    else {
+    // running pointers: inside a tap every k-tile advances the A rows by 64 channels (0 for the zero page), the
+    // stem by two image rows, the weight rows by 64 columns -- no per-tile multiplies
+    if (!stem) {
       const int tap = (t * BK) >> g.log2span;
       if (tap != cur_tap) { set_tap(); cur_tap = tap; }
-      c = (t * BK) & span_mask;
     }
     unsigned short* la = smem + buf * STAGE + wave * 512;      // + i * 2048 elements (4 KiB) per instruction
     unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
+    const int a_step = stem ? stem_step : BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + c * amul[i]), (lptr_t)(la + i * 2048), 16, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)aptr[i], (lptr_t)(la + i * 2048), 16, 0, 0);
+      aptr[i] += amul[i] ? a_step : 0;
+    }
 #pragma unroll
-    for (int i = 0; i < NBI; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wp[i] + t * BK), (lptr_t)(lb + i * 2048), 16, 0, 0);
+    for (int i = 0; i < NBI; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(lb + i * 2048), 16, 0, 0);
+      wp[i] += BK;
+    }
   };
 
   f32x16 acc[2][TNW];
@@ -633,15 +637,18 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
           amul[i] = ok ? 1 : 0;
         }
       }
-      const int c = (t * BK) & span_mask;
       unsigned short* la = smem + buf * STAGE + cw * 512;
       unsigned short* lb = smem + buf * STAGE + TILE_A + cw * 512;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + c * amul[i]), (lptr_t)(la + i * 2048), 16, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)aptr[i], (lptr_t)(la + i * 2048), 16, 0, 0);
+        aptr[i] += amul[i] ? BK : 0;                             // running pointers (see igemm_bf16_dma_kernel)
+      }
 #pragma unroll
-      for (int i = 0; i < NBI; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wp[i] + t * BK), (lptr_t)(lb + i * 2048), 16, 0, 0);
+      for (int i = 0; i < NBI; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(lb + i * 2048), 16, 0, 0);
+        wp[i] += BK;
+      }
     };
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
