@@ -557,6 +557,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// 3x3 layers with few splits: one workgroup per output channel.  The partial row [tap][c] (K floats, contiguous) is
+// summed over the splits with coalesced reads, transposed to OIHW's [c][tap] order in LDS, and leaves as ONE
+// contiguous K-float run (the generic kernel writes those 4-byte values 36 bytes apart).
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __restrict__ ws, int splits, int NCO, int K,
+                                                                int cin, int taps, float* __restrict__ dw_oihw,
+                                                                int accumulate) {
+  extern __shared__ float tr_lds[];                              // [K] in (c, tap) order
+  const int co = blockIdx.x;
+  const int64_t total = (int64_t)NCO * K;
+  const float* src = ws + (int64_t)co * K;
+  for (int e = threadIdx.x; e < K; e += 256) {
+    float a0 = 0.f, a1 = 0.f;
+    int sp = 0;
+    for (; sp + 1 < splits; sp += 2) { a0 += src[(int64_t)sp * total + e]; a1 += src[(int64_t)(sp + 1) * total + e]; }
+    if (sp < splits) a0 += src[(int64_t)sp * total + e];
+    const int tap = e / cin, c = e - tap * cin;
+    tr_lds[c * taps + tap] = a0 + a1;
+  }
+  __syncthreads();
+  float* dst = dw_oihw + (int64_t)co * K;
+  for (int e = threadIdx.x; e < K; e += 256) dst[e] = accumulate ? dst[e] + tr_lds[e] : tr_lds[e];
+}
+
 // ------------------------------------------------------------------------------------ host
 static int ilog2x(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return ((1LL << l) == v) ? l : -1; }
 
@@ -629,6 +652,12 @@ static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO,
   else if (p.tm == 128 && p.tn == 64) launch_wgrad_t<128, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
   else if (p.tm == 64 && p.tn == 128) launch_wgrad_t<64, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
   else launch_wgrad_t<64, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+  if (kh * kw == 9 && cpitch == cin && (1 << g.log2span) == cin && kw_taps == kw && p.splits <= 16 &&
+      (size_t)g.K * sizeof(float) <= 48 * 1024) {
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)NCO), dim3(256), (size_t)g.K * sizeof(float), s,
+                       (const float*)ws, p.splits, NCO, g.K, cin, 9, dw, accumulate);
+    return (int)hipGetLastError();
+  }
   const int64_t total4 = (int64_t)NCO * g.K / 4;
 #define CREID_WRED(SL_)                                                                                              \
   hipLaunchKernelGGL(wgrad_reduce_kernel<SL_>, dim3((unsigned)((total4 + 256 / SL_ - 1) / (256 / SL_))), dim3(256), 0, s, \
