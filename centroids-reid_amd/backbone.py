@@ -226,9 +226,10 @@ class BackboneEngine:
                 self.blocks.append(u)
         self.weights_dirty = True
         self._ws = None
-        # weight gradients are off the critical path of backward: run them on a second HIP stream (a parallel
-        # branch of the captured graph) so they fill the CUs the latency-bound dgrad / BN chain leaves idle
-        self.wgrad_stream = os.environ.get("CREID_WGRAD_STREAM", "1") == "1"
+        # CREID_WGRAD_STREAM=1: weight gradients on a second HIP stream (a parallel branch of the captured graph).
+        # Measured r01: the concurrent dgrad / wgrad kernels contend for LDS and L2 and the step gets 6 % SLOWER
+        # (7970 vs 8480 img/s), so the default is one stream.
+        self.wgrad_stream = os.environ.get("CREID_WGRAD_STREAM", "0") == "1"
         self._side = None
         self._keep = []
         self.saved = None
