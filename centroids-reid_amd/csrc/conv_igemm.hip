@@ -986,6 +986,11 @@ static int ilog2_exact(int64_t v) {
   return ((1LL << l) == v) ? l : -1;
 }
 
+static int ws_stages_env() {
+  static const int v = [] { const char* e = getenv("CREID_IGEMM_WS_STAGES"); int x = e ? atoi(e) : 0; return (x == 2 || x == 4) ? x : 3; }();
+  return v;
+}
+
 static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src,
                         float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}) {
   const int tiles_m = (g.M + 127) / 128;
@@ -1001,14 +1006,14 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
   if (dtype == CREID_BF16 && use_dma && (g.log2span >= 6 || (stem_geom && stem_dma))) {
     if (g.K % 64 != 0) return CREID_E_SHAPE;
-    // CREID_IGEMM_WS=1: warp-specialised kernel (512 threads, producer / consumer waves), ring depth
-    // CREID_IGEMM_WS_STAGES (3 or 4)
     static const int use_ws = [] { const char* e = getenv("CREID_IGEMM_WS"); return e ? atoi(e) : 1; }();
-    static const int ws_stages = [] { const char* e = getenv("CREID_IGEMM_WS_STAGES"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 3; }();
-    // measured per layer (profiles/r01_igemm_ws_sweep.md): the split wins 8-17% on the long-k 64-wide tiles
-    // (3x3 convs, K >= 1152) and loses wherever its 72-96 KB ring costs a resident workgroup (all 128-wide tiles)
+
+    // Producer / consumer split everywhere (single-stream step, r01: +4 % from the long-k 64-wide tiles with a
+    // 3-deep ring, +2.4 % more from 2-deep rings -- two workgroups per CU -- on all other tiles; standalone sweeps in
+    // profiles/r01_igemm_ws_sweep.md).  CREID_IGEMM_WS=0: the 4-wave DMA kernel; =2: force CREID_IGEMM_WS_STAGES.
     static const int ws_min_k = [] { const char* e = getenv("CREID_IGEMM_WS_MIN_K"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-    if (g.log2span >= 6 && (use_ws == 2 || (use_ws == 1 && bn == 64 && g.K >= ws_min_k))) {
+    if (g.log2span >= 6 && use_ws >= 1) {
+      const int ws_stages = use_ws == 2 ? ws_stages_env() : ((bn == 64 && g.K >= ws_min_k) ? 3 : 2);
       const dim3 block_ws(512);
 #define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
   hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid, block_ws, 0, s, g, (const unsigned short*)src,           \
