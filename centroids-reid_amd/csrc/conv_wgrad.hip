@@ -180,8 +180,10 @@ __device__ __forceinline__ void tr_load2(unsigned addr, s16x4& lo, s16x4& hi) {
 template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NS-stage LDS ring (see igemm_bf16_dma_kernel: with two stages the loop runs at global->LDS latency).
-template <int TM, int TN, int NS>
-__global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
+// WS = true: 512 threads, waves 4-7 issue the DMA (producers), waves 0-3 read fragments and multiply (consumers),
+// one s_barrier per k-tile between them -- the split of igemm_bf16_ws_kernel.
+template <int TM, int TN, int NS, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024) ? (WS ? 4 : 2) : (WS ? 2 : 1)) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
                                                                  const unsigned short* __restrict__ x, int NCO,
                                                                  float* __restrict__ ws, int tiles_k, int m_per_split) {
   constexpr int IM = TM / 64, JN = TN / 64;
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) v
   constexpr int LPT = NIA + NIB;
   static_assert((NS - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) unsigned short smem[NS * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;       // role-local wave index
+  const bool producer = !WS || (tid >> 6) >= 4, consumer = !WS || (tid >> 6) < 4;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile = blockIdx.x, split = blockIdx.y;
   const int tile_co = tile / tiles_k, tile_k = tile - tile_co * tiles_k;
@@ -346,22 +349,9 @@ __global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) v
   }
 
   const int nt = (m_end - m_begin + WKS - 1) / WKS;
-#pragma unroll
-  for (int p = 0; p < NS - 1; ++p)
-    if (p < nt) issue(m_begin + p * WKS, p);
-  int buf = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int younger = min(nt - 1 - t, NS - 2);
-    if constexpr (NS >= 5) { if (younger == 3) wg_wait_vm<3 * LPT>(); }
-    if constexpr (NS >= 4) { if (younger == 2) wg_wait_vm<2 * LPT>(); }
-    if constexpr (NS >= 3) { if (younger == 1) wg_wait_vm<1 * LPT>(); }
-    if (younger == 0) wg_wait_vm<0>();
-    asm volatile("s_barrier" ::: "memory");       // bare barrier: a fence would drain the whole ring (vmcnt 0)
-    if (t + NS - 1 < nt) issue(m_begin + (t + NS - 1) * WKS, buf == 0 ? NS - 1 : buf - 1);
-    const unsigned sb = (unsigned)(buf * STAGE * 2);
-    buf = (buf + 1 == NS) ? 0 : buf + 1;
-    // fragment reads run one 16-pixel slice ahead of the MFMAs (two register sets): `s_waitcnt lgkmcnt(8)`
-    // retires the older slice's eight transposing reads while the younger slice's eight stay in flight
+  // fragment reads run one 16-pixel slice ahead of the MFMAs (two register sets): `s_waitcnt lgkmcnt(8)`
+  // retires the older slice's eight transposing reads while the younger slice's eight stay in flight
+  auto compute = [&](unsigned sb) {
     s16x4 al[2][2], ah[2][2], bl[2][2], bh[2][2];
 #define WG_LOAD(KK, S)                                                                                   \
     tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[0] + sb, al[S][0], ah[S][0]);              \
@@ -388,6 +378,44 @@ __global__ __launch_bounds__(256, (NS * (TM + TN) * 128 <= 80 * 1024) ? 2 : 1) v
     WG_MMA(1, 0)
 #undef WG_LOAD
 #undef WG_MMA
+  };
+  if constexpr (!WS) {
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+      if (p < nt) issue(m_begin + p * WKS, p);
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+      const int younger = min(nt - 1 - t, NS - 2);
+      if constexpr (NS >= 5) { if (younger == 3) wg_wait_vm<3 * LPT>(); }
+      if constexpr (NS >= 4) { if (younger == 2) wg_wait_vm<2 * LPT>(); }
+      if constexpr (NS >= 3) { if (younger == 1) wg_wait_vm<1 * LPT>(); }
+      if (younger == 0) wg_wait_vm<0>();
+      asm volatile("s_barrier" ::: "memory");     // bare barrier: a fence would drain the whole ring (vmcnt 0)
+      if (t + NS - 1 < nt) issue(m_begin + (t + NS - 1) * WKS, buf == 0 ? NS - 1 : buf - 1);
+      compute((unsigned)(buf * STAGE * 2));
+      buf = (buf + 1 == NS) ? 0 : buf + 1;
+    }
+  } else if (producer) {                            // separate loops: the two roles' registers never coexist
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+      if (p < nt) issue(m_begin + p * WKS, p);
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+      const int younger = min(nt - 1 - t, NS - 2);
+      if constexpr (NS >= 3) { if (younger == 1) wg_wait_vm<1 * LPT>(); }
+      if (younger == 0) wg_wait_vm<0>();
+      asm volatile("s_barrier" ::: "memory");
+      if (t + NS - 1 < nt) issue(m_begin + (t + NS - 1) * WKS, buf == 0 ? NS - 1 : buf - 1);
+      buf = (buf + 1 == NS) ? 0 : buf + 1;
+    }
+    return;
+  } else {
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_barrier" ::: "memory");
+      compute((unsigned)(buf * STAGE * 2));
+      buf = (buf + 1 == NS) ? 0 : buf + 1;
+    }
   }
   const int l31 = lane & 31, kh = lane >> 5;
   float* wsp = ws + (int64_t)split * NCO * g.K;
@@ -624,7 +652,11 @@ static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
   static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
   const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0 && stem_dma;
   if (dtype == CREID_BF16 && use_dma && ((1 << g.log2span) >= TN || stem_geom)) {
-    if (stages == 2)
+    static const int use_ws = [] { const char* e = getenv("CREID_WGRAD_WS"); return e ? atoi(e) : 0; }();
+    if (use_ws && !stem_geom)
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, true>), grid, dim3(512), 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+    else if (stages == 2)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2>), grid, block, 0, s, g, (const unsigned short*)dy,
                          (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
     else if (stages == 3)
