@@ -181,7 +181,7 @@ def run_eval(args, rank, world):
             "l2norm_GBs": (nq + ng) * D * 8 / (t_norm * 1e-3) / 1e9,
             "rank_rows_GBs": rank_bytes / (t_rank * 1e-3) / 1e9,
             "peak_GBs": HBM_PEAK_GBS}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:             # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline_eval(feats, pids, cams, nq, ng)
         res["mAP"] = mAP
     return {

@@ -209,7 +209,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
                            "frac": tf / MFMA_BF16_TFLOPS, "traffic": pmc_traffic("igemm_family"),
                            "ms_per_step": ig_ms, "slowest_TFs": slow, "fastest_TFs": fast}
         res["roofline_hbm_stages"] = hbm_stage_rates(time_kernel, P * K, H, W)
-        if cpu_baseline_fn is not None:
+        if cpu_baseline_fn is not None and world == 1:          # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline_fn(P, K, H, W)
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
             "ms_per_step": dt / args.steps * 1e3, "dtype": "bf16",
