@@ -69,7 +69,8 @@ def test_sqdist_16bit_vs_oracle(rm, dt):
     np.testing.assert_allclose(d.numpy(), ref.numpy(), rtol=1e-4, atol=2e-3)
 
 
-@pytest.mark.parametrize("m,n", [(1, 1), (3, 63), (2, 64), (5, 65), (7, 1023), (4, 1025), (3, 5000), (600, 333)])
+@pytest.mark.parametrize("m,n", [(1, 1), (3, 63), (2, 64), (5, 65), (7, 1023), (4, 1025), (3, 5000), (600, 333),
+                                 (2, 21504), (2, 21505), (3, 30000)])   # LDS-bucket limit and beyond (radix kernel)
 def test_rank_rows_matches_stable_argsort(rm, m, n):
     rng = np.random.default_rng(n)
     d = rng.standard_normal((m, n)).astype(np.float32)
