@@ -232,6 +232,8 @@ class BackboneEngine:
         self.wgrad_stream = os.environ.get("CREID_WGRAD_STREAM", "0") == "1"
         self._side = None
         self._keep = []
+        self.reduce_stream = os.environ.get("CREID_REDUCE_STREAM", "0") == "1"
+        self._ws2 = [None, None]
         self.saved = None
         self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
@@ -474,9 +476,29 @@ class BackboneEngine:
         lib, st = L.lib(), L.stream()
         d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         nbytes = lib.creid_conv2d_wgrad_workspace_bytes(C.byref(d), self.dt)
-        ws = self._workspace(nbytes)
-        L.check(lib.creid_conv2d_wgrad_nhwc(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(self._grad_of(u.conv.weight)), 1,
-                                            L.ptr(ws), nbytes, self.dt, st), "conv2d_wgrad")
+        gw = self._grad_of(u.conv.weight)
+        if not self.reduce_stream:
+            ws = self._workspace(nbytes)
+            L.check(lib.creid_conv2d_wgrad_nhwc(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(gw), 1, L.ptr(ws), nbytes, self.dt,
+                                                st), "conv2d_wgrad")
+            return
+        # CREID_REDUCE_STREAM=1: partial tiles on the main stream, the short split reduce on a second stream beside
+        # the data gradient that follows; two workspaces alternate so the next wgrad never waits for this reduce
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        k = self._ws_flip = 1 - getattr(self, "_ws_flip", 0)
+        if self._ws2[k] is None or self._ws2[k].numel() < nbytes:
+            self._keep.append(self._ws2[k])
+            self._ws2[k] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        ws = self._ws2[k]
+        main.wait_stream(self._side)            # the reduce that last used this workspace (two wgrads ago) is done
+        L.check(lib.creid_conv2d_wgrad_partials(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(ws), nbytes, self.dt, st),
+                "conv2d_wgrad_partials")
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            L.check(lib.creid_conv2d_wgrad_reduce(C.byref(d), L.ptr(gw), 1, L.ptr(ws), nbytes, self.dt, L.stream()),
+                    "conv2d_wgrad_reduce")
 
     def _dgrad(self, u, dy, B, H, W, add_src=None, bnred=None, stat_image_rows=0, add_src_stride=1):
         """Data gradient.  bnred = (x, act, mean, invstd) of the BN layer that consumes the result: its column

@@ -675,15 +675,19 @@ static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
 }
 
 static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* dw, int kw_taps, int cpitch,
-                     int cin, int kh, int kw, int accumulate, void* ws, size_t ws_bytes, int dtype, hipStream_t s) {
+                     int cin, int kh, int kw, int accumulate, void* ws, size_t ws_bytes, int dtype, hipStream_t s,
+                     int phases = 3) {
   if (dtype != CREID_BF16 && dtype != CREID_F32) return CREID_E_DTYPE;
   const WgradPlan p = plan_wgrad(g.M, NCO, g.K, dtype);
   const size_t need = (size_t)p.splits * NCO * g.K * sizeof(float);
   if (ws_bytes < need) return CREID_E_WS;
-  if (p.tm == 128 && p.tn == 128) launch_wgrad_t<128, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
-  else if (p.tm == 128 && p.tn == 64) launch_wgrad_t<128, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
-  else if (p.tm == 64 && p.tn == 128) launch_wgrad_t<64, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
-  else launch_wgrad_t<64, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+  if (phases & 1) {
+    if (p.tm == 128 && p.tn == 128) launch_wgrad_t<128, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+    else if (p.tm == 128 && p.tn == 64) launch_wgrad_t<128, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+    else if (p.tm == 64 && p.tn == 128) launch_wgrad_t<64, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+    else launch_wgrad_t<64, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+  }
+  if (!(phases & 2)) return (int)hipGetLastError();
   if (kh * kw == 9 && cpitch == cin && (1 << g.log2span) == cin && kw_taps == kw && p.splits <= 16 &&
       (size_t)g.K * sizeof(float) <= 48 * 1024) {
     hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)NCO), dim3(256), (size_t)g.K * sizeof(float), s,
@@ -711,9 +715,30 @@ size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype) {
   return (size_t)p.splits * d->out_c * K * sizeof(float);
 }
 
+static int conv_wgrad_phases(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
+                             void* ws, size_t ws_bytes, int dtype, void* stream, int phases);
+
 int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
                             void* ws, size_t ws_bytes, int dtype, void* stream) {
-  CREID_CHECK_ARG(d && x && dy && dw_oihw && ws);
+  CREID_CHECK_ARG(x && dy && dw_oihw);
+  return conv_wgrad_phases(d, x, dy, dw_oihw, accumulate, ws, ws_bytes, dtype, stream, 3);
+}
+
+int creid_conv2d_wgrad_partials(const creid_conv_desc* d, const void* x, const void* dy, void* ws, size_t ws_bytes,
+                                int dtype, void* stream) {
+  CREID_CHECK_ARG(x && dy);
+  return conv_wgrad_phases(d, x, dy, nullptr, 0, ws, ws_bytes, dtype, stream, 1);
+}
+
+int creid_conv2d_wgrad_reduce(const creid_conv_desc* d, float* dw_oihw, int accumulate, const void* ws, size_t ws_bytes,
+                              int dtype, void* stream) {
+  CREID_CHECK_ARG(dw_oihw);
+  return conv_wgrad_phases(d, nullptr, nullptr, dw_oihw, accumulate, const_cast<void*>(ws), ws_bytes, dtype, stream, 2);
+}
+
+static int conv_wgrad_phases(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
+                             void* ws, size_t ws_bytes, int dtype, void* stream, int phases) {
+  CREID_CHECK_ARG(d && ws);
   if (ilog2x(d->in_c) < 0 || d->in_c < 64 || d->out_c % 64 != 0) return CREID_E_SHAPE;
   IGemmGeom g;
   g.M = (int)(d->batch * d->out_h * d->out_w); g.OH = (int)d->out_h; g.OW = (int)d->out_w;
@@ -723,7 +748,7 @@ int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void*
   { static const int noinc = [] { const char* e = getenv("CREID_WGRAD_NOINC"); return e ? atoi(e) : 0; }(); if (noinc) g.check_bounds = 2; }
   igemm_finish_geom(g);
   return run_wgrad(g, dy, x, (int)d->out_c, dw_oihw, d->kw, (int)d->in_c, (int)d->in_c, d->kh, d->kw, accumulate, ws,
-                   ws_bytes, dtype, as_stream(stream));
+                   ws_bytes, dtype, as_stream(stream), phases);
 }
 
 size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype) {

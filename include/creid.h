@@ -219,6 +219,12 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
 size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype);
 int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw,
                             int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* The two halves of the call above as separate launches (same workspace contents in between): the split
+ * reduce is a short, memory-light kernel that a caller may put on a second stream beside the next data gradient. */
+int creid_conv2d_wgrad_partials(const creid_conv_desc* d, const void* x, const void* dy, void* ws,
+                                size_t ws_bytes, int dtype, void* stream);
+int creid_conv2d_wgrad_reduce(const creid_conv_desc* d, float* dw_oihw, int accumulate, const void* ws,
+                              size_t ws_bytes, int dtype, void* stream);
 
 /* Stem (resnet.py:94): Conv2d(3, 64, 7, stride 2, pad 3) on the zero-padded NHWC4 image
  * xpad [B, H+8, W+6, 4] made by creid_image_to_nhwc4_pad; w_stem [64][8][32] from creid_stem_weight_prep. */
