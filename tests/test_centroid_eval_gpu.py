@@ -150,3 +150,23 @@ def test_run_inference_uses_bnneck():
     emb, paths = inf.run_inference(model, loader)
     np.testing.assert_array_equal(emb, (x.flatten(1)[:, :16] * 2 + 1).numpy())
     assert list(paths) == ["a", "b", "c", "d"]
+
+
+def test_inference_golden(golden):
+    """Against the reference's own inference helpers (tests/golden/inference.npz, tools/gen_golden.py inference)."""
+    from centroids_reid_amd import inference as inf
+    g = golden("inference")
+    nq, topk = int(g["num_query"]), int(g["topk"])
+    f = g["feats"]
+    res = inf.get_similar(f[:nq], g["query_paths"], f[nq:], g["gallery_paths"], topk=topk)
+    assert list(res.keys()) == list(g["query_paths"])
+    for i, p in enumerate(g["query_paths"]):
+        np.testing.assert_array_equal(res[p]["indices"], g["indices"][i])             # gap-designed gallery: bit-exact
+        np.testing.assert_array_equal(res[p]["paths"], g["gallery_paths"][g["indices"][i]])
+        np.testing.assert_allclose(res[p]["distances"], g["distances"][i], rtol=0, atol=3e-6)
+    index = inf.create_pid_path_index(list(g["gallery_paths"]), lambda p: p.split("/")[-1].split("_")[0])
+    assert list(index.keys()) == list(g["index_keys"])
+    np.testing.assert_array_equal(np.concatenate([np.asarray(v) for v in index.values()]), g["index_flat"])
+    cents, keys = inf.calculate_centroids(f[nq:], index)
+    assert list(keys) == list(g["centroid_keys"]) and keys.dtype == g["centroid_keys"].dtype
+    np.testing.assert_allclose(cents, g["centroids"], rtol=0, atol=2e-6)

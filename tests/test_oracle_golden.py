@@ -167,3 +167,25 @@ def test_val_centroids_camera_sets(golden):
     gap = np.diff(ds, axis=1) > 1e-6
     gap_ok[:, 1:] &= gap; gap_ok[:, :-1] &= gap
     np.testing.assert_array_equal(idx[gap_ok], g["indices"][gap_ok])
+
+
+def test_inference_golden_vs_oracle(golden):
+    """inference/inference_utils.py:134-159 + inference/get_similar.py:97-125 recorded from the reference: the oracle's
+    normalise -> squared-L2 -> stable rank pipeline reproduces the top-k indices and distances."""
+    g = golden("inference")
+    nq, topk = int(g["num_query"]), int(g["topk"])
+    f = torch.from_numpy(g["feats"])
+    q, gal = ro.l2_normalize(f[:nq]), ro.l2_normalize(f[nq:])
+    d = ro.sqdist_matrix(q, gal)
+    idx = ro.rank_rows(d)[:, :topk]
+    np.testing.assert_array_equal(idx, g["indices"])
+    np.testing.assert_allclose(np.take_along_axis(d.numpy(), idx, 1), g["distances"], rtol=0, atol=2e-6)
+    # per-pid index + centroids (plain numpy restatement of the two helper functions)
+    keys = [p.split("/")[-1].split("_")[0] for p in g["gallery_paths"]]
+    order = list(dict.fromkeys(keys))
+    assert order == list(g["index_keys"]) == list(g["centroid_keys"])
+    off = np.concatenate([[0], np.cumsum(g["index_sizes"])])
+    for i, k in enumerate(order):
+        members = np.nonzero(np.asarray(keys) == k)[0]
+        np.testing.assert_array_equal(members, g["index_flat"][off[i]:off[i + 1]])
+        np.testing.assert_allclose(f[nq:].numpy()[members].sum(0) / len(members), g["centroids"][i], rtol=0, atol=1e-6)

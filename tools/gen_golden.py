@@ -300,7 +300,7 @@ def gen_backbone(ref, name, arch, B, H, W):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.load()
-    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
+    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
     if "eval" in which:
         gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
         gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
@@ -413,3 +413,37 @@ def gen_camsets():
 
 if __name__ == "__main__" and "camsets" in sys.argv[1:]:
     gen_camsets()
+
+
+def gen_inference():
+    """Inference / similarity search: the reference's create_pid_path_index + calculate_centroids
+    (inference/inference_utils.py:134-159) on synthetic embeddings, and the body of inference/get_similar.py:97-125
+    (F.normalize -> get_dist_func('euclidean') -> np.argsort -> top-k) driven with the reference's own functions."""
+    import importlib
+    ref_import.install_stubs(); ref_import.ref_path_first()
+    iu = importlib.import_module("inference.inference_utils")
+    rm = importlib.import_module("utils.reid_metric")
+    nq, ng, D, topk = 24, 400, 64, 15
+    f, _ = gapped_features(nq, ng, D, 61, 2e-5)
+    rng = np.random.default_rng(62)
+    gal_pid = rng.integers(0, 37, ng)
+    gpaths = np.array([f"gallery/{p:04d}_c{rng.integers(1, 7)}_{i:05d}.jpg" for i, p in enumerate(gal_pid)])
+    qpaths = np.array([f"query/{i:04d}.jpg" for i in range(nq)])
+    index = iu.create_pid_path_index(list(gpaths), lambda p: p.split("/")[-1].split("_")[0])
+    cents, keys = iu.calculate_centroids(f[nq:], index)
+    q = torch.nn.functional.normalize(torch.from_numpy(f[:nq]), dim=1, p=2)
+    g = torch.nn.functional.normalize(torch.from_numpy(f[nq:]), dim=1, p=2)
+    distmat = rm.get_dist_func("euclidean")(x=q, y=g).cpu().numpy()
+    indices = np.argsort(distmat, axis=1)[:, :topk]
+    dist_sel = np.take_along_axis(distmat, indices, 1)
+    np.savez_compressed(os.path.join(OUT, "inference"), feats=f, num_query=np.int64(nq), topk=np.int64(topk),
+                        gallery_paths=gpaths, query_paths=qpaths, index_keys=np.array(list(index.keys())),
+                        index_sizes=np.array([len(v) for v in index.values()], np.int64),
+                        index_flat=np.concatenate([np.asarray(v, np.int64) for v in index.values()]),
+                        centroids=np.asarray(cents, np.float32), centroid_keys=keys,
+                        indices=indices.astype(np.int64), distances=dist_sel.astype(np.float32))
+    print(f"[inference] pids={len(index)} centroids={cents.shape} topk indices {indices.shape}")
+
+
+if __name__ == "__main__" and "inference" in sys.argv[1:]:
+    gen_inference()

@@ -76,8 +76,8 @@ def install_stubs():
     tv = _mod("torchvision")
     tv.models = _mod("torchvision.models")
     tv.transforms = _mod("torchvision.transforms")
-    tv.datasets = _mod("torchvision.datasets")
-    _mod("torchvision.datasets.folder", default_loader=None, IMG_EXTENSIONS=())
+    tv.datasets = _mod("torchvision.datasets", ImageFolder=type("ImageFolder", (), {}))
+    _mod("torchvision.datasets.folder", default_loader=None, IMG_EXTENSIONS=(), is_image_file=lambda p: True)
     _mod("yacs")
     _mod("yacs.config", CfgNode=AttrDict)
     _mod("mlflow")
