@@ -123,7 +123,8 @@ def pmc_traffic(key):
 def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
     P, K, H, W = 16, 4, 256, 128
     arch = os.environ.get("CREID_BENCH_ARCH", "resnet50")      # resnet50_ibn_a: side measurement, not the headline config
-    model = make_model(arch=arch)
+    f32 = os.environ.get("CREID_BENCH_DTYPE", "bf16") == "f32"   # side measurement: the exact-f32 parity mode
+    model = make_model(arch=arch, dtype=torch.float32 if f32 else torch.bfloat16)
     if world > 1:
         # identical initial weights on every rank, then data-parallel gradient all-reduce over RCCL
         opt, _ = model.optimizers()
@@ -212,7 +213,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
         if cpu_baseline_fn is not None and world == 1:          # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline_fn(P, K, H, W)
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
-            "ms_per_step": dt / args.steps * 1e3, "dtype": "bf16",
+            "ms_per_step": dt / args.steps * 1e3, "dtype": "f32" if f32 else "bf16",
             "config": {"workload": ("ResNet50" if arch == "resnet50" else arch) +
                                    " 256x128 CTL training step: fwd+bwd, centroid-triplet + center + xent, "
                                    "Adam + center SGD (BASELINE configs[1])",
