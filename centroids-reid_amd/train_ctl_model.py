@@ -156,9 +156,11 @@ class CTLModel(ModelBase):
         margin = float(self.contrastive_loss.margin)
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        dfeat = torch.zeros((B, D), **f32)
-        out4 = torch.empty((K + 1, 4), **f32)                                  # row 0: query triplet, 1..K: rounds
-        lc, lx = torch.empty(1, **f32), torch.empty(1, **f32)
+        zbuf = torch.zeros(B * D + K * 2 * P * D, **f32)                       # ONE fill for both accumulation buffers
+        dfeat = zbuf[:B * D].view(B, D)
+        scal = torch.empty(4 * (K + 1) + 2, **f32)                             # every scalar of the step in one buffer:
+        out4 = scal[:4 * (K + 1)].view(K + 1, 4)                               # row 0: query triplet, 1..K: rounds
+        lc, lx = scal[4 * (K + 1):4 * (K + 1) + 1], scal[4 * (K + 1) + 1:]
 
         def grad_of(p):
             if not p.requires_grad:
@@ -219,7 +221,7 @@ class CTLModel(ModelBase):
         emb[:, P:].copy_(cent)
         lt = labels.view(P, K).t()
         lab = torch.cat((lt, lt), dim=1).contiguous()                          # [K, 2P]
-        demb = torch.zeros((K, 2 * P, D), **f32)
+        demb = zbuf[B * D:].view(K, 2 * P, D)
         g_round = hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT / K
         keep.append(triplet(emb, lab, K, 2 * P, out4[1:], g_round, demb))      # the K rounds: one launch per kernel
         dfeat.view(P, K, D).add_(demb[:, :P].transpose(0, 1))
@@ -229,17 +231,34 @@ class CTLModel(ModelBase):
 
         eng.backward(dfeat)                                                    # manual_backward (:152)
 
-        xent_query = lx[0] * hp.SOLVER.QUERY_XENT_WEIGHT
-        contrastive_loss_query = out4[0, 0] * hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT
-        center_loss = lc[0] * hp.SOLVER.CENTER_LOSS_WEIGHT
+        # weighted terms with ONE multiply: w is a cached constant vector aligned with `scal`
+        # (query triplet loss, round losses / K, center loss, xent) -- the logged values are views of the product
+        wv = self._loss_weight_vector(K, dev)
+        terms = scal * wv
+        contrastive_loss_query = terms[0]
+        contrastive_loss_step = terms[4:4 * (K + 1):4].sum()
+        center_loss, xent_query = terms[4 * (K + 1)], terms[4 * (K + 1) + 1]
+        total_loss = terms.sum()                                               # :150 (unweighted slots have weight 0)
         rounds = out4[1:].mean(dim=0)                                          # {loss, mean ap, mean an, n}
-        contrastive_loss_step = rounds[0] * hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT
-        total_loss = contrastive_loss_step + center_loss + xent_query + contrastive_loss_query       # :150
         l2_mean = torch.linalg.vector_norm(cent, dim=2).mean()
         for name, val in zip(self.losses_names, (xent_query, contrastive_loss_query, center_loss, contrastive_loss_step)):
             self.losses_dict[name].append(val)
         log_data = {"step_dist_ap": rounds[1], "step_dist_an": rounds[2], "l2_mean_centroid": l2_mean}
         return {"loss": total_loss, "other": log_data}
+
+    def _loss_weight_vector(self, K, dev):
+        hp = self.hparams
+        key = (K, str(dev), hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT, hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT,
+               hp.SOLVER.CENTER_LOSS_WEIGHT, hp.SOLVER.QUERY_XENT_WEIGHT)
+        c = getattr(self, "_loss_wv", None)
+        if c is None or c[0] != key:
+            w = torch.zeros(4 * (K + 1) + 2)
+            w[0] = hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT
+            w[4:4 * (K + 1):4] = hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT / K
+            w[4 * (K + 1)] = hp.SOLVER.CENTER_LOSS_WEIGHT
+            w[4 * (K + 1) + 1] = hp.SOLVER.QUERY_XENT_WEIGHT
+            c = self._loss_wv = (key, w.to(dev))
+        return c[1]
 
     def _all_real_u8(self, B, dev):
         c = getattr(self, "_all_real_u8_dev", None)
