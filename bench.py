@@ -242,7 +242,13 @@ def cpu_baseline_train(P, K, H, W):
 
 
 # ----------------------------------------------------------------------------- main
+_REAL_STDOUT = sys.stdout
+
+
 def main():
+    # the contract is ONE JSON line on stdout: library chatter (optimizer grouping notes, metric banners that mirror
+    # the reference's prints) goes to stderr
+    sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
@@ -274,7 +280,7 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": out.pop("dtype"), "data": "synthetic", **out}
-        print(json.dumps(line))
+        print(json.dumps(line), file=_REAL_STDOUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
