@@ -25,12 +25,16 @@ struct IGemmGeom {
   int check_bounds;   // 0: source is pre-padded (stem)
   float inv_ohow, inv_ow;   // 1/(OH*OW), 1/OW for fast_divmod (M < 2^24)
   int add_compact;          // epilogue add_src is a stride-2 COMPACT tensor [B, OH/2, OW/2, N]: added at even (y, x) only
+  int parity;               // transposed stride-2 (data gradient): GEMM rows are enumerated parity-class major --
+                            // row m = class*(M/4) + (b, y/2, x/2), class = (y&1)*2 + (x&1) -- so a 128-row tile holds
+                            // one class and only that class's taps (1, 2, 2 or 4 of 9 for 3x3) are visited
 };
 
 static inline void igemm_finish_geom(IGemmGeom& g) {
   g.inv_ohow = 1.0f / (float)(g.OH * g.OW);
   g.inv_ow = 1.0f / (float)g.OW;
   g.add_compact = 0;
+  g.parity = 0;
 }
 
 // Source pixel of output row (oy, ox) under tap (r, s); returns false when it falls outside.

@@ -592,8 +592,23 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int row0 = tile_m * 128, col0 = tile_n * BN;
-  const int nk = g.K / BK;
   const int l31 = lane & 31, kh = lane >> 5;
+  // parity-class row order (g.parity): the tile's class fixes which taps exist; r, s step by 2 from (r0, s0)
+  const int msub = g.M >> 2;
+  const int cls = g.parity ? row0 / msub : 0, py = cls >> 1, px = cls & 1;
+  const int tstep = g.parity ? 2 : 1;
+  const int r0 = g.parity ? ((py + g.pad) & 1) : 0, s0 = g.parity ? ((px + g.pad) & 1) : 0;
+  const int kh_taps = (g.K >> g.log2span) / g.kw;                 // kernel rows
+  const int nk = g.parity ? ((kh_taps - r0 + 1) / 2) * ((g.kw - s0 + 1) / 2) * ((1 << g.log2span) / BK) : g.K / BK;
+  // GEMM row -> raster pixel index of the output tensor (identity unless parity-class order)
+  auto pixel_of = [&](int rr) -> int {
+    if (!g.parity) return rr;
+    const int rem2 = rr - cls * msub;
+    int b, rem, a, c;
+    fast_divmod(rem2, (g.OH >> 1) * (g.OW >> 1), g.inv_ohow * 4.f, b, rem);
+    fast_divmod(rem, g.OW >> 1, g.inv_ow * 2.f, a, c);
+    return (b * g.OH + 2 * a + py) * g.OW + 2 * c + px;
+  };
 
   f32x16 acc[2][TNW];
   if (producer) {
@@ -605,22 +620,25 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     for (int i = 0; i < 4; ++i) {
       const int r = (i * 4 + cw) * 8 + lr8, m = row0 + r;
       vm[i] = m < g.M;
-      const int mm = vm[i] ? m : 0;
+      const int mm = vm[i] ? m : row0;
+      const int pix = pixel_of(mm);
       int b, rem;
-      fast_divmod(mm, g.OH * g.OW, g.inv_ohow, b, rem);
+      fast_divmod(pix, g.OH * g.OW, g.inv_ohow, b, rem);
       fast_divmod(rem, g.OW, g.inv_ow, oy[i], ox[i]);
       bpix[i] = b * g.SH * g.SW;
       gch[i] = (lcp ^ ((r >> 1) & 7)) << 3;
     }
     const unsigned short* wp[NBI];
+    const unsigned short* wbase[NBI];
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
       const int r = (i * 4 + cw) * 8 + lr8;
-      wp[i] = wgt + (int64_t)(col0 + r) * g.K + ((lcp ^ ((r >> 1) & 7)) << 3);
+      wbase[i] = wgt + (int64_t)(col0 + r) * g.K + ((lcp ^ ((r >> 1) & 7)) << 3);
+      wp[i] = wbase[i];
     }
     const unsigned short* aptr[4];
     int amul[4];
-    int cur_tap = -1, cur_r = 0, cur_s = -1;
+    int cur_tap = -1, cur_r = r0, cur_s = s0 - tstep;
     const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_zero_page);
     typedef const void __attribute__((address_space(1)))* gptr_t;
     typedef void __attribute__((address_space(3)))* lptr_t;
@@ -628,7 +646,12 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       const int tap = (t * BK) >> g.log2span;
       if (tap != cur_tap) {
         cur_tap = tap;
-        if (++cur_s == g.kw) { cur_s = 0; ++cur_r; }
+        cur_s += tstep;
+        if (cur_s >= g.kw) { cur_s = s0; cur_r += tstep; }
+        if (g.parity) {
+#pragma unroll
+          for (int i = 0; i < NBI; ++i) wp[i] = wbase[i] + ((cur_r * g.kw + cur_s) << g.log2span);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           int iy, ix;
@@ -729,7 +752,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
       pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
       if (rr < g.M) {
-        const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
+        const int64_t off = (int64_t)pixel_of(rr) * g.N + col0 + ch * 8;
         pre_x[i] = *reinterpret_cast<const uint4*>(bx0 + off);
         if (ba0) pre_a[i] = *reinterpret_cast<const uint4*>(ba0 + off);
       }
@@ -778,13 +801,14 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     const int rr = row0 + rl;
     if (rr < g.M) {
       uint4 v = *reinterpret_cast<const uint4*>(&smem[rl * CP + ch * 8]);
-      const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
+      const int prow = pixel_of(rr);
+      const int64_t off = (int64_t)prow * g.N + col0 + ch * 8;
       if (add_src) {
         int64_t aoff = off;
         bool has = true;
         if (g.add_compact) {                                     // the stride-2 downsample branch's gradient, compact
           int ab, arem, ay, ax;
-          fast_divmod(rr, g.OH * g.OW, g.inv_ohow, ab, arem);
+          fast_divmod(prow, g.OH * g.OW, g.inv_ohow, ab, arem);
           fast_divmod(arem, g.OW, g.inv_ow, ay, ax);
           has = ((ay | ax) & 1) == 0;
           aoff = (int64_t)((ab * (g.OH >> 1) + (ay >> 1)) * (g.OW >> 1) + (ax >> 1)) * g.N + col0 + ch * 8;
@@ -1013,10 +1037,16 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
     // profiles/r01_igemm_ws_sweep.md).  CREID_IGEMM_WS=0: the 4-wave DMA kernel; =2: force CREID_IGEMM_WS_STAGES.
     static const int ws_min_k = [] { const char* e = getenv("CREID_IGEMM_WS_MIN_K"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     if (g.log2span >= 6 && use_ws >= 1) {
+      // stride-2 3x3 data gradients: parity-class row order, 9 tap-tiles per 4 output pixels instead of 36
+      static const int parity_on = [] { const char* e = getenv("CREID_DGRAD_PARITY"); return e ? atoi(e) : 1; }();
+      IGemmGeom gp = g;
+      if (parity_on && g.transposed && g.stride == 2 && g.kw == 3 && g.pad == 1 && (g.K >> g.log2span) == 9 &&
+          g.OH % 2 == 0 && g.OW % 2 == 0 && (g.M / 4) % 128 == 0 && !g.add_compact && bnred.tiles_per_image == 0)
+        gp.parity = 1;
       const int ws_stages = use_ws == 2 ? ws_stages_env() : ((bn == 64 && g.K >= ws_min_k) ? 3 : 2);
       const dim3 block_ws(512);
 #define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
-  hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid, block_ws, 0, s, g, (const unsigned short*)src,           \
+  hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid, block_ws, 0, s, gp, (const unsigned short*)src,          \
                      (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n, \
                      bnred)
       if (bn == 128) { if (ws_stages == 4) CREID_WS_LAUNCH(128, 4); else if (ws_stages == 2) CREID_WS_LAUNCH(128, 2); else CREID_WS_LAUNCH(128, 3); }

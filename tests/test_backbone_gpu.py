@@ -14,6 +14,8 @@ CASES = [  # B, H, W, cin, cout, k, stride
     (2, 16, 8, 64, 64, 1, 1),
     (2, 16, 8, 64, 64, 3, 1),
     (2, 16, 8, 128, 128, 3, 2),
+    (4, 16, 8, 128, 128, 3, 2),      # M/4 % 128 == 0: stride-2 data gradient in parity-class row order (one tile per class)
+    (2, 32, 16, 64, 64, 3, 2),       # ... two tiles per class, 64-channel taps
     (2, 16, 8, 256, 512, 1, 2),
     (1, 10, 10, 64, 256, 1, 1),      # M = 100: partial tile
     (3, 12, 6, 512, 128, 1, 1),
