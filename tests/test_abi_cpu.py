@@ -37,6 +37,29 @@ def test_binding_covers_header(built_lib):
     assert built_lib.lib().creid_abi_version() == 1
 
 
+def test_binding_arity_and_pointer_slots_match_header(built_lib):
+    """Every ctypes signature has the header's parameter count, pointers where the header has pointers and
+    64-bit integers where it has int64_t / size_t (a stale binding would pass garbage silently)."""
+    import ctypes as C
+    txt = open(os.path.join(ROOT, "include", "creid.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    decls = re.findall(r"\b(?:int|int64_t|size_t)\s+(creid_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S)
+    assert len(decls) == len(declared_symbols())
+    for name, params in decls:
+        plist = [q.strip() for q in params.split(",")]
+        if plist == ["void"] or plist == [""]:
+            plist = []
+        restype, argtypes = built_lib.SIGNATURES[name]
+        assert len(argtypes) == len(plist), (name, len(argtypes), len(plist))
+        for a, q in zip(argtypes, plist):
+            is_ptr = "*" in q
+            assert (a is C.c_void_p) == is_ptr, (name, q, a)
+            if not is_ptr and re.search(r"\b(int64_t|size_t)\b", q):
+                assert C.sizeof(a) == 8, (name, q, a)
+            if not is_ptr and re.search(r"\bfloat\b", q):
+                assert a is C.c_float, (name, q, a)
+
+
 def test_no_cpu_fallback(built_lib):
     import torch
     from centroids_reid_amd import reid_metric as rm
