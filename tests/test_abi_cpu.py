@@ -60,6 +60,18 @@ def test_binding_arity_and_pointer_slots_match_header(built_lib):
                 assert a is C.c_float, (name, q, a)
 
 
+def test_header_is_plain_c():
+    """include/creid.h is the FFI boundary: it must compile as C99 on its own (no torch / HIP / C++ types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "creid.h")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_no_cpu_fallback(built_lib):
     import torch
     from centroids_reid_amd import reid_metric as rm
