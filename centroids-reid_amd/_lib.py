@@ -31,12 +31,21 @@ SIGNATURES = {
     "creid_cmc_ap_ranked": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_cmc_ap_ranked_camsets": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_eval_reduce": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "creid_stream_poslist": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
+    "creid_stream_count": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    "creid_stream_finalize": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p]),
     "creid_loo_centroids_fwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "creid_loo_centroids_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "creid_triplet_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_triplet_bwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _f32, _p, _p]),
     "creid_triplet_fwd_batched": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_triplet_bwd_batched": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _f32, _p, _p]),
+    "creid_triplet_cosine_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_triplet_cosine_bwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _f32, _p, _p]),
+    "creid_rownorm_fwd": (C.c_int, [_p, _i64, _i64, C.c_int, _f32, _p, _p, _p]),
+    "creid_rownorm_bwd": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _f32, _p, _p]),
+    "creid_hard_mine_from_dist": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _p]),
+    "creid_clamp_sqrt_inplace": (C.c_int, [_p, _i64, _f32, _p]),
     "creid_center_loss_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "creid_center_loss_bwd": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _f32, _p, _p, _p]),
     "creid_xent_ls": (C.c_int, [_p, _p, _i64, _i64, _f32, _f32, _p, _p, _p, _p]),

@@ -88,7 +88,7 @@ class ResNet(nn.Module):
 
     def load_param(self, model_path):
         """resnet.py:135-154: strip 'backbone.base.' / 'base.' prefixes, skip fc/bottleneck/classifier."""
-        param_dict = torch.load(model_path, map_location="cpu")
+        param_dict = torch.load(model_path, map_location="cpu", weights_only=False)
         if "state_dict" in param_dict:
             param_dict = param_dict["state_dict"]
         own = self.state_dict()
@@ -175,7 +175,7 @@ class ResNet_IBN(ResNet):
 
     def load_param(self, model_path):
         """resnet_ibn_a.py:143-162."""
-        param_dict = torch.load(model_path, map_location="cpu")
+        param_dict = torch.load(model_path, map_location="cpu", weights_only=False)
         if "state_dict" in param_dict:
             param_dict = param_dict["state_dict"]
         own = self.state_dict()
@@ -224,7 +224,11 @@ class BackboneEngine:
                          c3=_ConvUnit(blk.conv3, blk.bn3),
                          ds=_ConvUnit(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None)
                 self.blocks.append(u)
-        self.weights_dirty = True
+        self.weights_dirty = True      # set by writers torch cannot see (our ctypes optimiser kernels)
+        self._wsig = None              # (data_ptr, _version) of every conv weight at the last prep_weights()
+        # nn.Module.load_state_dict copies through `param.copy_` under no_grad (bumps _version), but a post-hook makes
+        # the refresh independent of how a loader writes
+        net.register_load_state_dict_post_hook(lambda *_a: setattr(self, "weights_dirty", True))
         self._ws = None
         # CREID_WGRAD_STREAM=1: weight gradients on a second HIP stream (a parallel branch of the captured graph).
         # Measured r01: the concurrent dgrad / wgrad kernels contend for LDS and L2 and the step gets 6 % SLOWER
@@ -306,6 +310,13 @@ class BackboneEngine:
         L.check(lib.creid_stem_weight_prep(L.ptr(self.stem.conv.weight), self.dt, L.ptr(self.stem.w_krsc), st),
                 "stem_weight_prep")
         self.weights_dirty = False
+        self._wsig = self._weight_signature()
+
+    def _weight_signature(self):
+        """Changes whenever torch-visible code rewrites or re-homes a convolution weight after the compute-dtype
+        copies were made (load_state_dict, an external / PL optimiser, EMA, broadcast, .to()): in-place ops bump
+        `_version`, re-homing changes `data_ptr`.  Writers torch cannot see set `weights_dirty` themselves."""
+        return tuple((u.conv.weight.data_ptr(), u.conv.weight._version) for u in self.all_units())
 
     def fold_counters(self):
         """Fold the pending step count into every BatchNorm2d.num_batches_tracked (before a state_dict)."""
@@ -388,7 +399,7 @@ class BackboneEngine:
     def forward(self, x_nchw: torch.Tensor, training: bool, want_base_out: bool = False):
         L.require_gpu(x_nchw)
         assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3
-        if self.weights_dirty:
+        if self.weights_dirty or self._wsig != self._weight_signature():
             self.prep_weights()
         lib, st = L.lib(), L.stream()
         B, _, H, W = x_nchw.shape

@@ -57,7 +57,7 @@ class Baseline(nn.Module):
         return base_out, feat
 
     def load_param(self, trained_path, load_specific=None):
-        param_dict = torch.load(trained_path, map_location="cpu")
+        param_dict = torch.load(trained_path, map_location="cpu", weights_only=False)
         for i in param_dict:
             if load_specific is not None:
                 if load_specific in i:

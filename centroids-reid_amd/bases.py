@@ -6,8 +6,6 @@ class derives from pl.LightningModule, otherwise from nn.Module with a minimal t
 """
 from __future__ import annotations
 
-import copy
-from collections import defaultdict
 from types import SimpleNamespace
 
 import numpy as np
@@ -102,6 +100,23 @@ class ModelBase(_Base):
         @property
         def current_epoch(self):
             return self.trainer.current_epoch
+
+    def optimizer_step(self, epoch=None, batch_idx=None, optimizer=None, optimizer_idx=None, optimizer_closure=None,
+                       on_tpu=False, using_native_amp=False, using_lbfgs=False, **kwargs):
+        """modelling/bases.py:102-133: linear learning-rate warm-up over SOLVER.WARMUP_EPOCHS applied to the
+        optimiser being stepped, then the trainer's default step (closure first, as PL-1.1.4 does)."""
+        hp = self.hparams
+        if hp.SOLVER.USE_WARMUP_LR and epoch is not None and epoch < hp.SOLVER.WARMUP_EPOCHS:
+            lr_scale = min(1.0, float(epoch + 1) / float(hp.SOLVER.WARMUP_EPOCHS))
+            for pg in optimizer.param_groups:
+                pg["lr"] = lr_scale * hp.SOLVER.BASE_LR
+        if pl is not None:
+            return super().optimizer_step(epoch=epoch, batch_idx=batch_idx, optimizer=optimizer,
+                                          optimizer_idx=optimizer_idx, optimizer_closure=optimizer_closure, on_tpu=on_tpu,
+                                          using_native_amp=using_native_amp, using_lbfgs=using_lbfgs, **kwargs)
+        if optimizer_closure is not None:
+            optimizer_closure()
+        optimizer.step()
 
     # ------------------------------------------------------------------ checkpoint IO (SURVEY §5, §8f rank 4)
     def checkpoint_dict(self, epoch=0, global_step=0):
@@ -223,7 +238,7 @@ class ModelBase(_Base):
     def get_val_metrics(self, embeddings, labels, camids):
         """modelling/bases.py:264-297."""
         self.r1_map_func = R1_mAP(pl_module=self, num_query=self.hparams.num_query,
-                                  feat_norm=self.hparams.TEST.FEAT_NORM)
+                                  feat_norm=self.hparams.TEST.FEAT_NORM, streamed=True)   # only the metrics are used
         respect_camids = bool(self.hparams.MODEL.KEEP_CAMID_CENTROIDS and self.hparams.MODEL.USE_CENTROIDS)
         cmc, mAP, all_topk = self.r1_map_func.compute(feats=embeddings.float(), pids=labels, camids=camids,
                                                       respect_camids=respect_camids)
@@ -249,30 +264,42 @@ class ModelBase(_Base):
             print("Evaluation is done using centroids")
             embeddings, labels, camids = self.validation_create_centroids(
                 embeddings, labels, camids, respect_camids=self.hparams.MODEL.KEEP_CAMID_CENTROIDS)
-        return self.get_val_metrics(embeddings, labels, camids)
+        metrics = self.get_val_metrics(embeddings, labels, camids)
+        if pl is None and self.training:
+            # validation_step put backbone / BNNeck in eval mode (modelling/bases.py:170-171); the reference relies on
+            # the PL trainer to switch the module back for the next training epoch -- without a trainer do it here
+            self.backbone.train()
+            self.bn.train()
+        return metrics
 
     @staticmethod
     def create_masks_train(class_labels):
-        """modelling/bases.py:359-384 (host logic kept for API parity; the training step itself derives
-        the same masks on the fly from the PID-contiguous [P, K] batch layout)."""
-        labels_dict = defaultdict(list)
-        class_labels = class_labels.detach().cpu().numpy()
-        for idx, pid in enumerate(class_labels):
-            labels_dict[pid].append(idx)
-        labels_list = [v for _, v in labels_dict.items()]
-        labels_list_copy = copy.deepcopy(labels_list)
-        lens_list = [len(item) for item in labels_list]
-        lens_list_cs = np.cumsum(lens_list)
-        max_gal_num = max(lens_list)
-        masks = torch.ones((max_gal_num, len(class_labels)), dtype=torch.bool)
-        for r in range(max_gal_num):
-            for i, inner in enumerate(labels_list):
-                if len(inner) > 0:
-                    masks[r, inner.pop(0)] = 0
-                else:
-                    start = lens_list_cs[i - 1]
-                    masks[r, start:start + lens_list[i]] = 0
-        return masks, labels_list_copy
+        """modelling/bases.py:359-384 -> (masks bool [K_max, B], per-PID index lists in first-appearance order).
+        masks[r, j] is False iff sample j is the r-th occurrence of its PID (the query of round r).  A PID with
+        c < K_max occurrences additionally gets, in rounds r >= c, the index range [cs, cs + c) cleared, where
+        cs is the CUMULATIVE COUNT of the PIDs before it (for the first PID the reference reads cumsum[-1], i.e.
+        an empty range) -- that range is the PID's own block only when the batch is PID-contiguous."""
+        labels = np.asarray(class_labels.detach().cpu().numpy())
+        B = labels.shape[0]
+        _, first, inverse, counts = np.unique(labels, return_index=True, return_inverse=True, return_counts=True)
+        by_first = np.argsort(first, kind="stable")                  # PID groups in order of first appearance
+        group_of_unique = np.empty_like(by_first)
+        group_of_unique[by_first] = np.arange(len(by_first))
+        group = group_of_unique[inverse.reshape(-1)]                 # group id of every sample
+        cnt = counts[by_first]
+        perm = np.argsort(group, kind="stable")                      # samples grouped, batch order kept inside
+        ends = np.cumsum(cnt)
+        starts = ends - cnt
+        occurrence = np.empty(B, np.int64)
+        occurrence[perm] = np.arange(B) - np.repeat(starts, cnt)
+        k_max = int(cnt.max())
+        masks = np.ones((k_max, B), dtype=bool)
+        masks[occurrence, np.arange(B)] = False
+        for g in np.nonzero(cnt < k_max)[0]:
+            lo = int(ends[g - 1])                                    # g == 0 wraps to the total (reference quirk)
+            masks[cnt[g]:, lo:lo + int(cnt[g])] = False
+        index_lists = [perm[starts[g]:ends[g]].tolist() for g in range(len(cnt))]
+        return torch.from_numpy(masks), index_lists
 
     def test_step(self, batch, batch_idx):
         return self.validation_step(batch, batch_idx)

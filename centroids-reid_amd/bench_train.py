@@ -129,6 +129,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
         # identical initial weights on every rank, then data-parallel gradient all-reduce over RCCL
         opt, _ = model.optimizers()
         dist.broadcast(opt.flat, 0)
+        model.backbone.engine.weights_dirty = True      # the parameters are views of opt.flat
         dist.broadcast(model.center_loss.centers.data, 0)
         for b in model.buffers():
             if b.is_floating_point():

@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void loo_centroids_bwd_kernel(const float* __r
 // loads, wave reduction; 16 waves because N is only 32..128 and the kernel is pure latency), then
 // hardest-positive / hardest-negative mining by wave 0.
 // ======================================================================================
+// KIND 0: euclidean (sqrt of the clamped expanded square, triplet_loss.py:27-41); KIND 1: cosine distance
+// clamp(|1 - x.y|, 1e-12) on rows that the caller has already scaled to unit length (triplet_loss.py:44-65).
 constexpr int TM_T = 1024, TM_W = TM_T / 64;
+template <int KIND>
 __global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restrict__ x,
                                                            const int64_t* __restrict__ labels, int N, int D,
                                                            float* __restrict__ dist_ap, float* __restrict__ dist_an,
@@ -90,8 +93,12 @@ __global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restr
     }
     dot = wave_sum(dot); sjj = wave_sum(sjj);
     if (lane == 0) {
-      const float sq = fmaf(-2.0f, dot, saa + sjj);         // xx + yy - 2 x.y   (triplet_loss.py:35-39)
-      drow[j] = sqrtf(fmaxf(sq, 1e-12f));                    // clamp(min=1e-12).sqrt() (:40)
+      if (KIND == 0) {
+        const float sq = fmaf(-2.0f, dot, saa + sjj);       // xx + yy - 2 x.y   (triplet_loss.py:35-39)
+        drow[j] = sqrtf(fmaxf(sq, 1e-12f));                  // clamp(min=1e-12).sqrt() (:40)
+      } else {
+        drow[j] = fmaxf(fabsf(1.0f - dot), 1e-12f);          // abs(1 - sim).clamp(min=eps) (:65)
+      }
     }
   }
   __syncthreads();
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restri
 
 // dx[r,:] += g * sum_a coef[a] * ( [a==r]((xa-xp)/dap - (xa-xn)/dan) + [p_a==r](xp-xa)/dap - [n_a==r](xn-xa)/dan )
 // (gradient of sqrt(clamp(.)) is zero where the clamp was active: dist <= 1e-6).  One workgroup per row.
+template <int KIND>
 __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ x, int N, int D,
                                                           const float* __restrict__ dist_ap,
                                                           const float* __restrict__ dist_an,
@@ -198,7 +206,9 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
       const int p = p_idx[a], n = n_idx[a];
       if (a != r && p != r && n != r) continue;
       const float dap = dist_ap[a], dan = dist_an[a];
-      const float ip = dap > 1e-6f ? c / dap : 0.f, in_ = dan > 1e-6f ? c / dan : 0.f;
+      // cosine: d|1 - u.v| / du = -sign(1 - u.v) v (zero where the clamp is active); the sign is applied below
+      const float ip = KIND == 0 ? (dap > 1e-6f ? c / dap : 0.f) : (dap > 1e-12f ? -c : 0.f);
+      const float in_ = KIND == 0 ? (dan > 1e-6f ? c / dan : 0.f) : (dan > 1e-12f ? -c : 0.f);
       if (a == r) { t_other[k] = p; t_w[k++] = ip; t_other[k] = n; t_w[k++] = -in_; }
       if (p == r) { t_other[k] = a; t_w[k++] = ip; }
       if (n == r) { t_other[k] = a; t_w[k++] = -in_; }
@@ -211,6 +221,30 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
   const float g = gscale * (gscale_ptr ? *gscale_ptr : 1.f);
   const float* xr = x + (int64_t)r * D;
   float* out = dx + (int64_t)r * D;
+  if (KIND == 1) {
+    // every term pairs row r with t_other[k]: fold sign(1 - x_r . x_other) into its weight, then
+    // dx[r] += g * sum_k w_k * x[other_k]
+    __shared__ float part[4];
+    for (int k = 0; k < nt; ++k) {
+      const float* xo = x + (int64_t)t_other[k] * D;
+      float dot = 0.f;
+      for (int d = threadIdx.x; d < D; d += 256) dot = fmaf(xr[d], xo[d], dot);
+      dot = wave_sum(dot);
+      if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dot;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float v = 1.0f - ((part[0] + part[1]) + (part[2] + part[3]));
+        t_w[k] *= v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+      }
+      __syncthreads();
+    }
+    for (int d = threadIdx.x; d < D; d += 256) {
+      float acc = 0.f;
+      for (int k = 0; k < nt; ++k) acc += t_w[k] * x[(int64_t)t_other[k] * D + d];
+      out[d] += g * acc;
+    }
+    return;
+  }
   for (int d = threadIdx.x; d < D; d += 256) {
     const float xv = xr[d];
     float acc = 0.f;
@@ -559,6 +593,81 @@ __global__ __launch_bounds__(256) void gather_mean_rows_kernel(const float* __re
 }
 
 // ======================================================================================
+// Row scaling to unit length with its backward (losses/triplet_loss.py:16-24 `normalize`, :44-54 the two
+// normalisations inside cosine_similarity).  mode 0: y = x / max(|x|, eps); mode 1: y = x / (|x| + eps).
+// One workgroup per row.
+// ======================================================================================
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ x, int D, int mode, float eps,
+                                                          float* __restrict__ y, float* __restrict__ norm) {
+  __shared__ float sh[4];
+  const float* xr = x + (int64_t)blockIdx.x * D;
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) s = fmaf(xr[d], xr[d], s);
+  const float n = sqrtf(block_sum_256(s, sh));
+  const float den = mode == 0 ? fmaxf(n, eps) : n + eps;
+  for (int d = threadIdx.x; d < D; d += 256) y[(int64_t)blockIdx.x * D + d] = xr[d] / den;
+  if (threadIdx.x == 0) norm[blockIdx.x] = n;
+}
+
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norm,
+                                                          const float* __restrict__ dy, int D, int mode, float eps,
+                                                          float* __restrict__ dx) {
+  __shared__ float sh[4];
+  const float* xr = x + (int64_t)blockIdx.x * D;
+  const float* gr = dy + (int64_t)blockIdx.x * D;
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) s = fmaf(xr[d], gr[d], s);
+  const float xg = block_sum_256(s, sh);
+  const float n = norm[blockIdx.x];
+  float a, b;                                   // dx = a * dy - b * x
+  if (mode == 0) {
+    if (n > eps) { a = 1.f / n; b = xg / (n * n * n); } else { a = 1.f / eps; b = 0.f; }
+  } else {
+    const float den = n + eps;
+    a = 1.f / den; b = n > 0.f ? xg / (n * den * den) : 0.f;
+  }
+  for (int d = threadIdx.x; d < D; d += 256) dx[(int64_t)blockIdx.x * D + d] = a * gr[d] - b * xr[d];
+}
+
+// hard_example_mining on a GIVEN distance matrix (losses/triplet_loss.py:68-119): wave per anchor row.
+__global__ __launch_bounds__(64) void mine_from_dist_kernel(const float* __restrict__ dist, const int64_t* __restrict__ labels,
+                                                            int N, float* __restrict__ dist_ap, float* __restrict__ dist_an,
+                                                            int32_t* __restrict__ p_idx, int32_t* __restrict__ n_idx) {
+  const int a = blockIdx.x, lane = threadIdx.x;
+  const int64_t la = labels[a];
+  float bp = -INFINITY, bn = INFINITY;
+  int ip = 0x7fffffff, in_ = 0x7fffffff;
+  for (int j = lane; j < N; j += 64) {
+    const float d = dist[(int64_t)a * N + j];
+    if (labels[j] == la) { if (d > bp) { bp = d; ip = j; } }
+    else { if (d < bn) { bn = d; in_ = j; } }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float obp = __shfl_xor(bp, o, 64); int oip = __shfl_xor(ip, o, 64);
+    if (obp > bp || (obp == bp && oip < ip)) { bp = obp; ip = oip; }
+    float obn = __shfl_xor(bn, o, 64); int oin = __shfl_xor(in_, o, 64);
+    if (obn < bn || (obn == bn && oin < in_)) { bn = obn; in_ = oin; }
+  }
+  if (lane == 0) { dist_ap[a] = bp; dist_an[a] = bn; p_idx[a] = ip; n_idx[a] = in_; }
+}
+
+// d <- sqrt(max(d, lo)) in place (the tail of euclidean_dist, triplet_loss.py:40)
+__global__ __launch_bounds__(256) void clamp_sqrt_kernel(float* __restrict__ d, int64_t n, float lo) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    d[i] = sqrtf(fmaxf(d[i], lo));
+}
+
+// ======================================================================================
 extern "C" {
 
 int creid_loo_centroids_fwd(const float* feat, const uint8_t* is_real, int64_t P, int64_t K, int64_t D,
@@ -577,19 +686,37 @@ int creid_loo_centroids_bwd(const float* dcentroids, const uint8_t* is_real, int
   CREID_LAUNCH_RET();
 }
 
-int creid_triplet_fwd_batched(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t nb, int64_t N,
-                              int64_t D, float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx,
-                              float* coef, float* out4, float* dist_mat, void* stream) {
+static int triplet_fwd_impl(int kind, const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t nb, int64_t N,
+                            int64_t D, float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx,
+                            float* coef, float* out4, float* dist_mat, void* stream) {
   CREID_CHECK_ARG(x && labels && dist_ap && dist_an && p_idx && n_idx && out4 && N > 0 && D > 0 && nb > 0);
   if (D % 4 != 0 || nb > 65535) return CREID_E_SHAPE;
   const size_t smem = (size_t)(D + N) * sizeof(float);
   if (smem > 64 * 1024) return CREID_E_SHAPE;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(triplet_mine_kernel, dim3((unsigned)N, (unsigned)nb), dim3(TM_T), smem, s, x, labels, (int)N, (int)D,
-                     dist_ap, dist_an, p_idx, n_idx, dist_mat);
+  if (kind == 0)
+    hipLaunchKernelGGL(triplet_mine_kernel<0>, dim3((unsigned)N, (unsigned)nb), dim3(TM_T), smem, s, x, labels, (int)N,
+                       (int)D, dist_ap, dist_an, p_idx, n_idx, dist_mat);
+  else
+    hipLaunchKernelGGL(triplet_mine_kernel<1>, dim3((unsigned)N, (unsigned)nb), dim3(TM_T), smem, s, x, labels, (int)N,
+                       (int)D, dist_ap, dist_an, p_idx, n_idx, dist_mat);
   hipLaunchKernelGGL(triplet_loss_kernel, dim3(1, (unsigned)nb), dim3(256), 0, s, dist_ap, dist_an, anchor_mask, (int)N,
                      margin, out4, coef);
   CREID_LAUNCH_RET();
+}
+
+int creid_triplet_fwd_batched(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t nb, int64_t N,
+                              int64_t D, float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx,
+                              float* coef, float* out4, float* dist_mat, void* stream) {
+  return triplet_fwd_impl(0, x, labels, anchor_mask, nb, N, D, margin, dist_ap, dist_an, p_idx, n_idx, coef, out4, dist_mat,
+                          stream);
+}
+
+int creid_triplet_cosine_fwd(const float* x_unit, const int64_t* labels, const uint8_t* anchor_mask, int64_t N, int64_t D,
+                             float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx, float* coef,
+                             float* out4, float* dist_mat, void* stream) {
+  return triplet_fwd_impl(1, x_unit, labels, anchor_mask, 1, N, D, margin, dist_ap, dist_an, p_idx, n_idx, coef, out4,
+                          dist_mat, stream);
 }
 
 int creid_triplet_fwd(const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t N, int64_t D,
@@ -599,13 +726,60 @@ int creid_triplet_fwd(const float* x, const int64_t* labels, const uint8_t* anch
                                    dist_mat, stream);
 }
 
+static int triplet_bwd_impl(int kind, const float* x, int64_t nb, int64_t N, int64_t D, const float* dist_ap,
+                            const float* dist_an, const int32_t* p_idx, const int32_t* n_idx, const float* coef,
+                            const float* gscale_dev, float gscale, float* dx_accum, void* stream) {
+  CREID_CHECK_ARG(x && dist_ap && dist_an && p_idx && n_idx && coef && dx_accum && N > 0 && D > 0 && nb > 0);
+  if ((size_t)N * 8 * sizeof(float) > 48 * 1024 || nb > 65535) return CREID_E_SHAPE;
+  if (kind == 0)
+    hipLaunchKernelGGL(triplet_bwd_kernel<0>, dim3((unsigned)N, (unsigned)nb), dim3(256), (size_t)N * 8 * sizeof(float),
+                       as_stream(stream), x, (int)N, (int)D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum);
+  else
+    hipLaunchKernelGGL(triplet_bwd_kernel<1>, dim3((unsigned)N, (unsigned)nb), dim3(256), (size_t)N * 8 * sizeof(float),
+                       as_stream(stream), x, (int)N, (int)D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum);
+  CREID_LAUNCH_RET();
+}
+
 int creid_triplet_bwd_batched(const float* x, int64_t nb, int64_t N, int64_t D, const float* dist_ap, const float* dist_an,
                               const int32_t* p_idx, const int32_t* n_idx, const float* coef, const float* gscale_dev,
                               float gscale, float* dx_accum, void* stream) {
-  CREID_CHECK_ARG(x && dist_ap && dist_an && p_idx && n_idx && coef && dx_accum && N > 0 && D > 0 && nb > 0);
-  if ((size_t)N * 8 * sizeof(float) > 48 * 1024 || nb > 65535) return CREID_E_SHAPE;
-  hipLaunchKernelGGL(triplet_bwd_kernel, dim3((unsigned)N, (unsigned)nb), dim3(256), (size_t)N * 8 * sizeof(float),
-                     as_stream(stream), x, (int)N, (int)D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum);
+  return triplet_bwd_impl(0, x, nb, N, D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum, stream);
+}
+
+int creid_triplet_cosine_bwd(const float* x_unit, int64_t N, int64_t D, const float* dist_ap, const float* dist_an,
+                             const int32_t* p_idx, const int32_t* n_idx, const float* coef, const float* gscale_dev,
+                             float gscale, float* dx_accum, void* stream) {
+  return triplet_bwd_impl(1, x_unit, 1, N, D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_dev, gscale, dx_accum, stream);
+}
+
+int creid_rownorm_fwd(const float* x, int64_t N, int64_t D, int mode, float eps, float* y, float* norm, void* stream) {
+  CREID_CHECK_ARG(x && y && norm && N > 0 && D > 0 && (mode == 0 || mode == 1));
+  hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), x, (int)D, mode, eps, y, norm);
+  CREID_LAUNCH_RET();
+}
+
+int creid_rownorm_bwd(const float* x, const float* norm, const float* dy, int64_t N, int64_t D, int mode, float eps,
+                      float* dx, void* stream) {
+  CREID_CHECK_ARG(x && norm && dy && dx && N > 0 && D > 0 && (mode == 0 || mode == 1));
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), x, norm, dy, (int)D, mode, eps,
+                     dx);
+  CREID_LAUNCH_RET();
+}
+
+int creid_hard_mine_from_dist(const float* dist_mat, const int64_t* labels, int64_t N, float* dist_ap, float* dist_an,
+                              int32_t* p_idx, int32_t* n_idx, void* stream) {
+  CREID_CHECK_ARG(dist_mat && labels && dist_ap && dist_an && p_idx && n_idx && N > 0);
+  hipLaunchKernelGGL(mine_from_dist_kernel, dim3((unsigned)N), dim3(64), 0, as_stream(stream), dist_mat, labels, (int)N,
+                     dist_ap, dist_an, p_idx, n_idx);
+  CREID_LAUNCH_RET();
+}
+
+int creid_clamp_sqrt_inplace(float* d, int64_t n, float lo, void* stream) {
+  CREID_CHECK_ARG(d && n >= 0);
+  if (n == 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(clamp_sqrt_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d, n, lo);
   CREID_LAUNCH_RET();
 }
 

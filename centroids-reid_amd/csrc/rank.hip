@@ -412,7 +412,9 @@ __global__ __launch_bounds__(256) void eval_reduce_kernel(const uint8_t* __restr
                                                           float* __restrict__ out_cmc, double* __restrict__ out_map,
                                                           double* __restrict__ out_topk,
                                                           int64_t* __restrict__ out_nvalid) {
-  __shared__ unsigned s_hist[64];   // first-match rank histogram, bins 0..max_rank-1 (max_rank <= 64)
+  __shared__ unsigned s_hist[64];   // first-match rank histogram, bins 0..63 (max_rank <= 64): the CMC curve is cut at
+                                    // max_rank, the top-k hits (k up to 50) use the UNtruncated match row like
+                                    // top_k_retrieval(orig_cmc) of utils/eval_reid.py:18-22,84
   __shared__ unsigned s_nvalid;
   __shared__ double s_sum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256) void eval_reduce_kernel(const uint8_t* __restr
       ++nv;
       sum += ap[i];
       const int f = first[i];
-      if (f < max_rank) atomicAdd(&s_hist[f], 1u);
+      if (f < 64) atomicAdd(&s_hist[f], 1u);
     }
   }
   sum = wave_sum_d(sum);
@@ -440,12 +442,11 @@ __global__ __launch_bounds__(256) void eval_reduce_kernel(const uint8_t* __restr
     unsigned run = 0;
     const int ks[5] = {1, 5, 10, 20, 50};
     int kq = 0;
-    for (int r = 0; r < max_rank; ++r) {
+    for (int r = 0; r < 50 || r < max_rank; ++r) {
       run += s_hist[r];
-      out_cmc[r] = (float)run / (float)nvalid;          // float32 like the reference's all_cmc
+      if (r < max_rank) out_cmc[r] = (float)run / (float)nvalid;   // float32 like the reference's all_cmc
       while (kq < 5 && ks[kq] == r + 1) { out_topk[kq] = (double)run / (double)nvalid; ++kq; }
     }
-    while (kq < 5) { out_topk[kq] = (double)run / (double)nvalid; ++kq; }  // k > max_rank: all kept
   }
 }
 

@@ -1,0 +1,326 @@
+// Stages D + E fused for metric-only evaluation: CMC / mAP WITHOUT ever writing the m x n distance matrix or
+// the ranked index matrix (utils/reid_metric.py:93-151 + utils/eval_reid.py:25-92 of the reference, whose
+// `_commpute_batches_double` path exists because 50k x 200k x 4 B does not fit anywhere).
+//
+// eval_func only needs, per query, the kept-rank of each POSITIVE gallery entry (same pid, different camera):
+//     rank(p) = #{kept j : (d_j, j) < (d_p, p)},   kept = everything except (same pid AND same camera)
+// and kept = negatives (other pid; never removed) + positives.  So:
+//   1. stream_poslist_kernel   per query: distances to its few positives (gathered rows), sorted by (d, index);
+//   2. sqdist_count_f32_kernel the full Q.G^T contraction on the f32 MFMA pipe, tile by tile; the epilogue turns
+//                              every NEGATIVE's distance into "how many positives of this query rank before it"
+//                              (binary search in the query's LDS-resident positive list) and bumps an LDS
+//                              histogram -- the tile is consumed in registers and never stored;
+//   3. stream_finalize_kernel  prefix sums of the histogram -> rank of every positive -> AP, first match.
+// Bit-consistency with the materialised path (creid_sqdist_matrix + creid_rank_rows + creid_cmc_ap_ranked): a
+// v_mfma_f32_32x32x2_f32 accumulation is the sequential fmaf chain over k, which kernel 1 reproduces with plain
+// fmaf in the same order, and both use the same "(qq + gg) - 2 dot" epilogue, so positives and negatives compare
+// on identical bits and ties resolve by gallery index exactly like the stable rank kernel.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace {
+constexpr int SQ_TM = 64, SQ_TN = 256, SQ_BK = 16, SQ_LDA = SQ_TM + 1, SQ_LDB = SQ_TN + 1;
+constexpr int PL_MAXC = 128, PL_BK = 64;
+
+// float -> unsigned with the same order (negatives included; squared distances may be slightly negative)
+__device__ __forceinline__ unsigned mono_key(float d) {
+  const unsigned u = __float_as_uint(d);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
+// 1. positives.  One 256-thread workgroup per query.  Candidates = the gallery rows of the query's pid (CSR
+//    slice of g_order, ascending gallery index), kept when their camera differs from the query's.  The
+//    q / candidate rows go through LDS in 64-wide k chunks; thread c runs the fmaf chain of candidate c.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_poslist_kernel(
+    const float* __restrict__ q, const float* __restrict__ g, const float* __restrict__ qq, const float* __restrict__ gg,
+    int D, const int32_t* __restrict__ q_slot, const int64_t* __restrict__ csr_off, const int32_t* __restrict__ g_order,
+    const int64_t* __restrict__ q_cams, const int64_t* __restrict__ g_cams, int cap, unsigned* __restrict__ pos_key,
+    int32_t* __restrict__ pos_idx, int32_t* __restrict__ npos) {
+  __shared__ float qs[PL_BK];
+  __shared__ float tile[PL_MAXC][PL_BK + 1];
+  __shared__ int cand[PL_MAXC];
+  __shared__ unsigned skey[PL_MAXC];
+  __shared__ int s_n, s_wcnt[4];
+  const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned* okey = pos_key + (int64_t)qi * cap;
+  int32_t* oidx = pos_idx + (int64_t)qi * cap;
+  for (int i = tid; i < cap; i += 256) { okey[i] = 0xffffffffu; oidx[i] = 0x7fffffff; }   // padding for the search
+  const int slot = q_slot[qi];
+  if (slot < 0) { if (tid == 0) npos[qi] = 0; return; }
+  const int64_t c0 = csr_off[slot], c1 = csr_off[slot + 1];
+  const int64_t qc = q_cams[qi];
+  // compaction of the kept candidates in gallery-index order (every pass handles 256 CSR entries)
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  bool overflow = false;
+  for (int64_t b = c0; b < c1; b += 256) {
+    const int64_t e = b + tid;
+    int gi = -1;
+    if (e < c1) { gi = g_order[e]; if (g_cams[gi] == qc) gi = -1; }
+    const unsigned long long bal = __ballot(gi >= 0);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = s_n;
+    for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+    const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if (gi >= 0) {
+      const int p = base + __popcll(bal & lanemask_lt());
+      if (p < PL_MAXC) cand[p] = gi;
+    }
+    __syncthreads();
+    if (tid == 0) s_n += tot;
+    __syncthreads();
+  }
+  int nc = s_n;
+  if (nc > cap || nc > PL_MAXC) { overflow = true; nc = 0; }
+  if (overflow) { if (tid == 0) npos[qi] = -1; return; }          // the caller sends such queries to the general path
+  if (nc == 0) { if (tid == 0) npos[qi] = 0; return; }
+  const float* qrow = q + (int64_t)qi * D;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < D; k0 += PL_BK) {
+    __syncthreads();
+    if (tid < PL_BK) qs[tid] = (k0 + tid < D) ? qrow[k0 + tid] : 0.f;
+    for (int c = wave; c < nc; c += 4)
+      tile[c][lane] = (k0 + lane < D) ? g[(int64_t)cand[c] * D + k0 + lane] : 0.f;
+    __syncthreads();
+    if (tid < nc) {
+#pragma unroll 16
+      for (int kk = 0; kk < PL_BK; ++kk) acc = fmaf(qs[kk], tile[tid][kk], acc);      // the MFMA's own k order
+    }
+  }
+  if (tid < nc) {
+    const int gi = cand[tid];
+    skey[tid] = mono_key(fmaf(-2.0f, acc, qq[qi] + gg[gi]));                          // sqdist epilogue, same bits
+  }
+  __syncthreads();
+  if (tid < nc) {                                      // rank by counting over (key, gallery index)
+    const unsigned k = skey[tid];
+    const int gi = cand[tid];
+    int pos = 0;
+    for (int c = 0; c < nc; ++c) {
+      const unsigned kc = skey[c];
+      pos += (kc < k || (kc == k && cand[c] < gi)) ? 1 : 0;
+    }
+    okey[pos] = k; oidx[pos] = gi;
+  }
+  if (tid == 0) npos[qi] = nc;
+}
+
+// ----------------------------------------------------------------------------------------
+// 2. streamed contraction + count.  Workgroup = (query tile of 64 rows, slice of the gallery); 4 waves as 2 x 2,
+//    each 32 rows x 128 columns (1 x 4 MFMA 32x32 blocks) of a 64 x 256 tile; K-major LDS operands
+//    ([k][row], odd pitch -> conflict-free ds_read_b32 for the A[i = lane&31][k = lane>>5] operand layout).
+//    Dynamic LDS: this query tile's positive keys [64][cap] and the histogram [64][cap].
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
+    const float* __restrict__ q, const float* __restrict__ g, const float* __restrict__ qq, const float* __restrict__ gg,
+    int m, int n, int D, const int64_t* __restrict__ q_pids, const int64_t* __restrict__ g_pids, int cap, int log2cap,
+    const unsigned* __restrict__ pos_key, const int32_t* __restrict__ pos_idx, const int32_t* __restrict__ npos,
+    unsigned* __restrict__ hist_out, int tiles_m, int tiles_n, int nsplit) {
+  __shared__ float As[2][SQ_BK][SQ_LDA];
+  __shared__ float Bs[2][SQ_BK][SQ_LDB];
+  __shared__ float s_qq[SQ_TM];
+  __shared__ long long s_qpid[SQ_TM];
+  __shared__ int s_np[SQ_TM];
+  __shared__ unsigned s_kmax[SQ_TM];
+  extern __shared__ __attribute__((aligned(16))) unsigned dyn[];
+  unsigned* s_keys = dyn;                        // [64][cap]
+  unsigned* s_hist = dyn + SQ_TM * cap;          // [64][cap]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  // XCD-aware order: consecutive ids land on different XCDs; give every XCD a contiguous run of (split, tile_m)
+  // pairs with the split major, so the workgroups sharing an L2 walk the SAME gallery tiles at the same time.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    bid = base + (bid >> 3);
+  }
+  const int split = bid / tiles_m, tile_m = bid - split * tiles_m;
+  const int row0 = tile_m * SQ_TM;
+  const int t_per = (tiles_n + nsplit - 1) / nsplit;
+  const int t0 = split * t_per, t1 = min(t0 + t_per, tiles_n);
+
+  for (int i = tid; i < SQ_TM * cap; i += 256) {
+    const int r = i >> log2cap, rr = row0 + r;
+    s_keys[i] = rr < m ? pos_key[(int64_t)rr * cap + (i & (cap - 1))] : 0xffffffffu;
+    s_hist[i] = 0u;
+  }
+  if (tid < SQ_TM) {
+    const int rr = row0 + tid;
+    const int np = rr < m ? npos[rr] : 0;
+    s_np[tid] = np > 0 ? np : 0;
+    s_qq[tid] = rr < m ? qq[rr] : 0.f;
+    s_qpid[tid] = rr < m ? (long long)q_pids[rr] : 0;
+    s_kmax[tid] = np > 0 ? pos_key[(int64_t)rr * cap + np - 1] : 0u;
+  }
+
+  const int lrow = tid >> 2, lkc = tid & 3;
+  const float* ap = q + (int64_t)min(row0 + lrow, m - 1) * D + 4 * lkc;
+  for (int tn = t0; tn < t1; ++tn) {
+    const int col0 = tn * SQ_TN;
+    const float* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bp[i] = g + (int64_t)min(col0 + lrow + 64 * i, n - 1) * D + 4 * lkc;
+    float4 ra, rb[4];
+    auto gload = [&](int k0) {
+      if (k0 + 4 * lkc < D) {
+        ra = *reinterpret_cast<const float4*>(ap + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+      } else {
+        ra = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto lstore = [&](int buf) {
+      As[buf][4 * lkc + 0][lrow] = ra.x; As[buf][4 * lkc + 1][lrow] = ra.y;
+      As[buf][4 * lkc + 2][lrow] = ra.z; As[buf][4 * lkc + 3][lrow] = ra.w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = lrow + 64 * i;
+        Bs[buf][4 * lkc + 0][r] = rb[i].x; Bs[buf][4 * lkc + 1][r] = rb[i].y;
+        Bs[buf][4 * lkc + 2][r] = rb[i].z; Bs[buf][4 * lkc + 3][r] = rb[i].w;
+      }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nk = (D + SQ_BK - 1) / SQ_BK;
+    gload(0);
+    __syncthreads();                               // previous tile's readers are done with both LDS buffers
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < nk) gload((t + 1) * SQ_BK);
+#pragma unroll
+      for (int kk = 0; kk < SQ_BK; kk += 2) {
+        const float a = As[buf][kk + kh][wm * 32 + l31];
+        float b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kk + kh][wn * 128 + j * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+      }
+      if (t + 1 < nk) lstore(buf ^ 1);
+      __syncthreads();
+    }
+    // ---- epilogue: the tile is consumed here
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = col0 + wn * 128 + j * 32 + l31;
+      const bool okc = c < n;
+      const float gv = okc ? gg[c] : 0.f;
+      const long long gp = okc ? (long long)g_pids[c] : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int np = s_np[rl];
+        if (!okc || np == 0 || gp == s_qpid[rl]) continue;         // positives / removed entries are not counted
+        const unsigned key = mono_key(fmaf(-2.0f, acc[j][r], s_qq[rl] + gv));
+        if (key > s_kmax[rl]) continue;                            // behind every positive: affects no rank
+        const unsigned* K = s_keys + (rl << log2cap);
+        int lo = 0;
+        for (int step = cap >> 1; step > 0; step >>= 1)
+          if (K[lo + step - 1] < key) lo += step;
+        if (K[lo] < key) ++lo;                                     // lo = #positives with key strictly below
+        while (lo < np && K[lo] == key && pos_idx[(int64_t)(row0 + rl) * cap + lo] < c) ++lo;   // ties: by gallery index
+        if (lo < np) atomicAdd(&s_hist[(rl << log2cap) + lo], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < SQ_TM * cap; i += 256) {
+    const unsigned v = s_hist[i];
+    const int rr = row0 + (i >> log2cap);
+    if (v && rr < m) atomicAdd(&hist_out[(int64_t)rr * cap + (i & (cap - 1))], v);      // integer: order-independent
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// 3. per-query AP / first match from the histogram (one thread per query; float64 like utils/eval_reid.py:75-79)
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_finalize_kernel(const int32_t* __restrict__ npos,
+                                                              const unsigned* __restrict__ hist, int m, int cap,
+                                                              uint8_t* __restrict__ out_valid, double* __restrict__ out_ap,
+                                                              int32_t* __restrict__ out_first) {
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= m) return;
+  const int np = npos[qi];
+  if (np <= 0) { out_valid[qi] = np < 0 ? 2 : 0; out_ap[qi] = 0.0; out_first[qi] = -1; return; }
+  const unsigned* h = hist + (int64_t)qi * cap;
+  long long before = 0;
+  double ap = 0.0;
+  for (int s = 0; s < np; ++s) {
+    before += h[s];                                    // negatives ahead of positive s
+    ap += (double)(s + 1) / (double)(before + s + 1);  // matches so far / 1-based kept position
+  }
+  out_valid[qi] = 1;
+  out_ap[qi] = ap / (double)np;
+  out_first[qi] = (int32_t)h[0];
+}
+
+extern "C" {
+
+int creid_stream_poslist(const float* q, const float* g, const float* qq, const float* gg, int64_t m, int64_t n,
+                         int64_t D, const int32_t* q_slot, const int64_t* csr_off, const int32_t* g_order,
+                         const int64_t* q_cams, const int64_t* g_cams, int32_t cap, uint32_t* pos_key, int32_t* pos_idx,
+                         int32_t* npos, void* stream) {
+  CREID_CHECK_ARG(m >= 0 && n > 0 && D > 0);
+  if (m == 0) return 0;
+  CREID_CHECK_ARG(q && g && qq && gg && q_slot && csr_off && g_order && q_cams && g_cams && pos_key && pos_idx && npos);
+  if (cap < 2 || cap > PL_MAXC || (cap & (cap - 1)) != 0) return CREID_E_SHAPE;
+  if (n > 0x7ffffff0LL || m > 0x7ffffff0LL) return CREID_E_SHAPE;
+  hipLaunchKernelGGL(stream_poslist_kernel, dim3((unsigned)m), dim3(256), 0, as_stream(stream), q, g, qq, gg, (int)D, q_slot,
+                     csr_off, g_order, q_cams, g_cams, (int)cap, pos_key, pos_idx, npos);
+  CREID_LAUNCH_RET();
+}
+
+int creid_stream_count(const float* q, const float* g, const float* qq, const float* gg, int64_t m, int64_t n, int64_t D,
+                       const int64_t* q_pids, const int64_t* g_pids, int32_t cap, const uint32_t* pos_key,
+                       const int32_t* pos_idx, const int32_t* npos, uint32_t* hist, void* stream) {
+  CREID_CHECK_ARG(m >= 0 && n > 0 && D > 0);
+  if (m == 0) return 0;
+  CREID_CHECK_ARG(q && g && qq && gg && q_pids && g_pids && pos_key && pos_idx && npos && hist);
+  if (cap < 2 || cap > PL_MAXC || (cap & (cap - 1)) != 0 || D % 4 != 0) return CREID_E_SHAPE;
+  if (n > 0x7ffffff0LL || m > 0x7ffffff0LL) return CREID_E_SHAPE;
+  int log2cap = 0;
+  while ((1 << log2cap) < cap) ++log2cap;
+  const int tiles_m = (int)((m + SQ_TM - 1) / SQ_TM), tiles_n = (int)((n + SQ_TN - 1) / SQ_TN);
+  // enough workgroups for two per CU, but never fewer than ~4 gallery tiles per workgroup (per-tile restart cost)
+  static const int target = [] { const char* e = getenv("CREID_STREAM_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  int nsplit = (target + tiles_m - 1) / tiles_m;
+  if (nsplit > tiles_n) nsplit = tiles_n;
+  if (nsplit < 1) nsplit = 1;
+  const int t_per = (tiles_n + nsplit - 1) / nsplit;
+  nsplit = (tiles_n + t_per - 1) / t_per;                       // drop empty slices
+  const size_t dyn = (size_t)2 * SQ_TM * cap * sizeof(unsigned);
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sqdist_count_f32_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        2 * SQ_TM * PL_MAXC * (int)sizeof(unsigned));
+  if (attr_rc != hipSuccess) return (int)attr_rc;
+  hipLaunchKernelGGL(sqdist_count_f32_kernel, dim3((unsigned)(tiles_m * nsplit)), dim3(256), dyn, as_stream(stream), q, g, qq,
+                     gg, (int)m, (int)n, (int)D, q_pids, g_pids, (int)cap, log2cap, pos_key, pos_idx, npos, hist, tiles_m,
+                     tiles_n, nsplit);
+  CREID_LAUNCH_RET();
+}
+
+int creid_stream_finalize(const int32_t* npos, const uint32_t* hist, int64_t m, int32_t cap, uint8_t* valid, double* ap,
+                          int32_t* first, void* stream) {
+  CREID_CHECK_ARG(m >= 0);
+  if (m == 0) return 0;
+  CREID_CHECK_ARG(npos && hist && valid && ap && first && cap >= 2);
+  hipLaunchKernelGGL(stream_finalize_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, as_stream(stream), npos, hist,
+                     (int)m, (int)cap, valid, ap, first);
+  CREID_LAUNCH_RET();
+}
+
+}  // extern "C"

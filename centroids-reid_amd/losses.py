@@ -14,36 +14,65 @@ from torch import nn
 from . import ops
 
 
-def euclidean_dist(x, y=None):
-    """losses/triplet_loss.py:27-41 for the x-vs-x case used by the loss."""
-    if y is not None and y is not x:
-        raise NotImplementedError("only the self-distance used by TripletLoss is on the hot path")
-    labels = torch.zeros(x.shape[0], dtype=torch.int64, device=x.device)
-    return ops.pairwise_dist_mine(x, labels)[0]
+def normalize(x, axis=-1):
+    """losses/triplet_loss.py:16-24: x / (|x|_2 + 1e-12) along the last dimension of a [N, D] tensor."""
+    assert x.dim() == 2 and axis in (-1, 1)
+    return ops.RowNormalize.apply(x, 1, 1e-12)
 
 
-def hard_example_mining(features, labels, return_inds=False):
-    """losses/triplet_loss.py:68-119, fused with the distance computation (takes FEATURES)."""
-    _, dap, dan, pi, ni = ops.pairwise_dist_mine(features, labels)
+def euclidean_dist(x, y):
+    """losses/triplet_loss.py:27-41: sqrt(clamp(|x_i|^2 + |y_j|^2 - 2 x_i.y_j, 1e-12)) -> [m, n]."""
+    return ops.EuclideanDist.apply(x, y)
+
+
+def cosine_similarity(x, y, eps=1e-12):
+    """losses/triplet_loss.py:44-54 (rows scaled by 1 / max(|.|, eps), then the inner-product matrix)."""
+    xn, yn = ops.RowNormalize.apply(x, 0, eps), ops.RowNormalize.apply(y, 0, eps)
+    return ops.LinearNoBiasFn.apply(xn, yn)                  # xn @ yn^T on the HIP GEMM
+
+
+def cosine_dist(x, y, eps=1e-12):
+    """losses/triplet_loss.py:57-65."""
+    return torch.abs(1 - cosine_similarity(x, y, eps)).clamp(min=eps)
+
+
+def hard_example_mining(dist_mat, labels, return_inds=False):
+    """losses/triplet_loss.py:68-119 on a square distance matrix [N, N]."""
+    assert dist_mat.dim() == 2 and dist_mat.shape[0] == dist_mat.shape[1]
+    dap, dan, pi, ni = ops.HardMineFromDist.apply(dist_mat, labels)
     return (dap, dan, pi, ni) if return_inds else (dap, dan)
 
 
 class TripletLoss(object):
-    """losses/triplet_loss.py:122-173."""
+    """losses/triplet_loss.py:122-173.  The distance matrix, the mining and the loss run as ONE fused pass over
+    the features (the [N, N] matrix is never written); `dist_func` selects the euclidean or the cosine form and
+    normalize_feature=True prepends the reference's `normalize` (:141-142)."""
 
     def __init__(self, margin=None, dist_func="euclidean"):
         self.margin = margin
-        if dist_func != "euclidean":
-            raise NotImplementedError("SOLVER.DISTANCE_FUNC='cosine' is not on the accelerated path yet")
-        self.dist_func = dist_func
+        if dist_func not in ("euclidean", "cosine"):
+            raise KeyError(dist_func)             # the reference leaves self.dist_func unset -> AttributeError on call
+        self.dist_name = dist_func
+        self.dist_func = cosine_dist if dist_func == "cosine" else euclidean_dist
 
     def __call__(self, global_feat, labels, warmup_margin=False, print_data=False, normalize_feature=False,
                  mask=None):
         if normalize_feature:
-            raise NotImplementedError("normalize_feature=True is never used by the reference's training step")
-        loss, dist_ap, dist_an, _ = ops.TripletHardMine.apply(global_feat, labels, mask, self.margin)
+            global_feat = normalize(global_feat, axis=-1)
+        if self.dist_name == "cosine":
+            unit = ops.RowNormalize.apply(global_feat, 0, 1e-12)
+            loss, dist_ap, dist_an, _ = ops.TripletHardMine.apply(unit, labels, mask, self.margin, True)
+        else:
+            loss, dist_ap, dist_an, _ = ops.TripletHardMine.apply(global_feat, labels, mask, self.margin)
         if mask is not None:                      # losses/triplet_loss.py:148-151
             dist_ap, dist_an = dist_ap[mask], dist_an[mask]
+        if print_data:                            # :158-171
+            print(f"LOSS: {loss.item()}")
+            print(f"precision: {(dist_an > dist_ap).float().mean()}")
+            if self.margin is not None:
+                print(f"proportion of triplets that satisfy margin: {(dist_an > dist_ap + self.margin).float().mean()}")
+            print(f"AP mean distance: {dist_ap.mean()}")
+            print(f"AN mean distance: {dist_an.mean()}")
         return loss, dist_ap, dist_an
 
 

@@ -62,7 +62,9 @@ class TripletHardMine(torch.autograd.Function):
     """losses/triplet_loss.py:139-173 -> (loss, dist_ap[N], dist_an[N], stats4)."""
 
     @staticmethod
-    def forward(ctx, x, labels, mask, margin):
+    def forward(ctx, x, labels, mask, margin, cosine=False):
+        """cosine=True: `x` holds unit-length rows (RowNormalize mode 0) and the distance is
+        clamp(|1 - x_i.x_j|, 1e-12) (losses/triplet_loss.py:57-65)."""
         x = _f32c(x)
         labels = labels.to(torch.int64).contiguous()
         L.require_gpu(x, labels)
@@ -75,11 +77,11 @@ class TripletHardMine(torch.autograd.Function):
         ni = torch.empty(N, dtype=torch.int32, device=dev)
         coef = torch.empty(N, dtype=torch.float32, device=dev)
         out4 = torch.empty(4, dtype=torch.float32, device=dev)
-        L.check(L.lib().creid_triplet_fwd(L.ptr(x), L.ptr(labels), L.ptr(m8), N, D,
-                                          float(margin) if margin is not None else -1.0, L.ptr(dap), L.ptr(dan),
-                                          L.ptr(pi), L.ptr(ni), L.ptr(coef), L.ptr(out4), None, L.stream()),
-                "creid_triplet_fwd")
+        fn = L.lib().creid_triplet_cosine_fwd if cosine else L.lib().creid_triplet_fwd
+        L.check(fn(L.ptr(x), L.ptr(labels), L.ptr(m8), N, D, float(margin) if margin is not None else -1.0, L.ptr(dap),
+                   L.ptr(dan), L.ptr(pi), L.ptr(ni), L.ptr(coef), L.ptr(out4), None, L.stream()), "creid_triplet_fwd")
         ctx.save_for_backward(x, dap, dan, pi, ni, coef)
+        ctx.cosine = cosine
         ctx.mark_non_differentiable(dap, dan, out4)
         return out4[0].clone(), dap, dan, out4
 
@@ -89,9 +91,103 @@ class TripletHardMine(torch.autograd.Function):
         N, D = x.shape
         dx = torch.zeros_like(x)
         g = _f32c(gloss.reshape(1))
-        L.check(L.lib().creid_triplet_bwd(L.ptr(x), N, D, L.ptr(dap), L.ptr(dan), L.ptr(pi), L.ptr(ni), L.ptr(coef),
-                                          L.ptr(g), 1.0, L.ptr(dx), L.stream()), "creid_triplet_bwd")
-        return dx, None, None, None
+        fn = L.lib().creid_triplet_cosine_bwd if ctx.cosine else L.lib().creid_triplet_bwd
+        L.check(fn(L.ptr(x), N, D, L.ptr(dap), L.ptr(dan), L.ptr(pi), L.ptr(ni), L.ptr(coef), L.ptr(g), 1.0, L.ptr(dx),
+                   L.stream()), "creid_triplet_bwd")
+        return dx, None, None, None, None
+
+
+class RowNormalize(torch.autograd.Function):
+    """mode 0: x / max(|x|, eps) (cosine_similarity, losses/triplet_loss.py:50-52);
+    mode 1: x / (|x| + eps) (`normalize`, losses/triplet_loss.py:16-24)."""
+
+    @staticmethod
+    def forward(ctx, x, mode, eps):
+        x = _f32c(x)
+        L.require_gpu(x)
+        N, D = x.shape
+        y = torch.empty_like(x)
+        norm = torch.empty(N, dtype=torch.float32, device=x.device)
+        L.check(L.lib().creid_rownorm_fwd(L.ptr(x), N, D, int(mode), float(eps), L.ptr(y), L.ptr(norm), L.stream()),
+                "creid_rownorm_fwd")
+        ctx.save_for_backward(x, norm)
+        ctx.cfg = (int(mode), float(eps))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, norm = ctx.saved_tensors
+        mode, eps = ctx.cfg
+        N, D = x.shape
+        dx = torch.empty_like(x)
+        L.check(L.lib().creid_rownorm_bwd(L.ptr(x), L.ptr(norm), L.ptr(_f32c(dy)), N, D, mode, eps, L.ptr(dx), L.stream()),
+                "creid_rownorm_bwd")
+        return dx, None, None
+
+
+class HardMineFromDist(torch.autograd.Function):
+    """hard_example_mining(dist_mat, labels, return_inds=True) (losses/triplet_loss.py:68-119); the gradient
+    flows back to the two selected entries of each row, like the reference's masked max / min."""
+
+    @staticmethod
+    def forward(ctx, dist_mat, labels):
+        d = _f32c(dist_mat)
+        labels = labels.to(torch.int64).contiguous()
+        L.require_gpu(d, labels)
+        N = d.shape[0]
+        dev = d.device
+        dap = torch.empty(N, dtype=torch.float32, device=dev); dan = torch.empty_like(dap)
+        pi = torch.empty(N, dtype=torch.int32, device=dev); ni = torch.empty_like(pi)
+        L.check(L.lib().creid_hard_mine_from_dist(L.ptr(d), L.ptr(labels), N, L.ptr(dap), L.ptr(dan), L.ptr(pi), L.ptr(ni),
+                                                  L.stream()), "creid_hard_mine_from_dist")
+        pi64, ni64 = pi.long(), ni.long()
+        ctx.save_for_backward(pi64, ni64)
+        ctx.N = N
+        ctx.mark_non_differentiable(pi64, ni64)
+        return dap, dan, pi64, ni64
+
+    @staticmethod
+    def backward(ctx, gap, gan, _gp, _gn):
+        pi, ni = ctx.saved_tensors
+        g = torch.zeros((ctx.N, ctx.N), dtype=torch.float32, device=pi.device)
+        g.scatter_add_(1, pi[:, None], gap[:, None].float())
+        g.scatter_add_(1, ni[:, None], gan[:, None].float())
+        return g, None
+
+
+class EuclideanDist(torch.autograd.Function):
+    """euclidean_dist(x, y) of losses/triplet_loss.py:27-41 for two different row sets: the squared matrix comes
+    from the MFMA distance kernel of the evaluation stage, then clamp(min=1e-12).sqrt() in place."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x = _f32c(x); y = _f32c(y)
+        L.require_gpu(x, y)
+        lib = L.lib()
+        m, n, D = x.shape[0], y.shape[0], x.shape[1]
+        dev = x.device
+        xx = torch.empty(m, dtype=torch.float32, device=dev); yy = torch.empty(n, dtype=torch.float32, device=dev)
+        L.check(lib.creid_row_sqnorm(L.ptr(x), L.ptr(xx), m, D, L.F32, L.stream()), "creid_row_sqnorm")
+        L.check(lib.creid_row_sqnorm(L.ptr(y), L.ptr(yy), n, D, L.F32, L.stream()), "creid_row_sqnorm")
+        d = torch.empty((m, n), dtype=torch.float32, device=dev)
+        L.check(lib.creid_sqdist_matrix(L.ptr(x), L.ptr(y), L.ptr(xx), L.ptr(yy), m, n, D, L.F32, L.ptr(d), n, L.stream()),
+                "creid_sqdist_matrix")
+        L.check(lib.creid_clamp_sqrt_inplace(L.ptr(d), m * n, 1e-12, L.stream()), "creid_clamp_sqrt_inplace")
+        ctx.save_for_backward(x, y, d)
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, d = ctx.saved_tensors
+        m, n, D = x.shape[0], y.shape[0], x.shape[1]
+        # d dist_ij / d x_i = (x_i - y_j) / dist_ij, zero where the clamp was active (dist == 1e-6)
+        w = torch.where(d > 1e-6, _f32c(g) / d, torch.zeros_like(d)).contiguous()
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            dx = w.sum(1, keepdim=True) * x - gemm_f32(w, n, 1, y, D, 1, m, D, n)          # rowsum(W) x - W @ y
+        if ctx.needs_input_grad[1]:
+            dy = w.sum(0)[:, None] * y - gemm_f32(w, 1, n, x, D, 1, n, D, m)               # colsum(W) y - W^T @ x
+        return dx, dy
 
 
 def pairwise_dist_mine(x, labels):

@@ -109,6 +109,8 @@ def eval_func_device(indices: torch.Tensor, q_pids, g_pids, q_camids, g_camids, 
     if camsets:
         g_camids = _camset_masks(g_camids)
         q_camids = np.asarray([int(np.atleast_1d(c)[0]) for c in q_camids], np.int64)
+        if q_camids.size and (q_camids.min() < 0 or q_camids.max() >= 63):       # the kernel shifts a 64-bit mask by it
+            raise L.CreidError("camera-set evaluation supports camera ids 0..62")
     qp, gp, qc, gc = (_dev_i64(a, dev) for a in (q_pids, g_pids, q_camids, g_camids))
     valid = torch.empty(m, dtype=torch.uint8, device=dev)
     ap = torch.empty(m, dtype=torch.float64, device=dev)
@@ -140,12 +142,102 @@ def eval_func(indices, q_pids, g_pids, q_camids, g_camids, max_rank=50, respect_
     return cmc.cpu().numpy(), float(mAP.item()), topk.cpu().numpy(), single
 
 
+# --------------------------------------------------------------------------- streamed (metric-only) evaluation
+class StreamPlan:
+    """Host-side index for the streamed evaluation (csrc/stream_eval.hip): the gallery grouped by pid (CSR), every
+    query's slot in it, and the per-query number of positives (same pid, different camera) which fixes the LDS list
+    capacity `cap`.  Queries with more than 128 positives are listed in `overflow` and must take the general
+    (materialised) path.  Built once per (pids, camids) set; holds device tensors only."""
+
+    MAX_CAP = 128
+
+    def __init__(self, q_pids, g_pids, q_camids, g_camids, device):
+        qp = np.ascontiguousarray(np.asarray(q_pids), dtype=np.int64)
+        gp = np.ascontiguousarray(np.asarray(g_pids), dtype=np.int64)
+        qc = np.ascontiguousarray(np.asarray(q_camids), dtype=np.int64)
+        gc = np.ascontiguousarray(np.asarray(g_camids), dtype=np.int64)
+        self.m, self.n = len(qp), len(gp)
+        order = np.argsort(gp, kind="stable").astype(np.int32)            # by pid, gallery index ascending inside
+        upid, start = np.unique(gp[order], return_index=True)
+        csr = np.concatenate([start, [self.n]]).astype(np.int64)
+        slot = np.searchsorted(upid, qp)
+        slot_c = np.minimum(slot, max(len(upid) - 1, 0))
+        hit = (slot < len(upid)) & (upid[slot_c] == qp) if len(upid) else np.zeros(self.m, bool)
+        same_pid = np.where(hit, csr[slot_c + 1] - csr[slot_c], 0) if len(upid) else np.zeros(self.m, np.int64)
+        # same pid AND same camera (the removed entries): count through a combined key
+        cmin = int(min(gc.min(initial=0), qc.min(initial=0)))
+        span = int(max(gc.max(initial=0), qc.max(initial=0))) - cmin + 1
+        pmin = int(min(gp.min(initial=0), qp.min(initial=0)))
+        gk = (gp - pmin) * span + (gc - cmin)
+        qk = (qp - pmin) * span + (qc - cmin)
+        uk, cnt = np.unique(gk, return_counts=True)
+        ks = np.searchsorted(uk, qk)
+        ks_c = np.minimum(ks, max(len(uk) - 1, 0))
+        same_cam = np.where((ks < len(uk)) & (uk[ks_c] == qk), cnt[ks_c], 0) if len(uk) else np.zeros(self.m, np.int64)
+        self.n_pos = (same_pid - same_cam).astype(np.int64)
+        self.overflow = np.nonzero(self.n_pos > self.MAX_CAP)[0]
+        mx = int(self.n_pos[self.n_pos <= self.MAX_CAP].max(initial=1))
+        cap = 2
+        while cap < mx:
+            cap *= 2
+        self.cap = cap
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=device)
+        self.q_slot = t(np.where(hit, slot_c, -1), np.int32)
+        self.csr_off, self.g_order = t(csr, np.int64), t(order, np.int32)
+        self.q_pids, self.g_pids, self.q_cams, self.g_cams = t(qp, np.int64), t(gp, np.int64), t(qc, np.int64), t(gc, np.int64)
+
+
+def stream_eval(fq, fg, qq, gg, plan: StreamPlan):
+    """Per-query (valid u8[m], AP f64[m], first-match rank i32[m]) with no m x n matrix: positives' distances ->
+    streamed MFMA contraction with an in-register count epilogue -> histogram prefix.  valid == 2 marks a query
+    whose positive list overflowed the plan's capacity (see StreamPlan.overflow)."""
+    L.require_gpu(fq, fg, qq, gg)
+    assert fq.dtype == torch.float32 and fg.dtype == torch.float32
+    m, n, D = fq.shape[0], fg.shape[0], fq.shape[1]
+    assert (m, n) == (plan.m, plan.n)
+    dev, lib, st = fq.device, L.lib(), L.stream()
+    cap = plan.cap
+    pos_key = torch.empty((m, cap), dtype=torch.int32, device=dev)
+    pos_idx = torch.empty((m, cap), dtype=torch.int32, device=dev)
+    npos = torch.empty(m, dtype=torch.int32, device=dev)
+    hist = torch.zeros((m, cap), dtype=torch.int32, device=dev)
+    L.check(lib.creid_stream_poslist(L.ptr(fq), L.ptr(fg), L.ptr(qq), L.ptr(gg), m, n, D, L.ptr(plan.q_slot),
+                                     L.ptr(plan.csr_off), L.ptr(plan.g_order), L.ptr(plan.q_cams), L.ptr(plan.g_cams), cap,
+                                     L.ptr(pos_key), L.ptr(pos_idx), L.ptr(npos), st), "creid_stream_poslist")
+    L.check(lib.creid_stream_count(L.ptr(fq), L.ptr(fg), L.ptr(qq), L.ptr(gg), m, n, D, L.ptr(plan.q_pids),
+                                   L.ptr(plan.g_pids), cap, L.ptr(pos_key), L.ptr(pos_idx), L.ptr(npos), L.ptr(hist), st),
+            "creid_stream_count")
+    valid = torch.empty(m, dtype=torch.uint8, device=dev)
+    ap = torch.empty(m, dtype=torch.float64, device=dev)
+    first = torch.empty(m, dtype=torch.int32, device=dev)
+    L.check(lib.creid_stream_finalize(L.ptr(npos), L.ptr(hist), m, cap, L.ptr(valid), L.ptr(ap), L.ptr(first), st),
+            "creid_stream_finalize")
+    return valid, ap, first
+
+
+def eval_reduce_device(valid, ap, first, max_rank):
+    """Means over valid queries (utils/eval_reid.py:86-90) on the device: (cmc f32[max_rank], mAP f64[1],
+    topk f64[5], nvalid i64[1])."""
+    dev = valid.device
+    cmc = torch.empty(max_rank, dtype=torch.float32, device=dev)
+    mAP = torch.empty(1, dtype=torch.float64, device=dev)
+    topk = torch.empty(5, dtype=torch.float64, device=dev)
+    nvalid = torch.empty(1, dtype=torch.int64, device=dev)
+    L.check(L.lib().creid_eval_reduce(L.ptr(valid), L.ptr(ap), L.ptr(first), valid.shape[0], max_rank, L.ptr(cmc),
+                                      L.ptr(mAP), L.ptr(topk), L.ptr(nvalid), L.stream()), "creid_eval_reduce")
+    return cmc, mAP, topk, nvalid
+
+
 class R1_mAP:
     """utils/reid_metric.py:71-151.  `pl_module` only needs `.hparams` (SOLVER.DISTANCE_FUNC,
     MODEL.USE_CENTROIDS); trainer/logger lookups of the reference are optional here."""
 
     def __init__(self, pl_module=None, num_query=0, max_rank=50, feat_norm=True, dist_func="euclidean",
-                 compute_dtype=torch.float32):
+                 compute_dtype=torch.float32, streamed=False):
+        """streamed=True: metric-only evaluation that never materialises the distance / index matrices (euclidean,
+        plain camera ids, fp32); `last` then holds the per-query results only.  streamed=False keeps
+        `last["distmat"]` / `last["indices"]` (what the rank-index parity tests and get_similar read)."""
+        self.streamed = streamed
         self.num_query = num_query
         self.max_rank = max_rank
         self.feat_norm = feat_norm
@@ -165,6 +257,9 @@ class R1_mAP:
             raise L.CreidError("R1_mAP.compute needs device features (no CPU fallback)")
         feats = feats.float().contiguous()
         nq = self.num_query
+        if (self.streamed and self.dist_name == "euclidean" and not respect_camids
+                and self.compute_dtype == torch.float32):
+            return self._compute_streamed(feats, pids, camids)
         if self.dist_name == "euclidean":
             if self.feat_norm:
                 print("The test feature is normalized")
@@ -185,6 +280,35 @@ class R1_mAP:
         self.last = dict(distmat=distmat, indices=indices, single_performance=single)
         return cmc, mAP, all_topk
 
+    def _compute_streamed(self, feats, pids, camids, plan=None):
+        nq = self.num_query
+        if self.feat_norm:
+            print("The test feature is normalized")
+            f, sq = l2_normalize(feats, return_sqnorm=True)
+        else:
+            f, sq = feats, row_sqnorm(feats)
+        pids = np.asarray(pids); camids = np.asarray(camids)
+        if plan is None:
+            plan = StreamPlan(pids[:nq], pids[nq:], camids[:nq], camids[nq:], feats.device)
+        fq, fg = f[:nq], f[nq:]
+        qq, gg = sq[:nq].contiguous(), sq[nq:].contiguous()
+        valid, ap, first = stream_eval(fq, fg, qq, gg, plan)
+        if len(plan.overflow):
+            # queries with more positives than the LDS list holds: the general path on just those rows
+            rows = torch.as_tensor(plan.overflow, device=feats.device)
+            d = get_euclidean(fq.index_select(0, rows), fg, qq.index_select(0, rows), gg)
+            idx = rank_rows(d)
+            _, _, _, _, v2, a2, f2 = eval_func_device(idx, pids[:nq][plan.overflow], plan.g_pids, camids[:nq][plan.overflow],
+                                                      plan.g_cams, self.max_rank)
+            valid.index_copy_(0, rows, v2); ap.index_copy_(0, rows, a2); first.index_copy_(0, rows, f2)
+        max_rank = min(self.max_rank, fg.shape[0])
+        cmc, mAP, topk, _ = eval_reduce_device(valid, ap, first, max_rank)
+        valid_h = valid.cpu().numpy() == 1
+        vi = np.nonzero(valid_h)[0]
+        single = np.stack([vi.astype(np.float64), pids[:nq][vi].astype(np.float64), ap.cpu().numpy()[vi]], axis=1)
+        self.last = dict(valid=valid, ap=ap, first=first, single_performance=single, plan=plan)
+        return cmc.cpu().numpy(), float(mAP.item()), topk.cpu().numpy()
+
     def compute_chunked(self, feats, pids, camids, query_chunk=4096):
         """Same result as compute() for galleries whose m x n matrix should not be materialised at once
         (the reference's `_commpute_batches_double` path, utils/reid_metric.py:93-110,126-129, chunks the
@@ -193,6 +317,9 @@ class R1_mAP:
         if not isinstance(feats, torch.Tensor) or not feats.is_cuda:
             raise L.CreidError("R1_mAP.compute_chunked needs device features (no CPU fallback)")
         from .parallel import merge_eval_results
+        if self.dist_name != "euclidean":
+            raise L.CreidError("compute_chunked streams the squared-L2 kernel only; use compute() for "
+                               f"SOLVER.DISTANCE_FUNC={self.dist_name!r}")
         feats = feats.float().contiguous()
         nq = self.num_query
         if self.feat_norm:

@@ -13,19 +13,25 @@ import torch
 from . import _lib as L
 
 
+def flat_offsets(params):
+    """Start offset of every tensor in the flat buffer (each starts 16-byte aligned) and the padded total."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    return offs, off
+
+
 def flatten_(params, device):
     """Re-home `params` (list of nn.Parameter) as views of one flat fp32 buffer; returns (flat, gflat)."""
-    n_pad = sum((p.numel() + 3) // 4 * 4 for p in params)     # every tensor starts 16-byte aligned
+    offs, n_pad = flat_offsets(params)
     flat = torch.zeros(n_pad, dtype=torch.float32, device=device)
     gflat = torch.zeros(n_pad, dtype=torch.float32, device=device)
-    off = 0
-    for p in params:
+    for p, off in zip(params, offs):
         k = p.numel()
-        off_al = off
-        flat[off_al:off_al + k].copy_(p.data.reshape(-1))
-        p.data = flat[off_al:off_al + k].view(p.shape)
-        p.grad = gflat[off_al:off_al + k].view(p.shape)
-        off += (k + 3) // 4 * 4
+        flat[off:off + k].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + k].view(p.shape)
+        p.grad = gflat[off:off + k].view(p.shape)
     return flat, gflat
 
 
@@ -43,12 +49,36 @@ class FusedAdam(torch.optim.Optimizer):
         # device-resident {lr, step, bc1, bc2s}: keeps a captured hipGraph of the step valid
         self.hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
         self._lr_on_device = None
-        off = 0
-        for p in params:   # torch-compatible per-parameter state (views) for checkpoints
+        self._params = params
+        self._offsets, _ = flat_offsets(params)
+        self._bind_state_views()
+
+    def _bind_state_views(self):
+        """torch-compatible per-parameter state for checkpoints: VIEWS of the flat moment buffers, at the same
+        (16-byte aligned) offsets as the parameters themselves."""
+        for p, off in zip(self._params, self._offsets):
             k = p.numel()
             self.state[p] = dict(step=torch.tensor(0.0), exp_avg=self.exp_avg[off:off + k].view(p.shape),
                                  exp_avg_sq=self.exp_avg_sq[off:off + k].view(p.shape))
-            off += k
+
+    def load_state_dict(self, state_dict):
+        """Restore the moments INTO the flat buffers the kernel reads and the step count into the device-resident
+        hyper vector (torch's default only swaps self.state[p] for detached copies, which the kernel never sees).
+        Accepts this class's own state_dict and a torch.optim.Adam one (same per-parameter keys)."""
+        super().load_state_dict(state_dict)
+        step = 0.0
+        with torch.no_grad():
+            for p, off in zip(self._params, self._offsets):
+                st = self.state.get(p)
+                if not st:
+                    continue
+                k = p.numel()
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                step = max(step, float(st["step"]))
+            self.hyper[1:2].copy_(torch.tensor([step], dtype=torch.float32))     # bc1 / bc2 are recomputed per step
+        self._bind_state_views()
+        self._lr_on_device = None
 
     def zero_grad(self, set_to_none: bool = False):
         self.gflat.zero_()

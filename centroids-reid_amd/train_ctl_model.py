@@ -42,9 +42,16 @@ class CTLModel(ModelBase):
         self.apply_optimizers()
         return out
 
+    def _raw_optimizers(self):
+        """(Adam, center SGD) as the objects whose step() actually runs: under pytorch-lightning
+        `self.optimizers()` returns LightningOptimizer wrappers, and attributes set on a wrapper (grad_mul,
+        grad_scale) would never reach the wrapped optimizer."""
+        opt, opt_center = self.optimizers(use_pl_optimizer=True)
+        return getattr(opt, "_optimizer", opt), getattr(opt_center, "_optimizer", opt_center)
+
     def apply_optimizers(self):
         hp = self.hparams
-        opt, opt_center = self.optimizers(use_pl_optimizer=True)
+        opt, opt_center = self._raw_optimizers()
         opt.step()                                                             # :155
         eng = getattr(self.backbone, "_engine", None)
         if eng is not None:
@@ -54,12 +61,15 @@ class CTLModel(ModelBase):
 
     def forward_backward(self, batch, batch_idx=0):
         hp = self.hparams
-        opt, opt_center = self.optimizers(use_pl_optimizer=True)
+        opt, opt_center = self._raw_optimizers()
         if hp.SOLVER.USE_WARMUP_LR:                                           # :41-49
             if self.trainer.current_epoch < hp.SOLVER.WARMUP_EPOCHS:
                 lr_scale = min(1.0, float(self.trainer.current_epoch + 1) / float(hp.SOLVER.WARMUP_EPOCHS))
                 for pg in opt.param_groups:
                     pg["lr"] = lr_scale * hp.SOLVER.BASE_LR
+        if not (self.backbone.training and self.bn.training):
+            raise RuntimeError("training_step with backbone / BNNeck in eval mode (validation_step leaves them there, "
+                               "modelling/bases.py:170-171): call model.train() first, as the PL trainer does")
         opt_center.zero_grad()
         opt.zero_grad()
 
@@ -81,7 +91,8 @@ class CTLModel(ModelBase):
         class_labels = class_labels.to(dev, non_blocking=True)
 
         if (self.fused_heads and all_real and P >= 2 and K >= 2 and x.is_cuda and hasattr(self.backbone, "engine")
-                and self.backbone.training and self.contrastive_loss.margin is not None):
+                and self.backbone.training and self.contrastive_loss.margin is not None
+                and self.contrastive_loss.dist_name == "euclidean"):
             return self._forward_backward_fused(x, class_labels, P, K)
 
         _, features = self.backbone(x)                                        # :59
@@ -123,7 +134,10 @@ class CTLModel(ModelBase):
                 cur_cent = centroids_emb[i].index_select(0, sel)
             emb = torch.cat((query_feat, cur_cent))
             lab = torch.cat((cur_labels, cur_labels))
-            loss_i, dap, dan, stats = ops.TripletHardMine.apply(emb, lab, None, self.contrastive_loss.margin)
+            cos = self.contrastive_loss.dist_name == "cosine"            # SOLVER.DISTANCE_FUNC (:129-137 of the loss)
+            if cos:
+                emb = ops.RowNormalize.apply(emb, 0, 1e-12)
+            loss_i, dap, dan, stats = ops.TripletHardMine.apply(emb, lab, None, self.contrastive_loss.margin, cos)
             losses.append(loss_i); aps.append(stats[1]); ans.append(stats[2])
             norms.append(torch.linalg.vector_norm(cur_cent.detach(), dim=1).mean())
         contrastive_loss_step = torch.mean(torch.stack(losses)) * hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT

@@ -88,6 +88,30 @@ int creid_eval_reduce(const uint8_t* valid, const double* ap, const int32_t* fir
                       int64_t* out_nvalid, void* stream);
 
 
+/* ---- metric-only evaluation with NO m x n matrix (csrc/stream_eval.hip): what utils/reid_metric.py:93-151 +
+ * utils/eval_reid.py:25-92 compute, for plain camera ids and the squared-L2 distance.  Three launches:
+ *  poslist : per query, distances to its positives (gallery rows of the same pid, other camera) in the arithmetic
+ *            of creid_sqdist_matrix, sorted by (distance, gallery index).  The gallery is given grouped by pid:
+ *            g_order int32 [n] (gallery indices sorted by pid, ascending index inside a pid), csr_off int64
+ *            [n_pid + 1], q_slot int32 [m] (the query pid's group, -1 if absent).  cap = list capacity per query
+ *            (power of two, 2..128); pos_key uint32 [m][cap] (order-preserving image of the fp32 distance, padded
+ *            with 0xffffffff), pos_idx int32 [m][cap], npos int32 [m] (-1: more than cap positives -- such queries
+ *            must take creid_sqdist_matrix + creid_rank_rows + creid_cmc_ap_ranked instead).
+ *  count   : the full contraction, tile by tile on the f32 MFMA pipe; every negative (other pid) bumps
+ *            hist[q][#positives ranked before it] -- hist uint32 [m][cap] must be ZERO on entry.
+ *  finalize: valid uint8 [m] (0: no positive, 1: ok, 2: overflow), ap float64 [m], first int32 [m] with the
+ *            meaning of creid_cmc_ap_ranked; feed creid_eval_reduce. */
+int creid_stream_poslist(const float* q, const float* g, const float* qq, const float* gg, int64_t m, int64_t n,
+                         int64_t D, const int32_t* q_slot, const int64_t* csr_off, const int32_t* g_order,
+                         const int64_t* q_cams, const int64_t* g_cams, int32_t cap, uint32_t* pos_key,
+                         int32_t* pos_idx, int32_t* npos, void* stream);
+int creid_stream_count(const float* q, const float* g, const float* qq, const float* gg, int64_t m, int64_t n,
+                       int64_t D, const int64_t* q_pids, const int64_t* g_pids, int32_t cap,
+                       const uint32_t* pos_key, const int32_t* pos_idx, const int32_t* npos, uint32_t* hist,
+                       void* stream);
+int creid_stream_finalize(const int32_t* npos, const uint32_t* hist, int64_t m, int32_t cap, uint8_t* valid,
+                          double* ap, int32_t* first, void* stream);
+
 /* ------------------------------------------------------------------ stage B: centroids */
 
 /* train_ctl_model.py:79-104: leave-one-out per-PID centroids of a PID-contiguous [P,K] batch.
@@ -126,6 +150,36 @@ int creid_triplet_bwd_batched(const float* x, int64_t nb, int64_t N, int64_t D, 
                               const float* dist_an, const int32_t* p_idx, const int32_t* n_idx,
                               const float* coef, const float* gscale_dev, float gscale, float* dx_accum,
                               void* stream);
+
+/* SOLVER.DISTANCE_FUNC = 'cosine' (losses/triplet_loss.py:44-65,134-137): the same mining / loss / backward on
+ * the cosine distance clamp(|1 - x_i.x_j|, 1e-12) of rows already scaled to unit length (x_unit =
+ * creid_rownorm_fwd(mode 0) of the features).  Argument meaning as creid_triplet_fwd / _bwd; the backward is
+ * with respect to x_unit (chain creid_rownorm_bwd for the raw features). */
+int creid_triplet_cosine_fwd(const float* x_unit, const int64_t* labels, const uint8_t* anchor_mask, int64_t N,
+                             int64_t D, float margin, float* dist_ap, float* dist_an, int32_t* p_idx,
+                             int32_t* n_idx, float* coef, float* out4, float* dist_mat, void* stream);
+int creid_triplet_cosine_bwd(const float* x_unit, int64_t N, int64_t D, const float* dist_ap,
+                             const float* dist_an, const int32_t* p_idx, const int32_t* n_idx,
+                             const float* coef, const float* gscale_dev, float gscale, float* dx_accum,
+                             void* stream);
+
+/* Row scaling to unit length: mode 0  y = x / max(|x|_2, eps)  (cosine_similarity, losses/triplet_loss.py:50-52);
+ * mode 1  y = x / (|x|_2 + eps)  (`normalize`, losses/triplet_loss.py:16-24, used by normalize_feature=True).
+ * norm[N] receives |x|_2 (saved for the backward).  bwd: dx = d(y)/d(x)^T dy (overwrites dx). */
+int creid_rownorm_fwd(const float* x, int64_t N, int64_t D, int mode, float eps, float* y, float* norm,
+                      void* stream);
+int creid_rownorm_bwd(const float* x, const float* norm, const float* dy, int64_t N, int64_t D, int mode,
+                      float eps, float* dx, void* stream);
+
+/* hard_example_mining(dist_mat, labels, return_inds=True) of losses/triplet_loss.py:68-119 on a GIVEN
+ * square distance matrix fp32 [N,N]: hardest positive (max, self included) / hardest negative (min) per
+ * anchor row, first index wins ties. */
+int creid_hard_mine_from_dist(const float* dist_mat, const int64_t* labels, int64_t N, float* dist_ap,
+                              float* dist_an, int32_t* p_idx, int32_t* n_idx, void* stream);
+
+/* d[i] = sqrt(max(d[i], lo)) in place: the `clamp(min=1e-12).sqrt()` tail of euclidean_dist(x, y)
+ * (losses/triplet_loss.py:40) after creid_sqdist_matrix. */
+int creid_clamp_sqrt_inplace(float* d, int64_t n, float lo, void* stream);
 
 /* losses/center_loss.py:26-46.  row_sq[b] = |x_b|^2 + |c_y|^2 - 2 x_b.c_y (unclamped, saved for bwd);
  * loss[0] = (sum_b clamp(row_sq[b],1e-12,1e12) + B*(C-1)*1e-12) / B. */

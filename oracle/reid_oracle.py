@@ -259,10 +259,26 @@ def hard_example_mining(dist: torch.Tensor, labels: torch.Tensor):
     return d_ap, d_an, p_idx, n_idx
 
 
-def triplet_loss(feat: torch.Tensor, labels: torch.Tensor, margin=0.5, mask=None):
-    """losses/triplet_loss.py:139-173 TripletLoss.__call__ (euclidean).  `mask` filters
-    anchors AFTER mining (:148-151).  margin None -> SoftMarginLoss(an - ap, 1)."""
-    d = euclidean_dist(feat, feat)
+def normalize_rows(x: torch.Tensor) -> torch.Tensor:
+    """losses/triplet_loss.py:16-24 `normalize`: x / (|x|_2 + 1e-12) (NOT F.normalize: the epsilon is added)."""
+    return x / (torch.sqrt((x * x).sum(dim=-1, keepdim=True)) + 1e-12)
+
+
+def cosine_dist(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """losses/triplet_loss.py:44-65: rows / max(|row|, eps), similarity matrix, |1 - sim| clamped at eps."""
+    xn = x / torch.clamp(torch.sqrt((x * x).sum(1, keepdim=True)), min=eps)
+    yn = y / torch.clamp(torch.sqrt((y * y).sum(1, keepdim=True)), min=eps)
+    return torch.abs(1 - xn @ yn.t()).clamp(min=eps)
+
+
+def triplet_loss(feat: torch.Tensor, labels: torch.Tensor, margin=0.5, mask=None, dist="euclidean",
+                 normalize_feature=False):
+    """losses/triplet_loss.py:139-173 TripletLoss.__call__.  `mask` filters anchors AFTER mining (:148-151).
+    margin None -> SoftMarginLoss(an - ap, 1).  dist = SOLVER.DISTANCE_FUNC (:134-137); normalize_feature
+    (:141-142) rescales the rows first."""
+    if normalize_feature:
+        feat = normalize_rows(feat)
+    d = cosine_dist(feat, feat) if dist == "cosine" else euclidean_dist(feat, feat)
     d_ap, d_an, _, _ = hard_example_mining(d, labels)
     if mask is not None:
         d_ap, d_an = d_ap[mask], d_an[mask]

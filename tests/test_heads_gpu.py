@@ -134,3 +134,51 @@ def test_optimizer_steps_vs_oracle(mods):
     cg, gcg = c.cuda(), gc.cuda()
     L.check(L.lib().creid_sgd_scaled_step(L.ptr(cg), L.ptr(gcg), 5000, 0.5, 1.0 / 5e-4, L.stream()), "sgd")
     np.testing.assert_allclose(cg.cpu().numpy(), ro.center_sgd_step(c, gc).numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_triplet_cosine_and_normalize_golden(golden, mods):
+    """SOLVER.DISTANCE_FUNC='cosine' and normalize_feature=True (losses/triplet_loss.py:44-65,134-143) through the
+    HIP kernels vs vectors recorded from the reference."""
+    losses, ops = mods
+    g = golden("surface_r2")
+    x = torch.from_numpy(g["x"]).cuda(); labels = torch.from_numpy(g["labels"]).cuda()
+    for tag, margin, dist, norm, m in (("cos_m05", 0.5, "cosine", False, None), ("cos_soft", None, "cosine", False, None),
+                                       ("cos_m05_mask", 0.5, "cosine", False, g["mask"]),
+                                       ("euc_norm", 0.5, "euclidean", True, None), ("cos_norm", 0.3, "cosine", True, None)):
+        xt = x.clone().requires_grad_(True)
+        mask = None if m is None else torch.from_numpy(m).cuda()
+        loss, ap, an = losses.TripletLoss(margin, dist)(xt, labels, normalize_feature=norm, mask=mask)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"trip_{tag}_loss"])) < 2e-6, tag
+        np.testing.assert_allclose(ap.cpu().numpy(), g[f"trip_{tag}_ap"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(an.cpu().numpy(), g[f"trip_{tag}_an"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), g[f"trip_{tag}_grad"], rtol=2e-4, atol=2e-7)
+
+
+def test_general_distances_and_mining_golden(golden, mods):
+    """euclidean_dist(x, y) / cosine_dist(x, y) for two different row sets (values + both gradients) and
+    hard_example_mining(dist_mat, labels, return_inds=True) on a given matrix (losses/triplet_loss.py:27-119)."""
+    losses, ops = mods
+    g = golden("surface_r2")
+    w = torch.from_numpy(g["w"]).cuda()
+    for name, fn in (("euc", losses.euclidean_dist), ("cos", losses.cosine_dist)):
+        xt = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+        yt = torch.from_numpy(g["y"]).cuda().requires_grad_(True)
+        d = fn(xt, yt)
+        (d * w).sum().backward()
+        np.testing.assert_allclose(d.detach().cpu().numpy(), g[f"xy_{name}_dist"], rtol=1e-5, atol=2e-5 if name == "euc" else 2e-6)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), g[f"xy_{name}_gx"], rtol=2e-4, atol=2e-5 if name == "euc" else 2e-6)
+        np.testing.assert_allclose(yt.grad.cpu().numpy(), g[f"xy_{name}_gy"], rtol=2e-4, atol=2e-5 if name == "euc" else 2e-6)
+    labels = torch.from_numpy(g["labels"]).cuda()
+    dm = torch.from_numpy(g["mine_dist"]).cuda().requires_grad_(True)
+    ap, an, pi, ni = losses.hard_example_mining(dm, labels, return_inds=True)
+    np.testing.assert_array_equal(pi.cpu().numpy(), g["mine_pi"]); np.testing.assert_array_equal(ni.cpu().numpy(), g["mine_ni"])
+    np.testing.assert_array_equal(ap.detach().cpu().numpy(), g["mine_ap"])
+    np.testing.assert_array_equal(an.detach().cpu().numpy(), g["mine_an"])
+    (ap.sum() - 2 * an.sum()).backward()
+    ref = np.zeros_like(g["mine_dist"])
+    ref[np.arange(len(ref)), g["mine_pi"]] += 1.0
+    ref[np.arange(len(ref)), g["mine_ni"]] -= 2.0
+    np.testing.assert_array_equal(dm.grad.cpu().numpy(), ref)
+    ap2, an2 = losses.hard_example_mining(dm.detach(), labels)
+    assert torch.equal(ap2, ap.detach()) and torch.equal(an2, an.detach())

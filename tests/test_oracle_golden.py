@@ -189,3 +189,50 @@ def test_inference_golden_vs_oracle(golden):
         members = np.nonzero(np.asarray(keys) == k)[0]
         np.testing.assert_array_equal(members, g["index_flat"][off[i]:off[i + 1]])
         np.testing.assert_allclose(f[nq:].numpy()[members].sum(0) / len(members), g["centroids"][i], rtol=0, atol=1e-6)
+
+
+# ---- round 2: boundary surface (cosine / normalize_feature / general distances / ragged masks)
+def _mask_sets(g):
+    for i in range(int(g["n_mask_sets"])):
+        lens = g[f"mask{i}_lists_len"]
+        flat = g[f"mask{i}_lists_flat"]
+        lists, o = [], 0
+        for n in lens:
+            lists.append(flat[o:o + n].tolist()); o += n
+        yield g[f"mask{i}_labels"], g[f"mask{i}_masks"], lists
+
+
+def test_create_masks_ragged_oracle_and_product(golden):
+    """create_masks_train is host logic: the oracle AND the product's own rewrite are checked against the
+    reference's output on ragged / interleaved label vectors (incl. the cumsum[-1] quirk for a short first PID)."""
+    from centroids_reid_amd.bases import ModelBase
+    g = golden("surface_r2")
+    for labels, masks, lists in _mask_sets(g):
+        mo, lo = ro.create_masks_train(labels)
+        np.testing.assert_array_equal(mo, masks)
+        assert [list(map(int, v)) for v in lo] == lists
+        mp, lp = ModelBase.create_masks_train(torch.from_numpy(labels))
+        assert mp.dtype == torch.bool
+        np.testing.assert_array_equal(mp.numpy(), masks)
+        assert lp == lists
+
+
+def test_triplet_cosine_normalize_oracle(golden):
+    g = golden("surface_r2")
+    x = torch.from_numpy(g["x"]); labels = torch.from_numpy(g["labels"])
+    for tag, margin, dist, norm, m in (("cos_m05", 0.5, "cosine", False, None), ("cos_soft", None, "cosine", False, None),
+                                       ("cos_m05_mask", 0.5, "cosine", False, g["mask"]),
+                                       ("euc_norm", 0.5, "euclidean", True, None), ("cos_norm", 0.3, "cosine", True, None)):
+        xt = x.clone().requires_grad_(True)
+        loss, ap, an = ro.triplet_loss(xt, labels, margin, None if m is None else torch.from_numpy(m), dist, norm)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"trip_{tag}_loss"])) < 1e-6
+        np.testing.assert_allclose(ap.detach().numpy(), g[f"trip_{tag}_ap"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(an.detach().numpy(), g[f"trip_{tag}_an"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(xt.grad.numpy(), g[f"trip_{tag}_grad"], rtol=1e-4, atol=1e-7)
+    y = torch.from_numpy(g["y"])
+    np.testing.assert_allclose(ro.euclidean_dist(x, y).numpy(), g["xy_euc_dist"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ro.cosine_dist(x, y).numpy(), g["xy_cos_dist"], rtol=1e-5, atol=1e-6)
+    ap, an, pi, ni = ro.hard_example_mining(torch.from_numpy(g["mine_dist"]), labels)
+    np.testing.assert_array_equal(pi.numpy(), g["mine_pi"]); np.testing.assert_array_equal(ni.numpy(), g["mine_ni"])
+    np.testing.assert_array_equal(ap.numpy(), g["mine_ap"]); np.testing.assert_array_equal(an.numpy(), g["mine_an"])

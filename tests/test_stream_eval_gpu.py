@@ -1,0 +1,139 @@
+"""GPU parity: metric-only evaluation that never writes the m x n matrix (csrc/stream_eval.hip) against the
+materialised path (creid_sqdist_matrix + creid_rank_rows + creid_cmc_ap_ranked), the reference goldens and the CPU
+oracle -- including the per-rank shard of BASELINE configs[3] (6250 queries x 200 000 gallery x 2048)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(feats, pids, cams, nq, feat_norm=True):
+    from centroids_reid_amd import reid_metric as rm
+    f = feats.cuda()
+    a = rm.R1_mAP(num_query=nq, feat_norm=feat_norm)
+    ra = a.compute(f, pids, cams)
+    b = rm.R1_mAP(num_query=nq, feat_norm=feat_norm, streamed=True)
+    rb = b.compute(f, pids, cams)
+    return a, ra, b, rb
+
+
+def _per_query_from_indices(metric, pids, cams, nq):
+    from centroids_reid_amd import reid_metric as rm
+    _, _, _, _, valid, ap, first = rm.eval_func_device(metric.last["indices"], pids[:nq], pids[nq:], cams[:nq], cams[nq:], 50)
+    return valid.cpu().numpy(), ap.cpu().numpy(), first.cpu().numpy()
+
+
+def _assert_same(a, ra, b, rb, pids, cams, nq):
+    v0, ap0, f0 = _per_query_from_indices(a, pids, cams, nq)
+    v1, ap1, f1 = b.last["valid"].cpu().numpy(), b.last["ap"].cpu().numpy(), b.last["first"].cpu().numpy()
+    np.testing.assert_array_equal(v1, v0)                       # bit-exact: same ranks on the same distance bits
+    np.testing.assert_array_equal(f1, f0)
+    np.testing.assert_allclose(ap1, ap0, rtol=0, atol=1e-12)    # float64 sums in a different order
+    np.testing.assert_array_equal(rb[0], ra[0])                 # CMC curve
+    assert abs(rb[1] - ra[1]) < 1e-12
+    np.testing.assert_array_equal(rb[2], ra[2])
+    np.testing.assert_allclose(b.last["single_performance"], a.last["single_performance"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["eval_small", "eval_d2048", "eval_tiny_gallery"])
+def test_streamed_matches_reference_goldens(golden, name):
+    g = golden(name)
+    nq = int(g["num_query"])
+    feats = torch.from_numpy(g["feats"])
+    a, ra, b, rb = _both(feats, g["pids"], g["camids"], nq)
+    np.testing.assert_array_equal(a.last["indices"].cpu().numpy(), g["indices"])     # the materialised path is pinned
+    _assert_same(a, ra, b, rb, g["pids"], g["camids"], nq)
+    np.testing.assert_allclose(rb[0], g["cmc"], rtol=0, atol=1e-7)
+    assert abs(rb[1] - float(g["mAP"])) < 1e-9
+    np.testing.assert_allclose(rb[2], g["topk"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("nq,ng,D,npid,ncam,dup", [(300, 3000, 256, 60, 3, True), (70, 513, 100, 9, 2, False),
+                                                    (129, 1000, 2048, 400, 5, True), (5, 40, 32, 3, 2, False)])
+def test_streamed_equals_materialised_random(nq, ng, D, npid, ncam, dup):
+    """N(0,1) features (dense near-ties in fp32), duplicated gallery rows (exact ties -> order by gallery index),
+    queries whose pid is absent from the gallery or whose positives all share their camera."""
+    rng = np.random.default_rng(nq * 7 + ng)
+    f = rng.standard_normal((nq + ng, D)).astype(np.float32)
+    pids = rng.integers(0, npid, nq + ng)
+    cams = rng.integers(0, ncam, nq + ng)
+    if dup:
+        src = rng.integers(nq, nq + ng, ng // 4); dst = rng.integers(nq, nq + ng, ng // 4)
+        f[dst] = f[src]                                         # exact ties, possibly between a positive and a negative
+        f[nq + 7] = f[3]; pids[nq + 7] = pids[3]; cams[nq + 7] = cams[3] + 1      # a zero-distance positive
+    pids[0] = npid + 5                                          # pid absent from the gallery
+    same = (pids[nq:] == pids[1])
+    cams[nq:][same] = cams[1]                                   # every same-pid entry removed -> invalid query
+    for norm in (True, False):
+        a, ra, b, rb = _both(torch.from_numpy(f), pids, cams, nq, feat_norm=norm)
+        _assert_same(a, ra, b, rb, pids, cams, nq)
+        assert b.last["valid"][0].item() == 0 and b.last["valid"][1].item() == 0
+
+
+def test_streamed_overflow_rows_take_general_path():
+    """A pid with more than 128 positives does not fit the LDS list: those queries are routed through the
+    materialised kernels and merged; the rest stay streamed."""
+    from centroids_reid_amd import reid_metric as rm
+    rng = np.random.default_rng(5)
+    nq, ng, D = 40, 2000, 64
+    f = rng.standard_normal((nq + ng, D)).astype(np.float32)
+    pids = rng.integers(2, 30, nq + ng)
+    pids[nq:nq + 400] = 0; pids[:6] = 0                         # 400 gallery entries of pid 0
+    pids[nq + 400:nq + 500] = 1; pids[6:9] = 1                  # 100 of pid 1 (fits: cap 128)
+    cams = rng.integers(0, 4, nq + ng)
+    a, ra, b, rb = _both(torch.from_numpy(f), pids, cams, nq)
+    plan = b.last["plan"]
+    assert set(plan.overflow.tolist()) == set(range(6)) and plan.cap == 128
+    _assert_same(a, ra, b, rb, pids, cams, nq)
+
+
+def test_streamed_duke_shape_equals_materialised():
+    """BASELINE configs[4] shape (2228 x 17661 x 2048, the bench generator): whole-job equality of the two paths."""
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    nq, ng, D = 2228, 17661, 2048
+    feats = torch.randn((nq + ng, D), generator=gen, device="cuda", dtype=torch.float32)
+    rng = np.random.default_rng(0)
+    pids = rng.integers(0, 702, nq + ng); cams = rng.integers(0, 8, nq + ng)
+    a, ra, b, rb = _both(feats, pids, cams, nq)
+    _assert_same(a, ra, b, rb, pids, cams, nq)
+    assert 0 < rb[1] < 1
+
+
+def test_streamed_configs3_shard_6250x200000():
+    """The per-rank shard of BASELINE configs[3]: 6250 queries x 200 000 gallery x 2048 fp32, streamed (the 5 GB
+    distance matrix and the 10 GB index matrix are never written).  Full-size properties + equality with the
+    materialised kernels AND the CPU oracle's CMC/AP on a 256-query slice."""
+    from centroids_reid_amd import reid_metric as rm
+    from oracle import reid_oracle as ro
+    nq, ng, D, npid = 6250, 200_000, 2048, 50_000
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    feats = torch.randn((nq + ng, D), generator=gen, device="cuda", dtype=torch.float32)
+    rng = np.random.default_rng(4)
+    pids = np.concatenate([rng.integers(0, npid, nq), np.arange(ng) % npid])       # every query has 4 gallery matches
+    cams = np.concatenate([np.zeros(nq, np.int64), np.ones(ng, np.int64)])          # datasets/bases.py:226-229
+    cams[nq:nq + 5000] = 0                                                           # some same-camera entries to remove
+    m = rm.R1_mAP(num_query=nq, streamed=True)
+    cmc, mAP, topk = m.compute(feats, pids, cams)
+    valid, ap, first = m.last["valid"].cpu().numpy(), m.last["ap"].cpu().numpy(), m.last["first"].cpu().numpy()
+    plan = m.last["plan"]
+    assert plan.cap == 4 and len(plan.overflow) == 0
+    np.testing.assert_array_equal(valid == 1, plan.n_pos > 0)
+    assert (first[valid == 1] >= 0).all() and (first[valid == 1] < ng).all()
+    assert ((ap[valid == 1] > 0) & (ap[valid == 1] <= 1)).all()
+    assert np.all(np.diff(cmc) >= 0) and 0 < mAP < 1
+    assert abs(mAP - ap[valid == 1].mean()) < 1e-12
+    # 256-query slice through the materialised kernels and through the oracle's eval on the device's own distances
+    sl = np.arange(1000, 1256)
+    fn, sq = rm.l2_normalize(feats, return_sqnorm=True)
+    d = rm.get_euclidean(fn[:nq][sl[0]:sl[-1] + 1], fn[nq:], sq[:nq][sl[0]:sl[-1] + 1].contiguous(), sq[nq:].contiguous())
+    idx = rm.rank_rows(d)
+    _, _, _, _, v2, a2, f2 = rm.eval_func_device(idx, pids[:nq][sl], pids[nq:], cams[:nq][sl], cams[nq:], 50)
+    np.testing.assert_array_equal(valid[sl], v2.cpu().numpy())
+    np.testing.assert_array_equal(first[sl], f2.cpu().numpy())
+    np.testing.assert_allclose(ap[sl], a2.cpu().numpy(), rtol=0, atol=1e-12)
+    o_idx = ro.rank_rows(d.cpu())
+    _, _, _, per_q = ro.eval_market(o_idx, pids[:nq][sl], pids[nq:], cams[:nq][sl], cams[nq:])
+    np.testing.assert_array_equal(valid[sl] == 1, per_q["valid"])
+    np.testing.assert_array_equal(first[sl], per_q["first"])
+    np.testing.assert_allclose(ap[sl], per_q["ap"], rtol=0, atol=1e-12)

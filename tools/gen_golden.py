@@ -300,7 +300,7 @@ def gen_backbone(ref, name, arch, B, H, W):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.load()
-    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
+    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
     if "eval" in which:
         gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
         gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
@@ -447,3 +447,64 @@ def gen_inference():
 
 if __name__ == "__main__" and "inference" in sys.argv[1:]:
     gen_inference()
+
+
+def gen_surface_r2():
+    """Round-2 boundary surface: create_masks_train on ragged / non-contiguous label vectors, TripletLoss with
+    dist_func='cosine' and normalize_feature=True, euclidean_dist / cosine_dist between two DIFFERENT row sets,
+    hard_example_mining on a given matrix -- all recorded from the reference's own functions."""
+    ref = ref_import.load()
+    tl = ref.triplet_loss
+    rng = np.random.default_rng(2024)
+    rec = {}
+    label_sets = [np.array([3, 3, 3, 3, 9, 9, 9, 9, 1, 1, 1, 1]),            # regular P x K
+                  np.array([5, 5, 5, 7, 7, 2, 2, 2, 2, 8]),                  # ragged, contiguous
+                  np.array([4, 1, 4, 2, 1, 4, 2, 2, 2, 9]),                  # ragged, interleaved
+                  np.array([6, 6, 0, 0, 0, 0, 3]),                           # first PID short (cumsum[-1] quirk)
+                  np.array([11])]
+    for i, lab in enumerate(label_sets):
+        m, lists = ref.bases.ModelBase.create_masks_train(torch.from_numpy(lab))
+        rec[f"mask{i}_labels"] = lab.astype(np.int64)
+        rec[f"mask{i}_masks"] = m.numpy()
+        rec[f"mask{i}_lists_flat"] = np.concatenate([np.asarray(v, np.int64) for v in lists])
+        rec[f"mask{i}_lists_len"] = np.asarray([len(v) for v in lists], np.int64)
+    rec["n_mask_sets"] = np.int64(len(label_sets))
+    N, D, K = 32, 256, 4
+    x = rng.standard_normal((N, D)).astype(np.float32) * 1.7
+    labels = np.repeat(np.arange(N // K) * 3, K).astype(np.int64)
+    mask = np.ones(N, bool); mask[[2, 9, 30]] = False
+    rec.update(x=x, labels=labels, mask=mask)
+    for tag, margin, dist, norm, m in (("cos_m05", 0.5, "cosine", False, None), ("cos_soft", None, "cosine", False, None),
+                                       ("cos_m05_mask", 0.5, "cosine", False, mask), ("euc_norm", 0.5, "euclidean", True, None),
+                                       ("cos_norm", 0.3, "cosine", True, None)):
+        xt = torch.from_numpy(x).requires_grad_(True)
+        loss, ap, an = tl.TripletLoss(margin, dist)(xt, torch.from_numpy(labels), normalize_feature=norm,
+                                                    mask=None if m is None else torch.from_numpy(m))
+        loss.backward()
+        rec[f"trip_{tag}_loss"] = np.float32(loss.item())
+        rec[f"trip_{tag}_ap"] = ap.detach().numpy(); rec[f"trip_{tag}_an"] = an.detach().numpy()
+        rec[f"trip_{tag}_grad"] = xt.grad.numpy().copy()
+    y = rng.standard_normal((20, D)).astype(np.float32)
+    w = rng.standard_normal((N, 20)).astype(np.float32)
+    for name, fn in (("euc", tl.euclidean_dist), ("cos", tl.cosine_dist)):
+        xt = torch.from_numpy(x).requires_grad_(True); yt = torch.from_numpy(y).requires_grad_(True)
+        d = fn(xt, yt)
+        (d * torch.from_numpy(w)).sum().backward()
+        rec[f"xy_{name}_dist"] = d.detach().numpy(); rec[f"xy_{name}_gx"] = xt.grad.numpy().copy()
+        rec[f"xy_{name}_gy"] = yt.grad.numpy().copy()
+    rec.update(y=y, w=w)
+    dm = np.abs(rng.standard_normal((N, N))).astype(np.float32)
+    ap, an, pi, ni = tl.hard_example_mining(torch.from_numpy(dm), torch.from_numpy(labels), return_inds=True)
+    rec.update(mine_dist=dm, mine_ap=ap.numpy(), mine_an=an.numpy(), mine_pi=pi.numpy(), mine_ni=ni.numpy())
+    np.savez_compressed(os.path.join(OUT, "surface_r2"), **rec)
+    print(f"[surface_r2] cos_m05={rec['trip_cos_m05_loss']:.6f} cos_soft={rec['trip_cos_soft_loss']:.6f} "
+          f"euc_norm={rec['trip_euc_norm_loss']:.6f} cos_norm={rec['trip_cos_norm_loss']:.6f}")
+
+
+if __name__ == "__main__" and "surface_r2" in sys.argv[1:]:
+    gen_surface_r2()
+
+
+if __name__ == "__main__" and "ibn320" in sys.argv[1:]:
+    # BASELINE configs[3] input size: ResNet50-IBN-a at 320 x 320 (20 x 20 final maps), batch 2
+    gen_backbone(ref_import.load(), "backbone_r50ibn_2x320x320", "resnet50_ibn_a", 2, 320, 320)
