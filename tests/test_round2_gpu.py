@@ -51,7 +51,10 @@ def test_fused_adam_matches_torch_and_restores_state():
         np.testing.assert_allclose(sd["state"][i]["exp_avg"].cpu().numpy(), ot.state[pt[i]]["exp_avg"].cpu().numpy(),
                                    rtol=2e-6, atol=1e-8)
     # resume: fresh optimiser on the same parameter values, from FusedAdam's own state and from torch's
-    for src in (sd, ot.state_dict()):
+    # (deep copies: torch's load_state_dict may alias the tensors of the dict it is given)
+    import copy
+    sd_t = copy.deepcopy(ot.state_dict())
+    for src in (copy.deepcopy(sd), copy.deepcopy(sd_t)):
         pr = [torch.nn.Parameter(p.detach().clone()) for p in pf]
         orr = FusedAdam([{"params": pr}], lr=3e-3, weight_decay=5e-4)
         orr.load_state_dict(src)
@@ -59,7 +62,7 @@ def test_fused_adam_matches_torch_and_restores_state():
         run(pr, orr, grads[3:])
         pt2 = [torch.nn.Parameter(p.detach().clone()) for p in pt]
         ot2 = torch.optim.Adam([{"params": pt2}], lr=3e-3, weight_decay=5e-4)
-        ot2.load_state_dict(ot.state_dict())
+        ot2.load_state_dict(copy.deepcopy(sd_t))
         run(pt2, ot2, grads[3:])
         for a, b in zip(pt2, pr):
             np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=3e-6, atol=3e-7)
