@@ -101,59 +101,97 @@ def eval_inputs(nq, ng, D, rank, world):
 
 
 def pmc_traffic(key):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE + WRITE_SIZE collected in separate counter-only runs); None if the file is absent."""
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-            e = json.load(f)[key]
-        return (e["fetch_bytes"] + e["write_bytes"]) / e["launches"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, falling back
+    to the round-1 file: FETCH_SIZE + WRITE_SIZE collected in separate counter-only runs); None if absent."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                e = json.load(f)[key]
+            return (e["fetch_bytes"] + e["write_bytes"]) / e["launches"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
-def run_eval(args, rank, world):
+def run_eval(args, rank, world, steps=None, warmup=None):
+    """BASELINE configs[4]: normalise + squared-L2 + rank + CMC/mAP over 2228 x 17661 x 2048 fp32.  Timed twice:
+    the METRIC-ONLY path the validation hook uses (streamed: the m x n matrix is never written; `value`) and the
+    materialised path (distance matrix + int64 ranked indices, what get_similar / the rank-index goldens need)."""
     from centroids_reid_amd import reid_metric as rm
+    from centroids_reid_amd import parallel as par
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     nq, ng, D = 2228, 17661, 2048
     feats, pids, cams = eval_inputs(nq, ng, D, rank, world)
     # weak scaling: every rank ranks its own nq queries against the (all-gathered) gallery
     q_pids = torch.as_tensor(pids[:nq], device="cuda"); g_pids = torch.as_tensor(pids[nq:], device="cuda")
     q_cams = torch.as_tensor(cams[:nq], device="cuda"); g_cams = torch.as_tensor(cams[nq:], device="cuda")
-    from centroids_reid_amd import parallel as par
+    plan = rm.StreamPlan(pids[:nq], pids[nq:], cams[:nq], cams[nq:], "cuda")     # index structures: resident inputs
     glo, ghi = par.shard_bounds(ng, rank, world)
     gal_shard = feats[nq + glo:nq + ghi].contiguous() if world > 1 else None
     gcounts = [par.shard_bounds(ng, r, world)[1] - par.shard_bounds(ng, r, world)[0] for r in range(world)]
 
-    def step():
-        if world > 1:  # node-level all-gather of (gallery) embeddings before the distance matrix
-            f = torch.cat([feats[:nq], par.all_gather_rows(gal_shard, gcounts)])
-        else:
-            f = feats
-        fn, sq = rm.l2_normalize(f, return_sqnorm=True)
+    def gathered():
+        if world > 1:  # node-level all-gather of (gallery) embeddings before the distance stage
+            return torch.cat([feats[:nq], par.all_gather_rows(gal_shard, gcounts)])
+        return feats
+
+    def step_streamed():
+        fn, sq = rm.l2_normalize(gathered(), return_sqnorm=True)
+        v, a, fr = rm.stream_eval(fn[:nq], fn[nq:], sq[:nq].contiguous(), sq[nq:].contiguous(), plan)
+        return rm.eval_reduce_device(v, a, fr, 50)
+
+    def step_materialised():
+        fn, sq = rm.l2_normalize(gathered(), return_sqnorm=True)
         d = rm.get_euclidean(fn[:nq], fn[nq:], sq[:nq].contiguous(), sq[nq:].contiguous())
         idx = rm.rank_rows(d)
         return rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50)
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier_sync(world)
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    pairs = float(nq) * ng * world * args.steps
-    mAP = float(out[1].item())
+    def timed(step):
+        for _ in range(warmup):
+            out = step()
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        barrier_sync(world)
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), out
 
-    # ---- per-kernel roofline (rank 0): dominant kernel = distance GEMM (MFMA-bound, see DESIGN.md)
+    dt_m, out_m = timed(step_materialised)
+    dt, out = timed(step_streamed)
+    pairs = float(nq) * ng * world * steps
+    mAP = float(out[1].item())
+    assert abs(mAP - float(out_m[1].item())) < 1e-12, "streamed and materialised evaluation disagree"
+
+    # ---- per-kernel roofline (rank 0): dominant kernel = the distance contraction (MFMA-bound, see DESIGN.md)
     res = {}
     if rank == 0:
         fn, sq = rm.l2_normalize(feats, return_sqnorm=True)
         q, g = fn[:nq], fn[nq:]
         qq, gg = sq[:nq].contiguous(), sq[nq:].contiguous()
+        L = rm.L
+        lib = L.lib()
+        cap = plan.cap
+        pos_key = torch.empty((nq, cap), dtype=torch.int32, device="cuda"); pos_idx = torch.empty_like(pos_key)
+        npos = torch.empty(nq, dtype=torch.int32, device="cuda"); hist = torch.zeros((nq, cap), dtype=torch.int32, device="cuda")
+
+        def poslist():
+            L.check(lib.creid_stream_poslist(L.ptr(q), L.ptr(g), L.ptr(qq), L.ptr(gg), nq, ng, D, L.ptr(plan.q_slot),
+                                             L.ptr(plan.csr_off), L.ptr(plan.g_order), L.ptr(plan.q_cams), L.ptr(plan.g_cams),
+                                             cap, L.ptr(pos_key), L.ptr(pos_idx), L.ptr(npos), L.stream()), "poslist")
+
+        def count():
+            L.check(lib.creid_stream_count(L.ptr(q), L.ptr(g), L.ptr(qq), L.ptr(gg), nq, ng, D, L.ptr(plan.q_pids),
+                                           L.ptr(plan.g_pids), cap, L.ptr(pos_key), L.ptr(pos_idx), L.ptr(npos), L.ptr(hist),
+                                           L.stream()), "count")
+        poslist()
+        t_pos = time_kernel(poslist, 10)
+        t_count = time_kernel(count, 10)
         t_dist = time_kernel(lambda: rm.get_euclidean(q, g, qq, gg), 10)
         d = rm.get_euclidean(q, g, qq, gg)
         t_rank = time_kernel(lambda: rm.rank_rows(d), 5)
@@ -161,33 +199,36 @@ def run_eval(args, rank, world):
         t_norm = time_kernel(lambda: rm.l2_normalize(feats, return_sqnorm=True), 10)
         t_cmc = time_kernel(lambda: rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50), 10)
         flops = 2.0 * nq * ng * D
-        res["roofline"] = {"kernel": "sqdist_f32_kernel", "bound": "mfma", "achieved": flops / (t_dist * 1e-3) / 1e12,
-                           "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": flops / (t_dist * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
-                           "traffic": pmc_traffic("sqdist_f32_kernel"), "ms": t_dist}
+        res["roofline"] = {"kernel": "sqdist_count_f32_kernel (contraction + in-register rank-by-counting epilogue)",
+                           "bound": "mfma", "achieved": flops / (t_count * 1e-3) / 1e12, "peak": MFMA_F32_TFLOPS,
+                           "unit": "TFLOP/s", "frac": flops / (t_count * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
+                           "traffic": pmc_traffic("sqdist_count_f32_kernel"), "ms": t_count}
+        res["materialised"] = {
+            "value": float(nq) * ng * world * steps / dt_m, "unit": "pairs/s", "ms_per_step": dt_m / steps * 1e3,
+            "roofline": {"kernel": "sqdist_f32_kernel", "bound": "mfma", "achieved": flops / (t_dist * 1e-3) / 1e12,
+                         "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": flops / (t_dist * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
+                         "traffic": pmc_traffic("sqdist_f32_kernel"), "ms": t_dist},
+            "stages_ms": {"l2norm": t_norm, "sqdist": t_dist, "rank_rows": t_rank, "cmc_ap": t_cmc},
+            "rank_rows_GBs": nq * ng * (4 + 8) / (t_rank * 1e-3) / 1e9}
         # BASELINE configs[4] asks for fp16 vs fp32: the same distance stage on f16-rounded embeddings (MFMA f16,
         # fp32 accumulate) and what the rounding does to the ranking metric
         fn16 = fn.half()
         t_dist16 = time_kernel(lambda: rm.get_euclidean(fn16[:nq], fn16[nq:]), 10)
         idx16 = rm.rank_rows(rm.get_euclidean(fn16[:nq], fn16[nq:]))
         _, map16, _, _, _, _, _ = rm.eval_func_device(idx16, q_pids, g_pids, q_cams, g_cams, 50)
-        _, map32, _, _, _, _, _ = rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50)
         res["f16_vs_f32"] = {"sqdist_f16_ms": t_dist16, "sqdist_f16_TFLOPs": flops / (t_dist16 * 1e-3) / 1e12,
-                             "sqdist_f32_ms": t_dist, "mAP_f16_minus_f32": float(map16.item() - map32.item()),
+                             "sqdist_f32_ms": t_dist, "mAP_f16_minus_f32": float(map16.item()) - mAP,
                              "rank_index_agreement": float((idx16 == idx).float().mean().item())}
-        rank_bytes = nq * ng * (4 + 8)
-        res["stages_ms"] = {"l2norm": t_norm, "sqdist": t_dist, "rank_rows": t_rank, "cmc_ap": t_cmc}
-        res["roofline_hbm_stages"] = {
-            "l2norm_GBs": (nq + ng) * D * 8 / (t_norm * 1e-3) / 1e9,
-            "rank_rows_GBs": rank_bytes / (t_rank * 1e-3) / 1e9,
-            "peak_GBs": HBM_PEAK_GBS}
+        res["stages_ms"] = {"l2norm": t_norm, "poslist": t_pos, "sqdist_count": t_count}
+        res["roofline_hbm_stages"] = {"l2norm_GBs": (nq + ng) * D * 8 / (t_norm * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS}
         if not args.no_cpu_baseline and world == 1:             # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline_eval(feats, pids, cams, nq, ng)
         res["mAP"] = mAP
     return {
         "metric": "eval_dist_pairs_per_sec", "value": pairs / dt, "unit": "pairs/s",
-        "ms_per_step": dt / args.steps * 1e3, "dtype": "f32",
-        "config": {"workload": "DukeMTMC-shaped eval 2228x17661x2048: normalise+sqdist+rank+CMC/mAP (BASELINE configs[4])",
+        "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32",
+        "config": {"workload": "DukeMTMC-shaped eval 2228x17661x2048: normalise + squared-L2 + rank + CMC/mAP, metric-only "
+                               "streamed path (BASELINE configs[4])",
                    "queries_per_rank": nq, "gallery": ng, "D": D,
                    "parallelism": f"query-shard x{world}, gallery all-gather" if world > 1 else "single"},
         **res}
@@ -271,10 +312,18 @@ def main():
         args.warmup = args.warmup if args.warmup is not None else 5
         out = bench_train.run(args, rank, world, barrier_sync, time_kernel,
                               None if args.no_cpu_baseline else cpu_baseline_train)
+        if os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
+            # the other half of BASELINE.metric (eval query x gallery dist-pairs/s) rides in the same line, timed by
+            # the same invocation: 5 steps after 2 warm-up of the configs[4] workload
+            ev = run_eval(args, rank, world, steps=5, warmup=2)
+            if rank == 0:
+                ev["higher_is_better"] = True
+                out["eval"] = ev
     else:
         args.steps = args.steps or 5
         args.warmup = args.warmup if args.warmup is not None else 2
         out = run_eval(args, rank, world)
+        out.pop("steps", None)
     if rank == 0:
         line = {"metric": out.pop("metric"), "value": out.pop("value"), "unit": out.pop("unit"),
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
