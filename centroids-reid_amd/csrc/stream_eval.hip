@@ -20,7 +20,7 @@
 
 namespace {
 constexpr int SQ_TM = 64, SQ_TN = 256, SQ_BK = 16, SQ_LDA = SQ_TM + 1, SQ_LDB = SQ_TN + 1;
-constexpr int PL_MAXC = 128, PL_BK = 64;
+constexpr int PL_MAXC = 128;
 
 // float -> unsigned with the same order (negatives included; squared distances may be slightly negative)
 __device__ __forceinline__ unsigned mono_key(float d) {
@@ -30,42 +30,40 @@ __device__ __forceinline__ unsigned mono_key(float d) {
 }  // namespace
 
 // ----------------------------------------------------------------------------------------
-// 1. positives.  One 256-thread workgroup per query.  Candidates = the gallery rows of the query's pid (CSR
-//    slice of g_order, ascending gallery index), kept when their camera differs from the query's.  The
-//    q / candidate rows go through LDS in 64-wide k chunks; thread c runs the fmaf chain of candidate c.
+// 1. positives.  One 128-thread workgroup per query.  Candidates = the gallery rows of the query's pid (CSR slice
+//    of g_order, ascending gallery index), kept when their camera differs from the query's.  Thread c runs the fmaf
+//    chain of candidate c over its own gallery row (16-B loads, consecutive k: every 128-B line is fetched from L2
+//    once and then served by the L1); the query row is wave-uniform, so its values arrive through the scalar cache.
+//    A chain is 2048 dependent FMAs (~5 us); thousands of them run side by side.
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stream_poslist_kernel(
+__global__ __launch_bounds__(PL_MAXC) void stream_poslist_kernel(
     const float* __restrict__ q, const float* __restrict__ g, const float* __restrict__ qq, const float* __restrict__ gg,
     int D, const int32_t* __restrict__ q_slot, const int64_t* __restrict__ csr_off, const int32_t* __restrict__ g_order,
     const int64_t* __restrict__ q_cams, const int64_t* __restrict__ g_cams, int cap, unsigned* __restrict__ pos_key,
     int32_t* __restrict__ pos_idx, int32_t* __restrict__ npos) {
-  __shared__ float qs[PL_BK];
-  __shared__ float tile[PL_MAXC][PL_BK + 1];
   __shared__ int cand[PL_MAXC];
   __shared__ unsigned skey[PL_MAXC];
-  __shared__ int s_n, s_wcnt[4];
+  __shared__ int s_n, s_wcnt[2];
   const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned* okey = pos_key + (int64_t)qi * cap;
   int32_t* oidx = pos_idx + (int64_t)qi * cap;
-  for (int i = tid; i < cap; i += 256) { okey[i] = 0xffffffffu; oidx[i] = 0x7fffffff; }   // padding for the search
+  for (int i = tid; i < cap; i += PL_MAXC) { okey[i] = 0xffffffffu; oidx[i] = 0x7fffffff; }   // padding for the search
   const int slot = q_slot[qi];
   if (slot < 0) { if (tid == 0) npos[qi] = 0; return; }
   const int64_t c0 = csr_off[slot], c1 = csr_off[slot + 1];
   const int64_t qc = q_cams[qi];
-  // compaction of the kept candidates in gallery-index order (every pass handles 256 CSR entries)
+  // compaction of the kept candidates in gallery-index order (every pass handles 128 CSR entries)
   if (tid == 0) s_n = 0;
   __syncthreads();
-  bool overflow = false;
-  for (int64_t b = c0; b < c1; b += 256) {
+  for (int64_t b = c0; b < c1; b += PL_MAXC) {
     const int64_t e = b + tid;
     int gi = -1;
     if (e < c1) { gi = g_order[e]; if (g_cams[gi] == qc) gi = -1; }
     const unsigned long long bal = __ballot(gi >= 0);
     if (lane == 0) s_wcnt[wave] = __popcll(bal);
     __syncthreads();
-    int base = s_n;
-    for (int w = 0; w < wave; ++w) base += s_wcnt[w];
-    const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    const int base = s_n + (wave ? s_wcnt[0] : 0);
+    const int tot = s_wcnt[0] + s_wcnt[1];
     if (gi >= 0) {
       const int p = base + __popcll(bal & lanemask_lt());
       if (p < PL_MAXC) cand[p] = gi;
@@ -74,31 +72,38 @@ __global__ __launch_bounds__(256) void stream_poslist_kernel(
     if (tid == 0) s_n += tot;
     __syncthreads();
   }
-  int nc = s_n;
-  if (nc > cap || nc > PL_MAXC) { overflow = true; nc = 0; }
-  if (overflow) { if (tid == 0) npos[qi] = -1; return; }          // the caller sends such queries to the general path
+  const int nc = s_n;
+  if (nc > cap || nc > PL_MAXC) { if (tid == 0) npos[qi] = -1; return; }   // the caller sends such queries to the general path
   if (nc == 0) { if (tid == 0) npos[qi] = 0; return; }
-  const float* qrow = q + (int64_t)qi * D;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < D; k0 += PL_BK) {
-    __syncthreads();
-    if (tid < PL_BK) qs[tid] = (k0 + tid < D) ? qrow[k0 + tid] : 0.f;
-    for (int c = wave; c < nc; c += 4)
-      tile[c][lane] = (k0 + lane < D) ? g[(int64_t)cand[c] * D + k0 + lane] : 0.f;
-    __syncthreads();
-    if (tid < nc) {
-#pragma unroll 16
-      for (int kk = 0; kk < PL_BK; ++kk) acc = fmaf(qs[kk], tile[tid][kk], acc);      // the MFMA's own k order
-    }
-  }
+  const float* __restrict__ qrow = q + (int64_t)qi * D;
+  int gi = 0;
   if (tid < nc) {
-    const int gi = cand[tid];
+    gi = cand[tid];
+    const float* __restrict__ grow = g + (int64_t)gi * D;
+    float acc = 0.f;
+    int k = 0;
+    const int kend = D & ~15;
+    float4 n0, n1, n2, n3;                                 // the next 64 bytes of the row fly while this block is chained
+    if (kend > 0) {
+      n0 = *reinterpret_cast<const float4*>(grow); n1 = *reinterpret_cast<const float4*>(grow + 4);
+      n2 = *reinterpret_cast<const float4*>(grow + 8); n3 = *reinterpret_cast<const float4*>(grow + 12);
+    }
+    for (; k < kend; k += 16) {                            // the MFMA's own k order: one sequential fmaf chain
+      const float4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
+      const int kn = min(k + 16, kend - 16);
+      n0 = *reinterpret_cast<const float4*>(grow + kn); n1 = *reinterpret_cast<const float4*>(grow + kn + 4);
+      n2 = *reinterpret_cast<const float4*>(grow + kn + 8); n3 = *reinterpret_cast<const float4*>(grow + kn + 12);
+      acc = fmaf(qrow[k + 0], v0.x, acc); acc = fmaf(qrow[k + 1], v0.y, acc); acc = fmaf(qrow[k + 2], v0.z, acc); acc = fmaf(qrow[k + 3], v0.w, acc);
+      acc = fmaf(qrow[k + 4], v1.x, acc); acc = fmaf(qrow[k + 5], v1.y, acc); acc = fmaf(qrow[k + 6], v1.z, acc); acc = fmaf(qrow[k + 7], v1.w, acc);
+      acc = fmaf(qrow[k + 8], v2.x, acc); acc = fmaf(qrow[k + 9], v2.y, acc); acc = fmaf(qrow[k + 10], v2.z, acc); acc = fmaf(qrow[k + 11], v2.w, acc);
+      acc = fmaf(qrow[k + 12], v3.x, acc); acc = fmaf(qrow[k + 13], v3.y, acc); acc = fmaf(qrow[k + 14], v3.z, acc); acc = fmaf(qrow[k + 15], v3.w, acc);
+    }
+    for (; k < D; ++k) acc = fmaf(qrow[k], grow[k], acc);
     skey[tid] = mono_key(fmaf(-2.0f, acc, qq[qi] + gg[gi]));                          // sqdist epilogue, same bits
   }
   __syncthreads();
   if (tid < nc) {                                      // rank by counting over (key, gallery index)
     const unsigned k = skey[tid];
-    const int gi = cand[tid];
     int pos = 0;
     for (int c = 0; c < nc; ++c) {
       const unsigned kc = skey[c];
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
     const float* __restrict__ q, const float* __restrict__ g, const float* __restrict__ qq, const float* __restrict__ gg,
     int m, int n, int D, const int64_t* __restrict__ q_pids, const int64_t* __restrict__ g_pids, int cap, int log2cap,
     const unsigned* __restrict__ pos_key, const int32_t* __restrict__ pos_idx, const int32_t* __restrict__ npos,
-    unsigned* __restrict__ hist_out, int tiles_m, int tiles_n, int nsplit) {
+    unsigned* __restrict__ hist_out, int tiles_m, int tiles_n, int nsplit, int skip_count) {
   __shared__ float As[2][SQ_BK][SQ_LDA];
   __shared__ float Bs[2][SQ_BK][SQ_LDB];
   __shared__ float s_qq[SQ_TM];
@@ -161,42 +166,44 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
 
   const int lrow = tid >> 2, lkc = tid & 3;
   const float* ap = q + (int64_t)min(row0 + lrow, m - 1) * D + 4 * lkc;
+  const float* bp[4];
+  float4 ra, rb[4];
+  auto set_tile = [&](int tn) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bp[i] = g + (int64_t)min(tn * SQ_TN + lrow + 64 * i, n - 1) * D + 4 * lkc;
+  };
+  auto gload = [&](int k0) {
+    if (k0 + 4 * lkc < D) {
+      ra = *reinterpret_cast<const float4*>(ap + k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+    } else {
+      ra = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&](int buf) {
+    As[buf][4 * lkc + 0][lrow] = ra.x; As[buf][4 * lkc + 1][lrow] = ra.y;
+    As[buf][4 * lkc + 2][lrow] = ra.z; As[buf][4 * lkc + 3][lrow] = ra.w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = lrow + 64 * i;
+      Bs[buf][4 * lkc + 0][r] = rb[i].x; Bs[buf][4 * lkc + 1][r] = rb[i].y;
+      Bs[buf][4 * lkc + 2][r] = rb[i].z; Bs[buf][4 * lkc + 3][r] = rb[i].w;
+    }
+  };
+  const int nk = (D + SQ_BK - 1) / SQ_BK;
+  if (t0 < t1) { set_tile(t0); gload(0); }
   for (int tn = t0; tn < t1; ++tn) {
     const int col0 = tn * SQ_TN;
-    const float* bp[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bp[i] = g + (int64_t)min(col0 + lrow + 64 * i, n - 1) * D + 4 * lkc;
-    float4 ra, rb[4];
-    auto gload = [&](int k0) {
-      if (k0 + 4 * lkc < D) {
-        ra = *reinterpret_cast<const float4*>(ap + k0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
-      } else {
-        ra = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    auto lstore = [&](int buf) {
-      As[buf][4 * lkc + 0][lrow] = ra.x; As[buf][4 * lkc + 1][lrow] = ra.y;
-      As[buf][4 * lkc + 2][lrow] = ra.z; As[buf][4 * lkc + 3][lrow] = ra.w;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = lrow + 64 * i;
-        Bs[buf][4 * lkc + 0][r] = rb[i].x; Bs[buf][4 * lkc + 1][r] = rb[i].y;
-        Bs[buf][4 * lkc + 2][r] = rb[i].z; Bs[buf][4 * lkc + 3][r] = rb[i].w;
-      }
-    };
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const int nk = (D + SQ_BK - 1) / SQ_BK;
-    gload(0);
     __syncthreads();                               // previous tile's readers are done with both LDS buffers
-    lstore(0);
+    lstore(0);                                     // k-tile 0 was fetched during the previous tile's epilogue
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
       const int buf = t & 1;
@@ -213,28 +220,63 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
       if (t + 1 < nk) lstore(buf ^ 1);
       __syncthreads();
     }
-    // ---- epilogue: the tile is consumed here
+    if (tn + 1 < t1) { set_tile(tn + 1); gload(0); }               // flies while the epilogue runs
+    // ---- epilogue: the tile is consumed here (row-major walk: the row's metadata is read once per 4 columns)
+    float gv[4];
+    long long gp[4];
+    bool okc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = col0 + wn * 128 + j * 32 + l31;
-      const bool okc = c < n;
-      const float gv = okc ? gg[c] : 0.f;
-      const long long gp = okc ? (long long)g_pids[c] : 0;
+      okc[j] = c < n;
+      gv[j] = okc[j] ? gg[c] : 0.f;
+      gp[j] = okc[j] ? (long long)g_pids[c] : 0;
+    }
+    // Two accumulator rows x four column blocks = 8 binary searches in flight per lane: the search is a chain of
+    // dependent LDS reads (~100 cycles each), so it is the number of INDEPENDENT chains that sets the epilogue time.
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int np = s_np[rl];
-        if (!okc || np == 0 || gp == s_qpid[rl]) continue;         // positives / removed entries are not counted
-        const unsigned key = mono_key(fmaf(-2.0f, acc[j][r], s_qq[rl] + gv));
-        if (key > s_kmax[rl]) continue;                            // behind every positive: affects no rank
-        const unsigned* K = s_keys + (rl << log2cap);
-        int lo = 0;
-        for (int step = cap >> 1; step > 0; step >>= 1)
-          if (K[lo + step - 1] < key) lo += step;
-        if (K[lo] < key) ++lo;                                     // lo = #positives with key strictly below
-        while (lo < np && K[lo] == key && pos_idx[(int64_t)(row0 + rl) * cap + lo] < c) ++lo;   // ties: by gallery index
-        if (lo < np) atomicAdd(&s_hist[(rl << log2cap) + lo], 1u);
+    for (int r = 0; r < 16; r += 2) {
+      int rl[2], np[2], lo[2][4];
+      unsigned key[2][4];
+      bool live[2][4];
+      const unsigned* K[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        rl[h] = wm * 32 + ((r + h) & 3) + 8 * ((r + h) >> 2) + 4 * kh;
+        np[h] = skip_count ? 0 : s_np[rl[h]];
+        const long long qp = s_qpid[rl[h]];
+        const float qv = s_qq[rl[h]];
+        const unsigned kmax = s_kmax[rl[h]];
+        K[h] = s_keys + (rl[h] << log2cap);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          key[h][j] = mono_key(fmaf(-2.0f, acc[j][r + h], qv + gv[j]));
+          // positives / removed entries (same pid) are not counted; behind every positive: affects no rank
+          live[h][j] = np[h] > 0 && okc[j] && gp[j] != qp && key[h][j] <= kmax;
+          lo[h][j] = 0;
+        }
       }
+      if (np[0] == 0 && np[1] == 0) continue;                      // uniform per wave half
+      for (int step = cap >> 1; step > 0; step >>= 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lo[h][j] += (K[h][lo[h][j] + step - 1] < key[h][j]) ? step : 0;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int l = lo[h][j];
+          l += (K[h][l] < key[h][j]) ? 1 : 0;                      // l = #positives with key strictly below
+          if (live[h][j]) {
+            if (l < np[h] && K[h][l] == key[h][j]) {               // ties: by gallery index (rare)
+              const int c = col0 + wn * 128 + j * 32 + l31;
+              while (l < np[h] && K[h][l] == key[h][j] && pos_idx[(int64_t)(row0 + rl[h]) * cap + l] < c) ++l;
+            }
+            if (l < np[h]) atomicAdd(&s_hist[(rl[h] << log2cap) + l], 1u);
+          }
+        }
     }
   }
   __syncthreads();
@@ -279,7 +321,7 @@ int creid_stream_poslist(const float* q, const float* g, const float* qq, const 
   CREID_CHECK_ARG(q && g && qq && gg && q_slot && csr_off && g_order && q_cams && g_cams && pos_key && pos_idx && npos);
   if (cap < 2 || cap > PL_MAXC || (cap & (cap - 1)) != 0) return CREID_E_SHAPE;
   if (n > 0x7ffffff0LL || m > 0x7ffffff0LL) return CREID_E_SHAPE;
-  hipLaunchKernelGGL(stream_poslist_kernel, dim3((unsigned)m), dim3(256), 0, as_stream(stream), q, g, qq, gg, (int)D, q_slot,
+  hipLaunchKernelGGL(stream_poslist_kernel, dim3((unsigned)m), dim3(PL_MAXC), 0, as_stream(stream), q, g, qq, gg, (int)D, q_slot,
                      csr_off, g_order, q_cams, g_cams, (int)cap, pos_key, pos_idx, npos);
   CREID_LAUNCH_RET();
 }
@@ -297,6 +339,8 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
   const int tiles_m = (int)((m + SQ_TM - 1) / SQ_TM), tiles_n = (int)((n + SQ_TN - 1) / SQ_TN);
   // enough workgroups for two per CU, but never fewer than ~4 gallery tiles per workgroup (per-tile restart cost)
   static const int target = [] { const char* e = getenv("CREID_STREAM_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  // timing ablation only (CREID_STREAM_NOEPI=1: contraction without the count epilogue -- results are then wrong)
+  static const int skip_count = [] { const char* e = getenv("CREID_STREAM_NOEPI"); return e ? atoi(e) : 0; }();
   int nsplit = (target + tiles_m - 1) / tiles_m;
   if (nsplit > tiles_n) nsplit = tiles_n;
   if (nsplit < 1) nsplit = 1;
@@ -309,7 +353,7 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
   if (attr_rc != hipSuccess) return (int)attr_rc;
   hipLaunchKernelGGL(sqdist_count_f32_kernel, dim3((unsigned)(tiles_m * nsplit)), dim3(256), dyn, as_stream(stream), q, g, qq,
                      gg, (int)m, (int)n, (int)D, q_pids, g_pids, (int)cap, log2cap, pos_key, pos_idx, npos, hist, tiles_m,
-                     tiles_n, nsplit);
+                     tiles_n, nsplit, skip_count);
   CREID_LAUNCH_RET();
 }
 
