@@ -238,6 +238,13 @@ class BackboneEngine:
         self._keep = []
         self.reduce_stream = os.environ.get("CREID_REDUCE_STREAM", "0") == "1"
         self._ws2 = [None, None]
+        # weight-gradient split reductions ride in the first workgroups of the NEXT data-gradient launch
+        # (creid_conv2d_dgrad_fused_nhwc) instead of 53 stand-alone 5-25 us launches; CREID_WRED_PIGGYBACK=0: round-1 path
+        self.wred_piggyback = os.environ.get("CREID_WRED_PIGGYBACK", "1") == "1" and not self.wgrad_stream \
+            and not self.reduce_stream
+        self._wred_pending = []        # FIFO of (desc, grad tensor, workspace, nbytes)
+        self._wred_ws = [None, None, None]
+        self._wred_flip = 0
         self.saved = None
         self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
@@ -488,6 +495,19 @@ class BackboneEngine:
         d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         nbytes = lib.creid_conv2d_wgrad_workspace_bytes(C.byref(d), self.dt)
         gw = self._grad_of(u.conv.weight)
+        if self.wred_piggyback:
+            # partial tiles now; the sum over the splits is carried by the next data-gradient launch.  At most two
+            # jobs are ever pending (c1 and the downsample branch), so three rotating workspaces never collide.
+            k = self._wred_flip = (self._wred_flip + 1) % 3
+            if self._wred_ws[k] is None or self._wred_ws[k].numel() < nbytes:
+                self._keep.append(self._wred_ws[k])
+                self._wred_ws[k] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+            ws = self._wred_ws[k]
+            L.check(lib.creid_conv2d_wgrad_partials(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(ws), nbytes, self.dt, st),
+                    "conv2d_wgrad_partials")
+            self._wred_pending.append((d, gw, ws, nbytes))
+            assert len(self._wred_pending) <= 2
+            return
         if not self.reduce_stream:
             ws = self._workspace(nbytes)
             L.check(lib.creid_conv2d_wgrad_nhwc(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(gw), 1, L.ptr(ws), nbytes, self.dt,
@@ -519,6 +539,16 @@ class BackboneEngine:
         d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         M = B * H * W
         dx = self._empty(M, u.cin)
+        if self._wred_pending:
+            rd, rgw, rws, rbytes = self._wred_pending.pop(0)
+            fuse_bn = bnred is not None and self.fuse_bn_reduce
+            x, act, mean, invstd = bnred if fuse_bn else (None, None, None, None)
+            part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32) if fuse_bn else None
+            L.check(lib.creid_conv2d_dgrad_fused_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src),
+                                                      add_src_stride, L.ptr(x), L.ptr(act), L.ptr(mean), L.ptr(invstd),
+                                                      L.ptr(part), stat_image_rows if fuse_bn else 0, C.byref(rd), L.ptr(rgw), 1,
+                                                      L.ptr(rws), rbytes, self.dt, st), "conv2d_dgrad_fused")
+            return dx, part
         if bnred is not None and self.fuse_bn_reduce:
             x, act, mean, invstd = bnred
             part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32)
@@ -572,10 +602,9 @@ class BackboneEngine:
                         and s["hin"] % 2 == 0 and s["win"] % 2 == 0):
                     # stride-2 1x1 downsample: its data gradient lives on the even pixels only -- compute it as a
                     # plain 1x1 GEMM over the OUTPUT grid and let the c1 dgrad epilogue scatter-add it
-                    dd, _, _ = _desc(B, s["h2"], s["w2"], dsu.cin, dsu.cout, 1, 1, 0)
-                    tmp = self._empty(B * s["h2"] * s["w2"], dsu.cin)
-                    L.check(lib.creid_conv2d_dgrad_nhwc(C.byref(dd), L.ptr(dxd), L.ptr(dsu.w_crsk), L.ptr(tmp), None,
-                                                        self.dt, st), "conv2d_dgrad(ds compact)")
+                    from types import SimpleNamespace
+                    shim = SimpleNamespace(cin=dsu.cin, cout=dsu.cout, k=1, stride=1, pad=0, w_crsk=dsu.w_crsk)
+                    tmp, _ = self._dgrad(shim, dxd, B, s["h2"], s["w2"])        # (also carries a pending split reduction)
                     g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt, add_src_stride=2)
                 else:
                     tmp, _ = self._dgrad(dsu, dxd, B, s["hin"], s["win"])
@@ -596,8 +625,17 @@ class BackboneEngine:
                 L.check(lib.creid_stem_conv_wgrad(B, H, W, L.ptr(xpad), L.ptr(dx0),
                                                   L.ptr(self._grad_of(self.stem.conv.weight)), 1, L.ptr(ws), nbytes,
                                                   self.dt, L.stream()), "stem_conv_wgrad")
+        self._flush_wred()
         self._join_side()
         self.saved = None
+
+    def _flush_wred(self):
+        """Split reductions that found no data-gradient launch to ride on (never in the ResNet schedules)."""
+        lib, st = L.lib(), L.stream()
+        while self._wred_pending:
+            rd, rgw, rws, rbytes = self._wred_pending.pop(0)
+            L.check(lib.creid_conv2d_wgrad_reduce(C.byref(rd), L.ptr(rgw), 1, L.ptr(rws), rbytes, self.dt, st),
+                    "conv2d_wgrad_reduce")
 
 
 class _BackboneFn(torch.autograd.Function):

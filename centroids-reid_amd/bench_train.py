@@ -263,7 +263,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
         res["roofline_hbm_stages"] = hbm_stage_rates(time_kernel, P * K, H, W)
         if cpu_baseline_fn is not None and world == 1:          # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline_fn(P, K, H, W)
-        if world == 1 and arch == "resnet50" and not f32:
+        if world == 1 and arch == "resnet50" and not f32 and os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
             del model
             torch.cuda.empty_cache()
             res["map_delta_bf16"] = map_delta_bf16()             # BASELINE metric (iii) on clustered synthetic identities

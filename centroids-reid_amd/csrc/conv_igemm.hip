@@ -15,7 +15,13 @@
 // activation dtype, and optional per-tile per-channel (sum, sum of squares) partials of the fp32
 // accumulators for the training-mode BatchNorm that follows every convolution.
 #include "conv_common.hpp"
+#include "wgrad_reduce.hpp"
 #include <stdlib.h>
+
+// defined in conv_wgrad.hip
+bool wgrad_make_reduce_job(const creid_conv_desc* d, int dtype, const void* ws, size_t ws_bytes, float* dw, int accumulate,
+                           WRedJob& j);
+int wgrad_reduce_job_launch(const WRedJob& j, hipStream_t s);
 
 // Out-of-image taps read this 128-byte page of zeros instead of selecting zeros per dword (saves 3 VALU
 // per load in the gather path).
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
                                                                 unsigned short* __restrict__ out,
                                                                 const unsigned short* __restrict__ add_src,
                                                                 float* __restrict__ bn_part, int tiles_n,
-                                                                BnRedArgs bnred) {
+                                                                BnRedArgs bnred, WRedJob wred) {
   constexpr int NT = 512;
   constexpr int BK = 64, TNW = BN / 64, NBI = BN / 32;
   constexpr int CP = BN + 8;
@@ -586,10 +592,20 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   static_assert(NS >= 2 && (NS - 2) * LPT <= 63, "ring depth");
   __shared__ __attribute__((aligned(1024))) unsigned short smem[LDS_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // piggybacked job: the LAST wred.nblocks workgroups sum the split partials of the PREVIOUS weight-gradient launch
+  // instead of computing a tile.  Workgroups are dispatched in order, so these start when the final wave of tiles
+  // is running and fill the CUs that wave leaves idle (placed first they held every workgroup slot for ~10 us and
+  // delayed the tiles: measured, no gain over the stand-alone launch).
+  const int nred = wred.ws ? wred.nblocks : 0;
+  const int ntile_wgs = (int)gridDim.x - nred;
+  if ((int)blockIdx.x >= ntile_wgs) {
+    wgrad_reduce_block<NT>(wred, (int)blockIdx.x - ntile_wgs, reinterpret_cast<float*>(smem));
+    return;
+  }
   const bool producer = wave >= 4;
   const int cw = wave & 3;                                       // role-local wave index
   const int wm = cw >> 1, wn = cw & 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = xcd_remap((int)blockIdx.x, ntile_wgs);
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int row0 = tile_m * 128, col0 = tile_n * BN;
   const int l31 = lane & 31, kh = lane >> 5;
@@ -1016,7 +1032,11 @@ static int ws_stages_env() {
 }
 
 static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src,
-                        float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}) {
+                        float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
+                        const WRedJob* wred_in = nullptr) {
+  WRedJob wred{};
+  if (wred_in) wred = *wred_in;
+  static_assert(sizeof(float) * (4 * 512 + 8192) <= 2 * (128 + 64) * 64 * 2, "reduce scratch must fit the smallest LDS ring");
   const int tiles_m = (g.M + 127) / 128;
   // pick the N tile: 128 unless that leaves the chip (256 CUs) under-filled or N is only 64
   int bn = 128;
@@ -1045,15 +1065,17 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
         gp.parity = 1;
       const int ws_stages = use_ws == 2 ? ws_stages_env() : ((bn == 64 && g.K >= ws_min_k) ? 3 : 2);
       const dim3 block_ws(512);
+      const dim3 grid_ws((unsigned)(tiles_m * tiles_n + (wred.ws ? wred.nblocks : 0)));
 #define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
-  hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid, block_ws, 0, s, gp, (const unsigned short*)src,          \
+  hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid_ws, block_ws, 0, s, gp, (const unsigned short*)src,       \
                      (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n, \
-                     bnred)
+                     bnred, wred)
       if (bn == 128) { if (ws_stages == 4) CREID_WS_LAUNCH(128, 4); else if (ws_stages == 2) CREID_WS_LAUNCH(128, 2); else CREID_WS_LAUNCH(128, 3); }
       else { if (ws_stages == 4) CREID_WS_LAUNCH(64, 4); else if (ws_stages == 2) CREID_WS_LAUNCH(64, 2); else CREID_WS_LAUNCH(64, 3); }
 #undef CREID_WS_LAUNCH
       return (int)hipGetLastError();
     }
+    if (wred.ws) { const int rc = wgrad_reduce_job_launch(wred, s); if (rc) return rc; wred.ws = nullptr; }
     // LDS ring depth (CREID_IGEMM_STAGES = 2..5, default 2 -- measured r01: deeper rings LOSE, the k-loop is bound
     // by the LDS->MFMA chain and by workgroups/CU, not by DMA latency; 3+ stages cost occupancy)
     static const int stages = [] { const char* e = getenv("CREID_IGEMM_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 5) ? v : 2; }();
@@ -1073,6 +1095,8 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
 #undef CREID_DMA_LAUNCH
   } else if (bnred.x) {
     return CREID_E_DTYPE;          // the fused reduction exists only in the bf16 LDS-DMA kernel
+  } else if (wred.ws && wgrad_reduce_job_launch(wred, s) != 0) {
+    return (int)hipGetLastError();
   } else if (dtype == CREID_BF16) {
     if (g.K % 64 != 0) return CREID_E_SHAPE;
     if (bn == 128)
@@ -1163,6 +1187,45 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
   g.add_compact = add_src_stride == 2;
   BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial, prefetch, (int)(bn_stat_image_rows / 128)};
   return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream), br);
+}
+
+/* Data gradient with everything that can ride in the same launch: "+ add_src" (full or stride-2 compact), the NEXT
+ * BatchNorm-backward's column reduction (bn_x != NULL; bf16), and the split reduction of the PREVIOUS weight-gradient
+ * launch (wred_desc != NULL: creid_conv2d_wgrad_partials of that convolution wrote wred_ws; the first workgroups of
+ * this launch sum the partials into wred_dw).  Where the fused kernel does not apply (fp32 parity mode, stem) the
+ * reduction runs as its own launch first -- same result. */
+int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
+                                  const void* add_src, int add_src_stride, const void* bn_x, const void* bn_act,
+                                  const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                                  int64_t bn_stat_image_rows, const creid_conv_desc* wred_desc, float* wred_dw,
+                                  int wred_accumulate, const void* wred_ws, size_t wred_ws_bytes, int dtype, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CREID_CHECK_ARG(dy && w_crsk && dx && bn_stat_image_rows >= 0);
+  if (bn_x) CREID_CHECK_ARG(bn_mean && bn_invstd && bn_partial);
+  if (bn_stat_image_rows % 128 != 0) return CREID_E_SHAPE;
+  if (add_src_stride != 1 && add_src_stride != 2) return CREID_E_ARG;
+  if (add_src_stride == 2 && (!add_src || d->in_h % 2 || d->in_w % 2)) return CREID_E_SHAPE;
+  static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
+  if (bn_x && (dtype != CREID_BF16 || !use_dma)) return CREID_E_DTYPE;
+  WRedJob job{};
+  bool have_job = false;
+  if (wred_desc) {
+    CREID_CHECK_ARG(wred_dw && wred_ws);
+    if (!wgrad_make_reduce_job(wred_desc, dtype, wred_ws, wred_ws_bytes, wred_dw, wred_accumulate, job)) return CREID_E_SHAPE;
+    have_job = true;
+  }
+  IGemmGeom g;
+  g.M = (int)(d->batch * d->in_h * d->in_w); g.OH = (int)d->in_h; g.OW = (int)d->in_w;
+  g.SH = (int)d->out_h; g.SW = (int)d->out_w; g.pitch = (int)d->out_c; g.log2span = ilog2_exact(d->out_c);
+  g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 1;
+  g.K = (int)(d->kh * d->kw * d->out_c); g.N = (int)d->in_c; g.check_bounds = 1;
+  igemm_finish_geom(g);
+  static const int prefetch = [] { const char* e = getenv("CREID_BNRED_PREFETCH"); return e ? atoi(e) : 1; }();
+  g.add_compact = add_src_stride == 2;
+  BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial, prefetch, (int)(bn_stat_image_rows / 128)};
+  if (!bn_x) br = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream), br, have_job ? &job : nullptr);
 }
 
 /* stem: 7x7 stride-2 pad-3 conv, 3 -> 64 channels, on the pre-padded NHWC4 image

@@ -14,6 +14,7 @@
 // The pixel range is split over gridDim.y workgroups; fp32 partial tiles go to the workspace and
 // wgrad_reduce_kernel<SL> sums them in a fixed order (deterministic) and scatters into the OIHW fp32 gradient.
 #include "conv_common.hpp"
+#include "wgrad_reduce.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -185,7 +186,8 @@ template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_
 template <int TM, int TN, int NS, bool WS = false>
 __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024) ? (WS ? 4 : 2) : (WS ? 2 : 1)) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
                                                                  const unsigned short* __restrict__ x, int NCO,
-                                                                 float* __restrict__ ws, int tiles_k, int m_per_split) {
+                                                                 float* __restrict__ ws, int tiles_k, int m_per_split,
+                                                                 int xcd_tiles, int xcd_splits) {
   constexpr int IM = TM / 64, JN = TN / 64;
   constexpr int LPR_A = TM / 8, LPR_B = TN / 8;                // lanes (16-B chunks) per tile row
   constexpr int RPI_A = 64 / LPR_A, RPI_B = 64 / LPR_B;        // rows per wave-instruction
@@ -197,7 +199,26 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024)
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;       // role-local wave index
   const bool producer = !WS || (tid >> 6) >= 4, consumer = !WS || (tid >> 6) < 4;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x, split = blockIdx.y;
+  // XCD-aware split placement (xcd_tiles > 0, 1-D grid): workgroup b runs on XCD b % 8, and every XCD has its own
+  // 4 MB L2.  A pixel range (split) is read by ALL tiles of the weight matrix, so all workgroups of a split go to
+  // ONE XCD (split % 8 == XCD): the range's dY / X rows are fetched from HBM once and then re-read from that L2.
+  // With the tile-major placement each XCD touched every pixel range and the operand re-reads (35x the unique bytes
+  // for a 512 -> 512 3x3 layer) all missed to the fabric.
+  // Fewer than 8 splits (xcd_splits in {1, 2, 4}): the 8 / splits XCDs that share a pixel range interleave its tiles.
+  int tile, split;
+  if (xcd_tiles > 0 && xcd_splits >= 8) {
+    const int bid = blockIdx.x, j = bid >> 3, ls = j / xcd_tiles;
+    tile = j - ls * xcd_tiles;
+    split = (bid & 7) + 8 * ls;
+    if (split >= xcd_splits) return;
+  } else if (xcd_tiles > 0) {
+    const int bid = blockIdx.x, x8 = bid & 7, share = 8 / xcd_splits;
+    split = x8 % xcd_splits;
+    tile = x8 / xcd_splits + share * (bid >> 3);
+    if (tile >= xcd_tiles) return;
+  } else {
+    tile = blockIdx.x; split = blockIdx.y;
+  }
   const int tile_co = tile / tiles_k, tile_k = tile - tile_co * tiles_k;
   const int co0 = tile_co * TM, k0 = tile_k * TN;
   const int m_begin = split * m_per_split, m_end = min(g.M, m_begin + m_per_split);
@@ -611,7 +632,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __r
 // ------------------------------------------------------------------------------------ host
 static int ilog2x(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return ((1LL << l) == v) ? l : -1; }
 
-struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split; };
+struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split, xcd; };
 
 static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   // The fp32 partial tiles cost  workgroups x TM x TN x 8 bytes  of traffic per layer (write + re-read by the
@@ -633,11 +654,20 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
     p.tiles_k = K / tn;
     p.tiles = (NCO / tm) * p.tiles_k;
     int splits = (target + p.tiles - 1) / p.tiles;
+    // XCD placement (see wgrad_bf16_dma_kernel): a multiple of 8 splits, at least 8, so that every XCD owns whole
+    // pixel ranges; CREID_WGRAD_XCD=0 keeps the round-1 rule
+    static const int xcd_mode = [] { const char* e = getenv("CREID_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    p.xcd = 0;
+    if (xcd_mode && dtype == CREID_BF16) {
+      if (splits >= 8) { splits = (splits + 4) / 8 * 8; p.xcd = 1; }                     // nearest multiple of 8
+      else if (xcd_mode >= 2) { splits = splits >= 6 ? 8 : (splits >= 3 ? 4 : splits); p.xcd = 1; }   // 1, 2, 4, 8
+    }
     const int max_splits = (M + 4 * ks - 1) / (4 * ks);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     p.m_per_split = ((M + splits - 1) / splits + ks - 1) / ks * ks;
     p.splits = (M + p.m_per_split - 1) / p.m_per_split;
+    if (p.xcd && p.splits < 8 && (8 % p.splits) != 0) p.xcd = 0;      // the shared-range map needs 1, 2, 4 (or >= 8) splits
     if (p.splits <= max_splits_pref) break;
   }
   return p;
@@ -647,6 +677,11 @@ template <int TM, int TN>
 static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* ws, const WgradPlan& p,
                            int dtype, hipStream_t s) {
   dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(256);
+  const bool xcd_on = p.xcd != 0;
+  const int xt = xcd_on ? p.tiles : 0;
+  const int share = p.splits >= 8 ? 1 : 8 / p.splits;
+  const dim3 grid_x(p.splits >= 8 ? (unsigned)(p.tiles * ((p.splits + 7) / 8) * 8) : (unsigned)(8 * ((p.tiles + share - 1) / share)));
+  const dim3 grid_dma = xcd_on ? grid_x : grid;
   static const int use_dma = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
   static const int stages = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
   static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
@@ -654,17 +689,17 @@ static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
   if (dtype == CREID_BF16 && use_dma && ((1 << g.log2span) >= TN || stem_geom)) {
     static const int use_ws = [] { const char* e = getenv("CREID_WGRAD_WS"); return e ? atoi(e) : 0; }();
     if (use_ws && !stem_geom)
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, true>), grid, dim3(512), 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, true>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);
     else if (stages == 2)
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2>), grid, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);
     else if (stages == 3)
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 3>), grid, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 3>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);
     else
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 4>), grid, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 4>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);
   }
   else if (dtype == CREID_BF16)
     hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN>), grid, block, 0, s, g, (const unsigned short*)dy,
@@ -704,6 +739,27 @@ static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO,
   else CREID_WRED(64);
 #undef CREID_WRED
   return (int)hipGetLastError();
+}
+
+// ---- the split reduction as a job (wgrad_reduce.hpp): stand-alone launch and the glue used by the data-gradient
+// launch that carries it
+__global__ __launch_bounds__(512) void wgrad_reduce_job_kernel(WRedJob j) {
+  extern __shared__ __attribute__((aligned(16))) float wred_lds[];
+  wgrad_reduce_block<512>(j, (int)blockIdx.x, wred_lds);
+}
+
+int wgrad_reduce_job_launch(const WRedJob& j, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_reduce_job_kernel, dim3((unsigned)j.nblocks), dim3(512), (size_t)(4 * 512 + j.K) * sizeof(float), s, j);
+  return (int)hipGetLastError();
+}
+
+bool wgrad_make_reduce_job(const creid_conv_desc* d, int dtype, const void* ws, size_t ws_bytes, float* dw, int accumulate,
+                           WRedJob& j) {
+  if (!d || !ws || !dw) return false;
+  const int M = (int)(d->batch * d->out_h * d->out_w), K = (int)(d->kh * d->kw * d->in_c), NCO = (int)d->out_c;
+  const WgradPlan p = plan_wgrad(M, NCO, K, dtype);
+  if (ws_bytes < (size_t)p.splits * NCO * K * sizeof(float)) return false;
+  return wred_make_job(j, (const float*)ws, dw, p.splits, NCO, K, (int)d->in_c, d->kh, d->kw, accumulate);
 }
 
 extern "C" {

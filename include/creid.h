@@ -268,6 +268,20 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
                                   const void* add_src, const void* bn_x, const void* bn_act,
                                   const float* bn_mean, const float* bn_invstd, float* bn_partial,
                                   int64_t bn_stat_image_rows, int add_src_stride, int dtype, void* stream);
+
+/* The data gradient with everything that can ride in the same launch: "+ add_src" (add_src_stride as above), the
+ * NEXT BatchNorm-backward's column reduction (bn_x != NULL, arguments as creid_conv2d_dgrad_bnred_nhwc), and the
+ * split reduction of the PREVIOUS weight-gradient launch: wred_desc != NULL names the convolution whose
+ * creid_conv2d_wgrad_partials call filled wred_ws; the first workgroups of this launch sum those partials into
+ * wred_dw (OIHW fp32; wred_accumulate as in creid_conv2d_wgrad_nhwc) while the rest compute gradient tiles, so the
+ * 5-25 us stand-alone reduce launch per layer disappears.  In fp32 parity mode the reduction runs as its own launch
+ * first (same result). */
+int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
+                                  const void* add_src, int add_src_stride, const void* bn_x, const void* bn_act,
+                                  const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                                  int64_t bn_stat_image_rows, const creid_conv_desc* wred_desc, float* wred_dw,
+                                  int wred_accumulate, const void* wred_ws, size_t wred_ws_bytes, int dtype,
+                                  void* stream);
 /* weight gradient into the fp32 OIHW tensor (the reference's nn.Parameter layout), optionally
  * accumulating; the pixel reduction is split over workgroups through `ws`. */
 size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype);

@@ -324,6 +324,29 @@ def test_ibn_layer_vs_torch(dtype):
             np.testing.assert_allclose(got.cpu().numpy(), ref.grad.float().numpy(), rtol=2e-3, atol=2e-2 if dtype == torch.bfloat16 else 1e-4)
 
 
+@pytest.mark.parametrize("arch,dtype", [("resnet50", torch.bfloat16), ("resnet50_ibn_a", torch.bfloat16), ("resnet50", torch.float32)])
+def test_piggyback_wgrad_reduce_matches_standalone(arch, dtype):
+    """The split reduction of every weight gradient rides in the first workgroups of the following data-gradient
+    launch (creid_conv2d_dgrad_fused_nhwc); same partial tiles, same fixed summation order per element up to the
+    grouping of the split lanes -> gradients equal to fp32 rounding of a different association."""
+    from oracle import backbone_oracle as bo
+    x = bo.synthetic_images(4, 128, 64, seed=22).cuda()
+    coef = torch.from_numpy(np.random.default_rng(4).standard_normal((4, 2048)).astype(np.float32)).cuda()
+    grads = []
+    for piggy in (True, False):
+        net, eng, _ = _build(arch, dtype)
+        eng.wred_piggyback = piggy
+        for _ in range(2):                       # twice: gradients accumulate, workspaces rotate
+            _, feat = eng.forward(x, training=True)
+            eng.backward(coef)
+        assert not eng._wred_pending
+        grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert set(grads[0]) == set(grads[1])
+    for n in grads[0]:
+        a, b = grads[0][n].double(), grads[1][n].double()
+        assert float((a - b).norm()) <= 2e-6 * float(b.norm()) + 1e-12, (n, float((a - b).norm()), float(b.norm()))
+
+
 _NEEDS_DMA = pytest.mark.skipif(os.environ.get("CREID_IGEMM_DMA", "1") != "1",
                                 reason="the fused BN-reduce epilogue lives in the LDS-DMA igemm kernels")
 

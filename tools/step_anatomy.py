@@ -1,0 +1,45 @@
+"""Per-step kernel table from a rocprofv3 kernel-trace .db of bench.py: isolates ONE replay of the captured training step
+(the kernels between the last two image_pad launches) and prints name / launches / total us, plus group totals."""
+import re
+import sqlite3
+import sys
+
+GROUPS = [("conv fwd + dgrad (igemm)", r"igemm_"), ("conv wgrad", r"wgrad_bf16|wgrad_f32"), ("wgrad split reduce", r"wgrad_reduce"),
+          ("BN backward apply", r"bn2d_bwd_apply|ibn_bwd_apply"), ("BN apply", r"bn2d_apply|ibn_apply"),
+          ("BN finalize (fwd+bwd)", r"finalize"), ("BN reduce (unfused)", r"bwd_reduce|col_stats"),
+          ("optimisers", r"adam|sgd_scaled"), ("pool / gap", r"maxpool|gap_"), ("layout", r"weight_prep|image_pad|nhwc"),
+          ("heads", r"triplet|center_|xent|bn1d|loo_|gemm_f32|mean_rows")]
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if "image_pad" in r[0]]
+    if len(marks) < 3:
+        print("not enough steps in the trace"); return
+    a, b = marks[-3], marks[-2]                      # a full replay in the middle of the timed loop
+    step = rows[a:b]
+    span = step[-1][2] - step[0][1]
+    agg = {}
+    for n, s, e in step:
+        n = re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:70]
+        v = agg.setdefault(n, [0, 0]); v[0] += 1; v[1] += e - s
+    tot = sum(v[1] for v in agg.values())
+    print(f"one step: {len(step)} kernels, {tot/1e3:.0f} us summed over a {span/1e3:.0f} us span")
+    grp = {}
+    for n, (c, t) in agg.items():
+        g = next((gn for gn, pat in GROUPS if re.search(pat, n)), "torch glue / other")
+        v = grp.setdefault(g, [0, 0]); v[0] += c; v[1] += t
+    print("| group | launches | us | % |\n|---|---:|---:|---:|")
+    for g, (c, t) in sorted(grp.items(), key=lambda kv: -kv[1][1]):
+        print(f"| {g} | {c} | {t/1e3:.0f} | {100*t/tot:.1f} |")
+    print("\n| kernel | launches | us | avg us |\n|---|---:|---:|---:|")
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+        print(f"| {n} | {c} | {t/1e3:.0f} | {t/c/1e3:.1f} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
