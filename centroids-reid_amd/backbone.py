@@ -245,6 +245,11 @@ class BackboneEngine:
         self._wred_pending = []        # FIFO of (desc, grad tensor, workspace, nbytes)
         self._wred_ws = [None, None, None]
         self._wred_flip = 0
+        self.on_group_done = None
+        self._group_first, o = {}, 0             # index of each layer's FIRST block -> layer number
+        for k, layer in enumerate((net.layer1, net.layer2, net.layer3, net.layer4), start=1):
+            self._group_first[o] = k
+            o += len(layer)
         self.saved = None
         self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
@@ -561,7 +566,9 @@ class BackboneEngine:
         return dx, None
 
     def backward(self, dfeat: torch.Tensor):
-        """Accumulates parameter gradients into `.grad` (fp32, reference layouts)."""
+        """Accumulates parameter gradients into `.grad` (fp32, reference layouts).  `self.on_group_done(k)`, if set,
+        is called after the last kernel of layer k (4, 3, 2, 1) has been enqueued -- every gradient of that layer is
+        then final in stream order (the data-parallel bucketed all-reduce hangs on it, parallel.py)."""
         sv = self.saved
         assert sv is not None and sv["training"], "backward() needs a training-mode forward first"
         lib, st = L.lib(), L.stream()
@@ -611,6 +618,9 @@ class BackboneEngine:
                     g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt)
             else:
                 g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm, bnred=nxt)
+            if self.on_group_done is not None and bi in self._group_first:
+                assert not self._wred_pending            # the layer's last split reduction rode on the launch above
+                self.on_group_done(self._group_first[bi])
         # stem
         xpad, x0, y0, mean0, invstd0, idx0 = sv["stem"]
         H, W = sv["H"], sv["W"]

@@ -170,6 +170,77 @@ def map_delta_bf16(n_id=96, n_query=2, n_gallery=6, H=256, W=128, noise=0.6, see
             "images": int(len(x)), "identities": n_id, "noise": noise}
 
 
+class DDPStepper:
+    """Data-parallel training step with the gradient all-reduce OVERLAPPED with backward and no eager kernels between
+    the captured pieces: the step is captured as hipGraph segments split where a gradient bucket becomes final
+    (after layer4's and layer3's backward), each bucket's RCCL all-reduce is enqueued on a side stream right after
+    its segment's replay and runs under the next segment, and the optimiser segment waits for the side stream.
+        seg0 = forward + heads + layer4 backward   -> all-reduce(layer4 + heads, ~66 MB)   [side stream]
+        seg1 = layer3 backward                     -> all-reduce(layer3, ~28 MB)           [side stream]
+        seg2 = layer2, layer1, stem backward       -> all-reduce(rest, ~6 MB) + centers    [side stream]
+        seg3 = Adam + center SGD (after the side stream)
+    The collectives themselves stay outside the graphs (RCCL calls are issued by the host on the side stream)."""
+
+    def __init__(self, model, world, static, use_graph=True):
+        self.model, self.world, self.static = model, world, static
+        self.buckets, self.hook, self.finish = parallel.make_overlapped_grad_sync(model, world)
+        self.eng = model.backbone.engine
+        self.use_graph = use_graph
+        self.segs, self.split_at, self.gopt, self.out = [], [], None, None
+        model.grad_sync = None
+        if use_graph:
+            self._capture()
+
+    def _capture(self):
+        model, eng = self.model, self.eng
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for s in range(2):                              # eager warm-up (allocations, lazy inits), with real syncs
+                self._eager_step(s)
+            torch.cuda.synchronize()
+            segs = [torch.cuda.CUDAGraph()]
+            split_at = []
+
+            def cap_hook(k):
+                if k in (4, 3):
+                    segs[-1].capture_end()
+                    split_at.append(k)
+                    g = torch.cuda.CUDAGraph()
+                    segs.append(g)
+                    g.capture_begin(pool=segs[0].pool())
+            eng.on_group_done = cap_hook
+            segs[0].capture_begin()
+            self.out = model.forward_backward(self.static, 0)
+            segs[-1].capture_end()
+            eng.on_group_done = None
+            self.gopt = torch.cuda.CUDAGraph()
+            self.gopt.capture_begin(pool=segs[0].pool())
+            model.apply_optimizers()
+            self.gopt.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        self.segs, self.split_at = segs, split_at
+
+    def _eager_step(self, s):
+        self.eng.on_group_done = self.hook
+        out = self.model.forward_backward(self.static, s)
+        self.eng.on_group_done = None
+        self.finish()
+        self.model.apply_optimizers()
+        return out
+
+    def step(self, s=0):
+        if not self.use_graph:
+            return self._eager_step(s)
+        for g, k in zip(self.segs, self.split_at + [None]):
+            g.replay()
+            if k is not None:
+                self.hook(k)
+        self.finish()
+        self.gopt.replay()
+        return self.out
+
+
 def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
     P, K, H, W = 16, 4, 256, 128
     arch = os.environ.get("CREID_BENCH_ARCH", "resnet50")      # resnet50_ibn_a: side measurement, not the headline config
@@ -185,10 +256,18 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
             if b.is_floating_point():
                 dist.broadcast(b, 0)
         model.grad_sync = parallel.make_grad_sync(world)
+        overlap = os.environ.get("CREID_DDP_OVERLAP", "1") == "1"
     batches = [synthetic_batch(P, K, H, W, s, rank) for s in range(4)]
     use_graph = os.environ.get("CREID_NO_GRAPH", "0") != "1"
     split_graph = world > 1 or os.environ.get("CREID_SPLIT_GRAPH", "0") == "1"
-    if use_graph:
+    if world > 1 and overlap:
+        sx, sl = batches[0][0].clone(), batches[0][1].clone()
+        stepper = DDPStepper(model, world, (sx, sl, batches[0][2], batches[0][3]), use_graph=use_graph)
+
+        def one_step(s):
+            sx.copy_(batches[s % 4][0]); sl.copy_(batches[s % 4][1])
+            return stepper.step(s)
+    elif use_graph:
         # The step is captured ONCE into hipGraphs; every timed step copies a fresh synthetic batch into the
         # static input buffers and replays.  Single GPU: one graph for the whole step.  Data parallel: graph A =
         # forward + losses + backward, then the RCCL all-reduce of the flat gradient buffer (eager, same stream),

@@ -48,6 +48,90 @@ def make_grad_sync(world):
     return sync
 
 
+class GradBuckets:
+    """Reverse-order contiguous buckets of the flat fp32 gradient buffer for overlap with backward.
+
+    The flat buffer holds the parameters in `named_parameters()` order (stem, layer1..layer4, BNNeck, classifier), and
+    backward produces gradients back to front, so the ranges
+        bucket 0 = [layer4 .. end of buffer]   (layer4 + heads: final when layer4's backward is done)
+        bucket 1 = [layer3 .. layer4)
+        bucket 2 = [start  .. layer3)          (stem, layer1, layer2)
+    become final in that order and each is ONE contiguous slice: a bucket is all-reduced on a side stream as soon as
+    its last kernel has been enqueued, while the next layer group's backward runs (PL's DDP does the same with its
+    reverse-order 25 MB buckets, utils/misc.py:101-119; here the sizes follow the layer groups: ~66 / 28 / 6 MB for
+    ResNet50, few large transfers for the per-link-bound xGMI rings).  The 1/world is folded into the Adam kernel."""
+
+    def __init__(self, names, offsets, total, groups=("layer4.", "layer3.")):
+        """names / offsets: parameter names and start offsets (elements) in flat-buffer order; total: padded length."""
+        cuts = []
+        for gname in groups:
+            start = next((o for n, o in zip(names, offsets) if gname in n), None)
+            if start is not None and start not in cuts and 0 < start < total:
+                cuts.append(start)
+        cuts = sorted(set(cuts), reverse=True)
+        hi = total
+        self.ranges = []
+        for c in cuts:
+            self.ranges.append((c, hi)); hi = c
+        self.ranges.append((0, hi))
+        self.total = total
+
+    @classmethod
+    def for_optimizer(cls, opt, groups=("layer4.", "layer3.")):
+        names = opt.param_groups[0].get("names") or [str(i) for i in range(len(opt._params))]
+        return cls(list(names), list(opt._offsets), opt.gflat.numel(), groups)
+
+    def __len__(self):
+        return len(self.ranges)
+
+    def all_reduce(self, gflat, i):
+        lo, hi = self.ranges[i]
+        if hi > lo:
+            dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
+
+
+def make_overlapped_grad_sync(model, world, groups=("layer4.", "layer3.")):
+    """Returns (buckets, on_group_done, finish): `on_group_done(k)` is the backbone engine's backward hook (k = 4, 3,
+    2, 1 after layer k's last kernel has been enqueued): it all-reduces the bucket that just became final on a side
+    stream; `finish()` reduces what is left (first bucket, centers) and makes the main stream wait for the side
+    stream before the optimiser kernels.  Works with eager steps and with the step captured as per-bucket graph
+    segments (bench_train.DDPStepper)."""
+    opt, _ = model.optimizers()
+    opt = getattr(opt, "_optimizer", opt)
+    buckets = GradBuckets.for_optimizer(opt, groups)
+    opt.grad_scale = 1.0 / world
+    side = torch.cuda.Stream()
+    layer_to_bucket = {}
+    for i, g in enumerate(groups):
+        if i < len(buckets) - 1:
+            layer_to_bucket[int(g.strip("layer."))] = i
+    state = {"next": 0}
+
+    def _launch(i):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            buckets.all_reduce(opt.gflat, i)
+
+    def on_group_done(k):
+        i = layer_to_bucket.get(k)
+        if i is not None and i == state["next"]:
+            _launch(i)
+            state["next"] = i + 1
+
+    def finish():
+        while state["next"] < len(buckets):
+            _launch(state["next"]); state["next"] += 1
+        cg = model.center_loss.centers.grad
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_reduce(cg, op=dist.ReduceOp.SUM)
+            cg.mul_(1.0 / world)
+        torch.cuda.current_stream().wait_stream(side)
+        state["next"] = 0
+
+    return buckets, on_group_done, finish
+
+
 def shard_bounds(n, rank, world):
     """Contiguous [lo, hi) slice of n items for `rank` (np.array_split sizes, like the reference's PK sampler
     split, datasets/samplers/distributed_pids_sampler.py:71)."""
@@ -57,22 +141,27 @@ def shard_bounds(n, rank, world):
 
 
 def all_gather_rows(local: torch.Tensor, counts=None) -> torch.Tensor:
-    """Concatenate row-shards [n_r, D] from all ranks (ragged allowed)."""
+    """Concatenate row-shards [n_r, D] from all ranks (ragged allowed) with ONE all_gather_into_tensor: equal shards
+    land directly in the output; ragged shards are padded to the longest and the padding rows are dropped after."""
     rank, world = world_info()
     if world == 1:
         return local
     if counts is None:
         cnt = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)
-        counts = [int(c.item()) for c in allc]
+        allc = torch.empty(world, device=local.device, dtype=torch.int64)
+        dist.all_gather_into_tensor(allc, cnt)
+        counts = [int(c) for c in allc.tolist()]
     mx = max(counts)
-    pad = local
+    tail = tuple(local.shape[1:])
+    pad = local.contiguous()
     if local.shape[0] < mx:
-        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))])
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad.contiguous())
-    return torch.cat([p[:c] for p, c in zip(parts, counts)])
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tail)])
+    out = torch.empty((world * mx,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    if all(c == mx for c in counts):
+        return out
+    out = out.view((world, mx) + tail)
+    return torch.cat([out[r, :c] for r, c in enumerate(counts)])
 
 
 def merge_eval_results(valid, ap, first, max_rank=50):

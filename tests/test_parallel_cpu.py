@@ -85,3 +85,51 @@ def test_shard_bounds_cover():
             b = [par.shard_bounds(n, r, w) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert [hi - lo for lo, hi in b] == [len(a) for a in np.array_split(np.arange(n), w)]
+
+
+def test_grad_buckets_cover_flat_buffer_in_reverse_layer_order():
+    """Bucket ranges: contiguous, disjoint, cover the whole padded buffer, ordered layer4+heads -> layer3 -> rest."""
+    from centroids_reid_amd import parallel as par
+    names = ["backbone.base.conv1.weight", "backbone.base.bn1.weight", "backbone.base.layer1.0.conv1.weight",
+             "backbone.base.layer2.0.conv1.weight", "backbone.base.layer3.0.conv1.weight", "backbone.base.layer3.1.bn1.bias",
+             "backbone.base.layer4.0.conv1.weight", "backbone.base.layer4.2.bn3.weight", "bn.weight", "fc_query.weight"]
+    numels = [9408, 64, 4096, 32768, 262144, 256, 1048576, 2048, 2048, 1538048]
+    offs, o = [], 0
+    for n in numels:
+        offs.append(o); o += (n + 3) // 4 * 4
+    b = par.GradBuckets(names, offs, o)
+    assert len(b) == 3
+    assert b.ranges[0] == (offs[6], o) and b.ranges[1] == (offs[4], offs[6]) and b.ranges[2] == (0, offs[4])
+    # a backbone without the named groups degrades to one bucket
+    b1 = par.GradBuckets(["a", "b"], [0, 8], 16)
+    assert b1.ranges == [(0, 16)]
+
+
+def _bucket_case(rank, world):
+    from centroids_reid_amd import parallel as par
+    names = ["stem.w", "layer1.0.w", "layer3.0.w", "layer3.1.w", "layer4.0.w", "bn.weight", "fc_query.weight"]
+    numels = [12, 20, 40, 8, 64, 4, 32]
+    offs, o = [], 0
+    for n in numels:
+        offs.append(o); o += (n + 3) // 4 * 4
+    b = par.GradBuckets(names, offs, o)
+    g = torch.arange(o, dtype=torch.float32) * (rank + 1) + rank
+    flat = g.clone()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    for i in range(len(b)):                       # bucket by bucket, in readiness order
+        b.all_reduce(g, i)
+    # ragged all-gather through ONE collective
+    rows = 3 + 2 * rank
+    local = torch.arange(rows * 4, dtype=torch.float32).view(rows, 4) + 100 * rank
+    allr = par.all_gather_rows(local)
+    eq = par.all_gather_rows(torch.full((2, 3), float(rank)))
+    return bool(torch.equal(g, flat)), allr.numpy(), eq.numpy(), len(b)
+
+
+def test_bucketed_allreduce_equals_flat_and_ragged_allgather_gloo():
+    out = _run(_bucket_case)
+    expect = np.concatenate([np.arange(3 * 4).reshape(3, 4), np.arange(5 * 4).reshape(5, 4) + 100]).astype(np.float32)
+    for same, allr, eq, nb in out:
+        assert same and nb == 3
+        np.testing.assert_array_equal(allr, expect)
+        np.testing.assert_array_equal(eq, np.repeat([[0.0], [1.0]], 2, axis=0).repeat(3, axis=1))
