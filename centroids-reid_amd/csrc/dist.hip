@@ -76,11 +76,14 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const void* __restrict_
 
 // ----------------------------------------------------------------------------------------
 // fp32 distance GEMM.  128x128 tile / 256 threads (4 waves as 2x2, 64x64 per wave = 2x2
-// MFMA 32x32 tiles), BK = 16, LDS double-buffered and K-MAJOR ([k][row], LD = 129) so that the
+// MFMA 32x32 tiles), BK = 16, LDS double-buffered and K-MAJOR ([k][row], LD = 130) so that the
 // per-lane MFMA operand (A[i = lane&31][k = lane>>5]) is a conflict-free ds_read_b32.
 // ----------------------------------------------------------------------------------------
 namespace {
-constexpr int DBM = 128, DBN = 128, DBK = 16, DLD = 129;
+// DLD = 130: 4*DLD = 8 (mod 32), so the staging stores of a 32-lane group (4 k-columns x 8 rows) fall on 32 distinct banks
+// (with 129 they were ~2-way conflicted: SQ_LDS_BANK_CONFLICT = 40 % of the busy cycles, profiles/r02_pmc_summary.md);
+// the fragment reads (32 consecutive rows of one k) are conflict-free for any pitch.
+constexpr int DBM = 128, DBN = 128, DBK = 16, DLD = 130;
 }
 
 __global__ __launch_bounds__(256) void sqdist_f32_kernel(const float* __restrict__ q, const float* __restrict__ g,

@@ -19,7 +19,7 @@
 #include <stdlib.h>
 
 namespace {
-constexpr int SQ_TM = 64, SQ_TN = 256, SQ_BK = 16, SQ_LDA = SQ_TM + 1, SQ_LDB = SQ_TN + 1;
+constexpr int SQ_TM = 64, SQ_TN = 256, SQ_BK = 16, SQ_LDA = SQ_TM + 2, SQ_LDB = SQ_TN + 2;   // pitch = 2 (mod 8): see dist.hip
 constexpr int PL_MAXC = 128;
 
 // float -> unsigned with the same order (negatives included; squared distances may be slightly negative)
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(PL_MAXC) void stream_poslist_kernel(
 // ----------------------------------------------------------------------------------------
 // 2. streamed contraction + count.  Workgroup = (query tile of 64 rows, slice of the gallery); 4 waves as 2 x 2,
 //    each 32 rows x 128 columns (1 x 4 MFMA 32x32 blocks) of a 64 x 256 tile; K-major LDS operands
-//    ([k][row], odd pitch -> conflict-free ds_read_b32 for the A[i = lane&31][k = lane>>5] operand layout).
+//    ([k][row]: conflict-free ds_read_b32 for the A[i = lane&31][k = lane>>5] operand layout; pitch = 2 mod 8 keeps
+//    the staging stores conflict-free too).
 //    Dynamic LDS: this query tile's positive keys [64][cap] and the histogram [64][cap].
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(

@@ -1,0 +1,76 @@
+"""Turn the gpurun_out/pmc_*.json passes (tools/pmc_run.sh) into profiles/r02_pmc_traffic.json + profiles/r02_pmc_summary.md."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+meta = json.load(open(os.path.join(G, "pmc_meta.json")))
+F, W, S, D = (json.load(open(os.path.join(G, f"pmc_{n}.json"))) for n in ("fetch", "write", "sq", "derived"))
+NSIMD = 256 * 4
+
+
+def fam(db, prefix, counter):
+    tot = n = 0
+    for k, v in db.items():
+        if k.startswith(prefix) and counter in v:
+            tot += v[counter]["sum"]; n += v[counter]["dispatches"]
+    return tot, n
+
+
+calib = {}
+for name, kern in (("calib_l2norm_rows", "l2norm_rows_kernel<0>"), ("calib_bn2d_apply", "bn2d_apply_kernel<unsigned short>"),
+                   ("calib_igemm_1x1_stream", "igemm_bf16_ws_kernel<64, 2>")):
+    f = F["_first_dispatch"][kern]["FETCH_SIZE"] * 1024
+    w = W["_first_dispatch"][kern]["WRITE_SIZE"] * 1024
+    calib[name] = {"known_read_bytes": meta[name]["read"], "known_write_bytes": meta[name]["write"], "FETCH_SIZE_bytes": f,
+                   "WRITE_SIZE_bytes": w, "fetch_ratio": f / meta[name]["read"], "write_ratio": w / meta[name]["write"]}
+cal_f = F["_first_dispatch"]["igemm_bf16_ws_kernel<64, 2>"]["FETCH_SIZE"] * 1024
+cal_w = W["_first_dispatch"]["igemm_bf16_ws_kernel<64, 2>"]["WRITE_SIZE"] * 1024
+out = {"_comment": "HBM-side traffic from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, unit KiB -> bytes), round 2, one "
+                   "MI355X, tools/pmc_run.sh.  CALIBRATION on kernels of exactly known traffic: FETCH_SIZE reads 0.500x the bytes of "
+                   "16-byte streaming loads, both plain global loads (bn2d_apply, bf16) and LDS-DMA (1x1 convolution), WRITE_SIZE "
+                   "1.000x -- as MI355X_MICROARCH.md says.  Round 1 calibrated on l2norm_rows, which reads every row TWICE "
+                   "(norm pass + scale pass): its 0.99 ratio was 2 reads x 0.5, and the 'no correction' conclusion was wrong.  "
+                   "`traffic_bytes` below = 2 * FETCH_SIZE + WRITE_SIZE.",
+       "calibration": calib}
+for key, prefix in (("igemm_family", "igemm_bf16_"), ("wgrad_family", "wgrad_bf16_")):
+    f, n = fam(F, prefix, "FETCH_SIZE"); w, _ = fam(W, prefix, "WRITE_SIZE")
+    f *= 1024; w *= 1024
+    if key == "igemm_family":
+        f -= cal_f; w -= cal_w; n -= 1
+    out[key] = {"launches": n, "fetch_bytes": 2 * f, "write_bytes": w, "fetch_size_raw_bytes": f,
+                "algorithmic_bytes": meta[key]["algorithmic_bytes"],
+                "traffic_over_algorithmic": (2 * f + w) / meta[key]["algorithmic_bytes"]}
+for key in ("sqdist_f32_kernel", "sqdist_count_f32_kernel", "rank_rows_lds_kernel", "stream_poslist_kernel", "cmc_ap_ranked_wide_kernel<false>"):
+    f = F[key]["FETCH_SIZE"]["sum"] * 1024; w = W[key]["WRITE_SIZE"]["sum"] * 1024
+    e = {"launches": F[key]["FETCH_SIZE"]["dispatches"], "fetch_bytes": 2 * f, "write_bytes": w, "fetch_size_raw_bytes": f}
+    if key in meta:
+        e["algorithmic_bytes"] = meta[key]["algorithmic_bytes"]
+        e["traffic_over_algorithmic"] = (2 * f + w) / meta[key]["algorithmic_bytes"]
+    out[key] = e
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
+
+lines = ["# rocprofv3 --pmc passes, round 2 (tools/pmc_run.sh over tools/pmc_kernels.py, one MI355X)", "",
+         "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of SIMD-cycles whose matrix",
+         "pipe is occupied, i.e. the MFMA-roofline fraction measured by the hardware rather than derived from time.  `MfmaUtil` /",
+         "`VALUBusy` are rocprofv3's derived metrics (gfx94x formulas), averaged over the dispatches.", "",
+         "| kernel | dispatches | MFMA busy % | MfmaUtil % | VALUBusy % | LDS bank-conflict cycles / SQ busy cycles |", "|---|---:|---:|---:|---:|---:|"]
+for k in sorted(S):
+    if k.startswith("_") or "at::" in k or "rocclr" in k:
+        continue
+    v = S[k]
+    if "GRBM_GUI_ACTIVE" not in v:
+        continue
+    simd_cycles = v["GRBM_GUI_ACTIVE"]["sum"] / 8 * NSIMD
+    busy = 100 * v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / simd_cycles
+    d = D.get(k, {})
+    mu = d.get("MfmaUtil", {}).get("sum", 0) / max(1, d.get("MfmaUtil", {}).get("dispatches", 1))
+    vb = d.get("VALUBusy", {}).get("sum", 0) / max(1, d.get("VALUBusy", {}).get("dispatches", 1))
+    bc = v["SQ_LDS_BANK_CONFLICT"]["sum"] / max(1.0, v["SQ_BUSY_CYCLES"]["sum"])
+    lines.append(f"| {k} | {v['GRBM_GUI_ACTIVE']['dispatches']} | {busy:.1f} | {mu:.1f} | {vb:.1f} | {bc:.2f} |")
+for fam_name, prefix in (("igemm family (conv fwd + dgrad, whole layer mix)", "igemm_bf16_"), ("wgrad family", "wgrad_bf16_")):
+    mf, _ = fam(S, prefix, "SQ_VALU_MFMA_BUSY_CYCLES"); ga, n = fam(S, prefix, "GRBM_GUI_ACTIVE")
+    lines.append(f"| **{fam_name}** | {n} | **{100 * mf / (ga / 8 * NSIMD):.1f}** | | | |")
+lines += ["", "HBM-side traffic and the FETCH_SIZE calibration: profiles/r02_pmc_traffic.json.", ""]
+open(os.path.join(ROOT, "profiles", "r02_pmc_summary.md"), "w").write("\n".join(lines))
+print("\n".join(lines[:4])); print(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.md")).read()[-2500:])
