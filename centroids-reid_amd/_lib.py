@@ -30,6 +30,7 @@ SIGNATURES = {
     "creid_rank_rows": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "creid_cmc_ap_ranked": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_cmc_ap_ranked_camsets": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_topk_rows": (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
     "creid_eval_reduce": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "creid_stream_poslist": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "creid_stream_count": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _p]),

@@ -405,6 +405,101 @@ __global__ __launch_bounds__(1024) void cmc_ap_ranked_wide_kernel(const int64_t*
   }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// top-k per row (inference/get_similar.py:114-119 keeps `indices[:, :topk]` of a full argsort): the k smallest
+// (distance, index) pairs of a row, in order, without ranking the other n - k entries.  One 1024-thread workgroup
+// per row, three streaming reads of the row (L2-resident): key range -> 4096-bucket histogram over the range ->
+// the bucket where the running count crosses k -> everything up to that bucket (k + a few entries) is collected
+// into LDS as (key << 32 | index) and bitonic-sorted; 64-bit order == (distance, index) order, so ties resolve by
+// gallery index like the stable rank kernel.  A row whose candidate set exceeds 4096 (massive ties) is flagged.
+// ----------------------------------------------------------------------------------------
+namespace {
+constexpr int TK_T = 1024, TK_B = 4096, TK_CAP = 4096;
+__device__ __forceinline__ unsigned tk_key(float d) {
+  const unsigned u = __float_as_uint(d);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float tk_unkey(unsigned k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+}  // namespace
+
+__global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict__ dist, int n, int64_t ld, int k,
+                                                         int64_t* __restrict__ out_idx, float* __restrict__ out_dist,
+                                                         uint8_t* __restrict__ flags) {
+  __shared__ unsigned hist[TK_B];
+  __shared__ unsigned long long cand[TK_CAP];
+  __shared__ unsigned s_lo[16], s_hi[16], s_wsum[16];
+  __shared__ unsigned s_cnt;
+  __shared__ int s_bstar, s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = dist + (int64_t)blockIdx.x * ld;
+  // A: key range
+  unsigned lo = 0xffffffffu, hi = 0u;
+  for (int j = tid; j < n; j += TK_T) { const unsigned key = tk_key(row[j]); lo = min(lo, key); hi = max(hi, key); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64)); hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64)); }
+  if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+  for (int i = tid; i < TK_B; i += TK_T) hist[i] = 0u;
+  if (tid == 0) { s_cnt = 0u; s_bstar = TK_B - 1; s_total = n; }
+  __syncthreads();
+  lo = s_lo[0]; hi = s_hi[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
+  const float scale = (float)TK_B / ((float)(hi - lo) + 1.0f);        // monotone map of [lo, hi] onto the buckets
+  auto bucket = [&](unsigned key) { return min((int)((float)(key - lo) * scale), TK_B - 1); };
+  // B: histogram, then the bucket where the running count reaches k
+  for (int j = tid; j < n; j += TK_T) atomicAdd(&hist[bucket(tk_key(row[j]))], 1u);
+  __syncthreads();
+  unsigned h4[4], mine = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { h4[q] = hist[tid * 4 + q]; mine += h4[q]; }
+  unsigned incl = mine;                                                // inclusive scan across the workgroup
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned v = (unsigned)__shfl_up((int)incl, o, 64); if (lane >= o) incl += v; }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  unsigned base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wsum[w];
+  unsigned run = base + incl - mine;                                   // entries in the buckets before mine
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (run < (unsigned)k && run + h4[q] >= (unsigned)k) { s_bstar = tid * 4 + q; s_total = (int)(run + h4[q]); }
+    run += h4[q];
+  }
+  __syncthreads();
+  const int bstar = s_bstar, total = s_total;
+  if (total > TK_CAP) { if (tid == 0) flags[blockIdx.x] = 1; return; }
+  // C: collect and sort the candidates
+  for (int j = tid; j < n; j += TK_T) {
+    const unsigned key = tk_key(row[j]);
+    if (bucket(key) <= bstar) cand[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)key << 32) | (unsigned)j;
+  }
+  int S = 1;
+  while (S < total) S <<= 1;
+  __syncthreads();
+  for (int i = total + tid; i < S; i += TK_T) cand[i] = ~0ull;
+  __syncthreads();
+  for (int sz = 2; sz <= S; sz <<= 1) {
+    for (int st = sz >> 1; st > 0; st >>= 1) {
+      for (int i = tid; i < (S >> 1); i += TK_T) {
+        const int a = ((i / st) * st * 2) + (i % st), b = a + st;
+        const bool up = ((a & sz) == 0);
+        const unsigned long long x = cand[a], y = cand[b];
+        if ((x > y) == up) { cand[a] = y; cand[b] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = tid; t < k; t += TK_T) {
+    const unsigned long long c = cand[t];
+    out_idx[(int64_t)blockIdx.x * k + t] = (int64_t)(c & 0xffffffffull);
+    if (out_dist) out_dist[(int64_t)blockIdx.x * k + t] = tk_unkey((unsigned)(c >> 32));
+  }
+  if (tid == 0) flags[blockIdx.x] = 0;
+}
+
 // means over valid queries: single workgroup
 __global__ __launch_bounds__(256) void eval_reduce_kernel(const uint8_t* __restrict__ valid,
                                                           const double* __restrict__ ap,
@@ -535,6 +630,17 @@ int creid_eval_reduce(const uint8_t* valid, const double* ap, const int32_t* fir
   if (max_rank < 1 || max_rank > 64) return CREID_E_SHAPE;
   hipLaunchKernelGGL(eval_reduce_kernel, dim3(1), dim3(256), 0, as_stream(stream), valid, ap, first, m,
                      (int)max_rank, out_cmc, out_map, out_topk, out_nvalid);
+  CREID_LAUNCH_RET();
+}
+
+int creid_topk_rows(const float* dist, int64_t m, int64_t n, int64_t ld, int32_t k, int64_t* out_idx, float* out_dist,
+                    uint8_t* flags, void* stream) {
+  CREID_CHECK_ARG(m >= 0 && n > 0 && ld >= n && k >= 1);
+  if (m == 0) return 0;
+  CREID_CHECK_ARG(dist && out_idx && flags);
+  if (k > n || k > 1024 || n > 0x7ffffff0LL || m > 0x7fffffffLL) return CREID_E_SHAPE;
+  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)m), dim3(TK_T), 0, as_stream(stream), dist, (int)n, ld, (int)k, out_idx,
+                     out_dist, flags);
   CREID_LAUNCH_RET();
 }
 

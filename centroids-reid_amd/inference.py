@@ -85,11 +85,13 @@ def get_similar(embeddings, paths, embeddings_gallery, paths_gallery, topk=0, no
     g = torch.as_tensor(np.asarray(embeddings_gallery, np.float32)).cuda() if not isinstance(embeddings_gallery, torch.Tensor) else embeddings_gallery.float().cuda()
     if normalize_features:
         q, g = rm.l2_normalize(q.contiguous()), rm.l2_normalize(g.contiguous())
-    distmat = rm.get_dist_func(distance_func)(x=q.contiguous(), y=g.contiguous())
-    indices = rm.rank_rows(distmat.contiguous())
-    if topk:
-        indices = indices[:, :topk]
-    dist_sel = torch.gather(distmat, 1, indices).cpu().numpy()
+    distmat = rm.get_dist_func(distance_func)(x=q.contiguous(), y=g.contiguous()).contiguous()
+    if topk:                                                   # top-k selection kernel: no full sort of the row
+        indices, dist_sel = rm.topk_rows(distmat, min(int(topk), distmat.shape[1]))
+        dist_sel = dist_sel.cpu().numpy()
+    else:
+        indices = rm.rank_rows(distmat)
+        dist_sel = torch.gather(distmat, 1, indices).cpu().numpy()
     idx = indices.cpu().numpy()
     paths_gallery = np.asarray(paths_gallery)
     return {qp: {"indices": idx[i, :], "paths": paths_gallery[idx[i, :]], "distances": dist_sel[i, :]}

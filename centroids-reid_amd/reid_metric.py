@@ -79,6 +79,30 @@ def rank_rows(distmat: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def topk_rows(distmat: torch.Tensor, k: int):
+    """(indices int64 [m, k], distances fp32 [m, k]): the first k columns of np.argsort(distmat, axis=1) and the
+    distances there (inference/get_similar.py:114-119), selected without sorting the whole row."""
+    L.require_gpu(distmat)
+    assert distmat.dtype == torch.float32 and distmat.dim() == 2
+    m, n = distmat.shape
+    if k > 1024 or k * 2 > n:
+        idx = rank_rows(distmat)[:, :k].contiguous()
+        return idx, torch.gather(distmat, 1, idx)
+    dev = distmat.device
+    idx = torch.empty((m, k), dtype=torch.int64, device=dev)
+    dsel = torch.empty((m, k), dtype=torch.float32, device=dev)
+    flags = torch.empty(m, dtype=torch.uint8, device=dev)
+    L.check(L.lib().creid_topk_rows(L.ptr(distmat), m, n, n, k, L.ptr(idx), L.ptr(dsel), L.ptr(flags), L.stream()),
+            "creid_topk_rows")
+    bad = torch.nonzero(flags).flatten()
+    if bad.numel():                                         # rows with massive ties at the k-th distance
+        sub = distmat.index_select(0, bad).contiguous()
+        ridx = rank_rows(sub)[:, :k].contiguous()
+        idx.index_copy_(0, bad, ridx)
+        dsel.index_copy_(0, bad, torch.gather(sub, 1, ridx))
+    return idx, dsel
+
+
 def _dev_i64(a, device):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.int64).contiguous()

@@ -80,6 +80,14 @@ int creid_cmc_ap_ranked_camsets(const int64_t* idx, int64_t m, int64_t n, const 
                                 const int64_t* g_pids, const int64_t* q_camids, const int64_t* g_cam_masks,
                                 uint8_t* out_valid, double* out_ap, int32_t* out_first, void* stream);
 
+/* The k smallest (distance, index) pairs of every row of dist fp32 [m, ld >= n], ascending -- what
+ * inference/get_similar.py:114-119 keeps of its full argsort (`indices[:, :topk]`) -- without ranking the rest.
+ * k <= min(n, 1024).  out_idx int64 [m][k]; out_dist fp32 [m][k] (nullable) the corresponding distances; ties resolve by
+ * index like creid_rank_rows.  flags uint8 [m]: 1 = the row's candidate set did not fit (massive ties at the k-th
+ * distance): that row's outputs are unwritten, use creid_rank_rows for it. */
+int creid_topk_rows(const float* dist, int64_t m, int64_t n, int64_t ld, int32_t k, int64_t* out_idx,
+                    float* out_dist, uint8_t* flags, void* stream);
+
 /* utils/eval_reid.py:86-90: means over valid queries.  out_cmc float32[max_rank]
  * (= count(first<=r)/n_valid in float32), out_map float64[1], out_topk float64[5] for
  * k in {1,5,10,20,50}, out_nvalid int64[1]. */

@@ -176,3 +176,23 @@ def test_chunked_compute_equals_full(rm):
     assert abs(mAP - mAP2) < 1e-12
     np.testing.assert_allclose(cmc, cmc2, rtol=0, atol=1e-7)
     np.testing.assert_allclose(topk, topk2, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("m,n,k", [(7, 50, 1), (33, 1000, 15), (64, 17661, 100), (5, 4000, 1024), (3, 200000, 50)])
+def test_topk_rows_equals_rank_prefix(m, n, k):
+    """creid_topk_rows == the first k columns of the stable rank (ties by gallery index), distances included; rows made
+    of duplicated values (exact ties across the k-th position) and a constant row (candidate overflow -> flagged,
+    served by the rank kernel) included."""
+    from centroids_reid_amd import reid_metric as rm
+    rng = np.random.default_rng(m * 31 + n)
+    d = rng.standard_normal((m, n)).astype(np.float32) * 3
+    d[0] = np.round(d[0], 1)                                   # heavy ties, resolved by index
+    if m > 2:
+        d[1] = 0.25                                             # constant row
+        d[2, ::3] = -7.0
+    dt = torch.from_numpy(d).cuda()
+    idx, dsel = rm.topk_rows(dt, k)
+    ref = rm.rank_rows(dt)[:, :k]
+    assert torch.equal(idx, ref)
+    assert torch.equal(dsel, torch.gather(dt, 1, ref))
+    np.testing.assert_array_equal(idx.cpu().numpy(), np.argsort(d, axis=1, kind="stable")[:, :k])
