@@ -109,65 +109,18 @@ def hbm_stage_rates(time_kernel, B, H, W):
 
 def pmc_traffic(key):
     """Average HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, collected in their own runs); None if absent."""
+    (profiles/r02_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE -- FETCH_SIZE reads 0.5x on 16-byte streaming loads, see
+    the calibration block of that file -- collected in their own counter-only runs); None if absent."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            e = json.load(f)[key]
-        return (e["fetch_bytes"] + e["write_bytes"]) / e["launches"]
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def map_delta_bf16(n_id=96, n_query=2, n_gallery=6, H=256, W=128, noise=0.6, seed=0):
-    """BASELINE metric (iii) on synthetic data: mAP of the retrieval evaluation on embeddings of CLUSTERED synthetic
-    identities (image = smooth per-identity pattern + N(0, noise) pixels), once through the fp32 parity mode and once
-    through the bf16 throughput mode of the same randomly initialised ResNet50 (BatchNorm running statistics settled
-    by a few training-mode passes first, then eval-mode embedding + BNNeck like validation_step).  Random weights are
-    a random feature extractor: identities stay separable, camera / instance noise does the rest."""
-    from . import reid_metric as rm
-    torch.manual_seed(seed)                                    # the random initialisation is part of the recipe
-    gen = torch.Generator(device="cuda").manual_seed(seed)
-    per = n_query + n_gallery
-    base = torch.randn((n_id, 3, H // 16, W // 16), generator=gen, device="cuda")
-    base = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
-    x = base.repeat_interleave(per, 0) + noise * torch.randn((n_id * per, 3, H, W), generator=gen, device="cuda")
-    pid = np.repeat(np.arange(n_id), per)
-    slot = np.tile(np.arange(per), n_id)
-    q_rows = np.nonzero(slot < n_query)[0]; g_rows = np.nonzero(slot >= n_query)[0]
-    order = np.concatenate([q_rows, g_rows])
-    pids = pid[order]
-    cams = np.concatenate([np.zeros(len(q_rows), np.int64), np.ones(len(g_rows), np.int64)])   # datasets/bases.py:226-229
-    ref = make_model(dtype=torch.float32)
-    ref.train()
-    with torch.no_grad():
-        for s in range(0, min(len(x), 512), 64):                           # settle the running statistics ONCE (fp32)
-            _, f = ref.backbone(x[s:s + 64])
-            ref.bn(f)
-    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
-    del ref
-    embs = {}
-    for dt in (torch.float32, torch.bfloat16):
-        model = make_model(dtype=dt)
-        model.load_state_dict(sd)                                          # identical weights AND statistics
-        model.eval()
-        out = []
-        with torch.no_grad():
-            for s in range(0, len(x), 64):
-                _, f = model.backbone(x[s:s + 64])
-                out.append(model.bn(f).float())
-        embs[dt] = torch.cat(out)[torch.as_tensor(order, device="cuda")].contiguous()
-        del model
-    res = {}
-    for dt, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
-        cmc, mAP, _ = rm.R1_mAP(num_query=len(q_rows), streamed=True).compute(embs[dt], pids, cams)
-        res[name] = (mAP, float(cmc[0]))
-    a, b = embs[torch.float32], embs[torch.bfloat16]
-    cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
-    return {"mAP_f32": res["f32"][0], "mAP_bf16": res["bf16"][0], "mAP_bf16_minus_f32": res["bf16"][0] - res["f32"][0],
-            "rank1_f32": res["f32"][1], "rank1_bf16": res["bf16"][1], "min_cosine": float(cos.min().item()),
-            "images": int(len(x)), "identities": n_id, "noise": noise}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(root, "profiles", name)) as f:
+                e = json.load(f)[key]
+            return (e["fetch_bytes"] + e["write_bytes"]) / e["launches"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 class DDPStepper:
@@ -244,6 +197,8 @@ class DDPStepper:
 def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
     P, K, H, W = 16, 4, 256, 128
     arch = os.environ.get("CREID_BENCH_ARCH", "resnet50")      # resnet50_ibn_a: side measurement, not the headline config
+    if os.environ.get("CREID_BENCH_CONFIG3", "0") == "1":      # side line: the training half of BASELINE configs[3]
+        arch, P, H, W = "resnet50_ibn_a", 14, 320, 320         # (configs/320_resnet50_ibn_a.yml: 320 x 320, 14 x 4 images)
     f32 = os.environ.get("CREID_BENCH_DTYPE", "bf16") == "f32"   # side measurement: the exact-f32 parity mode
     model = make_model(arch=arch, dtype=torch.float32 if f32 else torch.bfloat16)
     if world > 1:
@@ -332,7 +287,8 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
         res["host_enqueue_ms_per_step"] = t_host / args.steps * 1e3
         res["hip_graph"] = bool(use_graph)
         ms = dt / args.steps * 1e3
-        tf_step = R50_FWD_BWD_GFLOP_PER_IMG * P * K / (ms * 1e-3) / 1e3
+        gflop_img = 76.0 if (H, W) == (320, 320) else R50_FWD_BWD_GFLOP_PER_IMG      # IBN-a 320x320 / R50 256x128
+        tf_step = gflop_img * P * K / (ms * 1e-3) / 1e3
         res["step_mfma_frac"] = tf_step / MFMA_BF16_TFLOPS     # all conv FLOPs / whole-step time (incl. HBM-bound BN etc.)
         tf, ig_ms, slow, fast = igemm_roofline(P * K, H, W, time_kernel)
         res["roofline"] = {"kernel": "igemm_bf16_{dma,ws}_kernel (conv fwd + dgrad, 104 launches/step, real layer mix)",
@@ -349,7 +305,8 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
             "ms_per_step": dt / args.steps * 1e3, "dtype": "f32" if f32 else "bf16",
             "config": {"workload": ("ResNet50" if arch == "resnet50" else arch) +
-                                   " 256x128 CTL training step: fwd+bwd, centroid-triplet + center + xent, "
-                                   "Adam + center SGD (BASELINE configs[1])",
+                                   f" {H}x{W} CTL training step: fwd+bwd, centroid-triplet + center + xent, "
+                                   "Adam + center SGD (BASELINE configs[1])" if (H, W) == (256, 128) else
+                                   f"{arch} {H}x{W} CTL training step, P={P} x K={K} (training half of BASELINE configs[3], side line)",
                        "P": P, "K": K, "global_batch": P * K * world, "num_classes": 751,
                        "parallelism": f"dp{world}" if world > 1 else "single"}, **res}
