@@ -29,19 +29,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int l31 = lane & 31, kh = lane >> 5;
-  for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+  // register prefetch: the loads of k-tile t+1 fly while tile t is multiplied (these GEMMs are pure latency: a few
+  // k-tiles per workgroup, every one of which used to expose a full global-load round trip)
+  float ra[4], rb[4];
+  auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + 256 * i;
       int kk, rr;
       if (a_kfast) { kk = e & 15; rr = e >> 4; } else { rr = e & 63; kk = e >> 6; }
       const int gr = row0 + rr, gk = k0 + kk;
-      As[kk][rr] = (gr < M && gk < kend) ? A[(int64_t)gr * sam + (int64_t)gk * sak] : 0.f;
+      ra[i] = (gr < M && gk < kend) ? A[(int64_t)gr * sam + (int64_t)gk * sak] : 0.f;
       if (b_kfast) { kk = e & 15; rr = e >> 4; } else { rr = e & 63; kk = e >> 6; }
       const int gc = col0 + rr, gk2 = k0 + kk;
-      Bs[kk][rr] = (gc < N && gk2 < kend) ? B[(int64_t)gk2 * sbk + (int64_t)gc * sbn] : 0.f;
+      rb[i] = (gc < N && gk2 < kend) ? B[(int64_t)gk2 * sbk + (int64_t)gc * sbn] : 0.f;
     }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int kk, rr;
+      if (a_kfast) { kk = e & 15; rr = e >> 4; } else { rr = e & 63; kk = e >> 6; }
+      As[kk][rr] = ra[i];
+      if (b_kfast) { kk = e & 15; rr = e >> 4; } else { rr = e & 63; kk = e >> 6; }
+      Bs[kk][rr] = rb[i];
+    }
+  };
+  if (kbeg < kend) gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+    lstore();
     __syncthreads();
+    if (k0 + GBK < kend) gload(k0 + GBK);
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 2) {
       const float a = As[kk + kh][wm * 32 + l31];

@@ -214,12 +214,12 @@ class CTLModel(ModelBase):
                                    L.ptr(si), st), "creid_bn1d_fwd")
         C_cls = W.shape[0]
         det = ops._DETERMINISTIC
-        logits = ops.gemm_f32(bnf, D, 1, W, 1, D, B, C_cls, D, split_k=1 if det else 8)
+        logits = ops.gemm_f32(bnf, D, 1, W, 1, D, B, C_cls, D, split_k=1 if det else 32)          # 64-deep K slices
         row_x, dlogits = torch.empty(B, **f32), torch.empty((B, C_cls), **f32)
         L.check(lib.creid_xent_ls(L.ptr(logits), L.ptr(labels), B, C_cls, float(self.xent.epsilon),
                                   float(hp.SOLVER.QUERY_XENT_WEIGHT), L.ptr(row_x), L.ptr(lx), L.ptr(dlogits), st),
                 "creid_xent_ls")
-        dbnf = ops.gemm_f32(dlogits, C_cls, 1, W, D, 1, B, D, C_cls, split_k=1 if det else 4)       # dlogits @ W
+        dbnf = ops.gemm_f32(dlogits, C_cls, 1, W, D, 1, B, D, C_cls, split_k=1 if det else 12)      # dlogits @ W
         if W.requires_grad:
             ops.gemm_f32(dlogits, 1, C_cls, bnf, D, 1, C_cls, D, B, out=grad_of(W), beta=1.0)     # += dlogits^T @ bnf
         L.check(lib.creid_bn1d_bwd(L.ptr(feat), L.ptr(dbnf), B, D, L.ptr(bn.weight), L.ptr(sm), L.ptr(si), L.ptr(dfeat),
