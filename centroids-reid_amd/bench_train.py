@@ -123,6 +123,56 @@ def pmc_traffic(key):
     return None
 
 
+def map_delta_bf16(n_id=96, n_query=2, n_gallery=6, H=256, W=128, noise=0.6, seed=0):
+    """BASELINE metric (iii) on synthetic data: mAP of the retrieval evaluation on embeddings of CLUSTERED synthetic
+    identities (image = smooth per-identity pattern + N(0, noise) pixels), once through the fp32 parity mode and once
+    through the bf16 throughput mode of the same randomly initialised ResNet50 (BatchNorm running statistics settled
+    by a few training-mode passes first, then eval-mode embedding + BNNeck like validation_step).  Random weights are
+    a random feature extractor: identities stay separable, camera / instance noise does the rest."""
+    from . import reid_metric as rm
+    torch.manual_seed(seed)                                    # the random initialisation is part of the recipe
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    per = n_query + n_gallery
+    base = torch.randn((n_id, 3, H // 16, W // 16), generator=gen, device="cuda")
+    base = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
+    x = base.repeat_interleave(per, 0) + noise * torch.randn((n_id * per, 3, H, W), generator=gen, device="cuda")
+    pid = np.repeat(np.arange(n_id), per)
+    slot = np.tile(np.arange(per), n_id)
+    q_rows = np.nonzero(slot < n_query)[0]; g_rows = np.nonzero(slot >= n_query)[0]
+    order = np.concatenate([q_rows, g_rows])
+    pids = pid[order]
+    cams = np.concatenate([np.zeros(len(q_rows), np.int64), np.ones(len(g_rows), np.int64)])   # datasets/bases.py:226-229
+    ref = make_model(dtype=torch.float32)
+    ref.train()
+    with torch.no_grad():
+        for s in range(0, min(len(x), 512), 64):                           # settle the running statistics ONCE (fp32)
+            _, f = ref.backbone(x[s:s + 64])
+            ref.bn(f)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    del ref
+    embs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = make_model(dtype=dt)
+        model.load_state_dict(sd)                                          # identical weights AND statistics
+        model.eval()
+        out = []
+        with torch.no_grad():
+            for s in range(0, len(x), 64):
+                _, f = model.backbone(x[s:s + 64])
+                out.append(model.bn(f).float())
+        embs[dt] = torch.cat(out)[torch.as_tensor(order, device="cuda")].contiguous()
+        del model
+    res = {}
+    for dt, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        cmc, mAP, _ = rm.R1_mAP(num_query=len(q_rows), streamed=True).compute(embs[dt], pids, cams)
+        res[name] = (mAP, float(cmc[0]))
+    a, b = embs[torch.float32], embs[torch.bfloat16]
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
+    return {"mAP_f32": res["f32"][0], "mAP_bf16": res["bf16"][0], "mAP_bf16_minus_f32": res["bf16"][0] - res["f32"][0],
+            "rank1_f32": res["f32"][1], "rank1_bf16": res["bf16"][1], "min_cosine": float(cos.min().item()),
+            "images": int(len(x)), "identities": n_id, "noise": noise}
+
+
 class DDPStepper:
     """Data-parallel training step with the gradient all-reduce OVERLAPPED with backward and no eager kernels between
     the captured pieces: the step is captured as hipGraph segments split where a gradient bucket becomes final

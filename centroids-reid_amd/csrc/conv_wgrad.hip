@@ -639,9 +639,9 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   // reduce).  Measured (r01): shrinking the tile to cut that traffic LOSES (6147 vs 6370 img/s) -- the larger
   // tile's MFMA/LDS efficiency matters more and the partials mostly stay in the 256 MB Infinity Cache -- so the
   // largest tile wins by default; CREID_WGRAD_MAX_SPLITS re-enables the size/split trade-off for experiments.
-  // Split target: ~384 workgroups per launch (r01 sweep 256 / 320 / 384 / 448 / 512 / 768 / 1024 -> 384-448 best:
-  // 1.5 workgroups per CU keep the pixel loops long enough and the fp32 partial traffic low).
-  static const int target = [] { const char* e = getenv("CREID_WGRAD_TARGET_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
+  // Split target: ~512 workgroups per launch (r01 sweep with stand-alone reduce launches: 384-448 best; r02 with the
+  // reduction riding on the next launch: 256 / 384 / 512 / 768 -> 7.20 / 7.10 / 7.08 / 7.18 ms per step).
+  static const int target = [] { const char* e = getenv("CREID_WGRAD_TARGET_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   static const int max_splits_pref = [] { const char* e = getenv("CREID_WGRAD_MAX_SPLITS"); int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 30); }();
   const int ks = (dtype == CREID_BF16) ? WKS : WKF;
   const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
