@@ -40,6 +40,46 @@ def _to_attr(d):
     return d
 
 
+def _plain_dict(d):
+    """dict subclasses (AttributeDict / CfgNode stand-ins) -> plain nested dicts."""
+    if isinstance(d, dict):
+        return {k: _plain_dict(v) for k, v in d.items()}
+    return d
+
+
+def load_checkpoint_file(path, map_location="cpu"):
+    """torch.load for the reference's pytorch-lightning 1.1.4 checkpoints (utils/misc.py:80-93): the pickled
+    `hyper_parameters` reference `pytorch_lightning.utilities.parsing.AttributeDict` and `yacs.config.CfgNode`
+    (plain dict subclasses).  When those packages are absent, stand-in dict subclasses are registered under the
+    pickled module paths for the duration of the load, so the file opens without either dependency."""
+    import importlib
+    import sys
+    import types
+    wanted = {"pytorch_lightning.utilities.parsing": ("AttributeDict",), "pytorch_lightning.utilities": ("AttributeDict",),
+              "yacs.config": ("CfgNode",)}
+    added = []
+    for mod_name, classes in wanted.items():
+        try:
+            importlib.import_module(mod_name)
+            continue
+        except Exception:  # noqa: BLE001
+            pass
+        parts = mod_name.split(".")
+        for i in range(1, len(parts) + 1):
+            name = ".".join(parts[:i])
+            if name not in sys.modules:
+                sys.modules[name] = types.ModuleType(name)
+                added.append(name)
+        for c in classes:
+            if not hasattr(sys.modules[mod_name], c):
+                setattr(sys.modules[mod_name], c, type(c, (AttributeDict,), {"__module__": mod_name}))
+    try:
+        return torch.load(path, map_location=map_location, weights_only=False)
+    finally:
+        for name in added:
+            sys.modules.pop(name, None)
+
+
 class ModelBase(_Base):
     def __init__(self, cfg=None, test_dataloader=None, compute_dtype=None, **kwargs):
         super().__init__()
@@ -141,9 +181,11 @@ class ModelBase(_Base):
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location="cpu", strict=True, **overrides):
         """pl.LightningModule.load_from_checkpoint as the reference uses it (utils/misc.py:128-147,
-        inference/get_similar.py:84): rebuild the module from `hyper_parameters`, then load `state_dict`."""
-        ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
-        hp = _to_attr({**ckpt["hyper_parameters"], **overrides})
+        inference/get_similar.py:84): rebuild the module from `hyper_parameters`, then load `state_dict`.
+        Checkpoints written by the reference pickle `hyper_parameters` as pytorch-lightning `AttributeDict` /
+        yacs `CfgNode` objects; neither package needs to be installed to read them (see load_checkpoint_file)."""
+        ckpt = load_checkpoint_file(checkpoint_path, map_location)
+        hp = _to_attr({**_plain_dict(ckpt["hyper_parameters"]), **overrides})
         hp["MODEL"]["PRETRAINED"] = False            # weights come from the checkpoint, not from ImageNet
         model = cls(cfg=None, **hp)
         model.load_state_dict(ckpt["state_dict"], strict=strict)

@@ -334,16 +334,18 @@ class R1_mAP:
         return cmc.cpu().numpy(), float(mAP.item()), topk.cpu().numpy()
 
     def compute_chunked(self, feats, pids, camids, query_chunk=4096):
-        """Same result as compute() for galleries whose m x n matrix should not be materialised at once
-        (the reference's `_commpute_batches_double` path, utils/reid_metric.py:93-110,126-129, chunks the
-        gallery on the host instead): query rows are processed `query_chunk` at a time -- distance tile,
-        rank, CMC/AP scan all on the device -- and only per-query (valid, AP, first) results are kept."""
+        """Galleries whose m x n matrix must not be materialised (the reference's `_commpute_batches_double` path,
+        utils/reid_metric.py:93-110,126-129, chunks the gallery on the host): fp32 features go through the streamed
+        kernels in ONE pass with no matrix at all; other compute dtypes process `query_chunk` query rows at a time
+        (distance tile, rank, CMC/AP scan on the device, only per-query results kept)."""
         if not isinstance(feats, torch.Tensor) or not feats.is_cuda:
             raise L.CreidError("R1_mAP.compute_chunked needs device features (no CPU fallback)")
         from .parallel import merge_eval_results
         if self.dist_name != "euclidean":
             raise L.CreidError("compute_chunked streams the squared-L2 kernel only; use compute() for "
                                f"SOLVER.DISTANCE_FUNC={self.dist_name!r}")
+        if self.compute_dtype == torch.float32:
+            return self._compute_streamed(feats.float().contiguous(), pids, camids)
         feats = feats.float().contiguous()
         nq = self.num_query
         if self.feat_norm:

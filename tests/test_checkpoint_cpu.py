@@ -70,3 +70,85 @@ def test_optimizer_step_hook_warms_up_lr():
     o = Rec()
     model.optimizer_step(epoch=10, batch_idx=0, optimizer=o, optimizer_idx=0)
     assert o.calls == ["step"] and o.param_groups[0]["lr"] == 123.0          # past the warm-up: untouched
+
+
+def test_load_checkpoint_with_pickled_pl_and_yacs_classes(tmp_path):
+    """A checkpoint as the reference writes it: hyper_parameters pickled as pytorch-lightning AttributeDict holding
+    yacs CfgNode sub-trees.  Neither package is installed here; load_from_checkpoint must still open it."""
+    import importlib
+    import sys
+    import types
+    import torch
+    from centroids_reid_amd.config import get_cfg_defaults
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    for m in ("pytorch_lightning", "yacs"):
+        try:
+            importlib.import_module(m)
+            import pytest
+            pytest.skip(f"{m} is installed: the stand-in path is not exercised")
+        except ImportError:
+            pass
+    cfg = get_cfg_defaults()
+    cfg.MODEL.PRETRAINED = False
+    model = CTLModel(cfg, num_classes=7, num_query=3)
+    ck = model.checkpoint_dict(epoch=4, global_step=99)
+    # re-wrap the hyper parameters in classes that live under the reference's module paths (as PL / yacs pickle them)
+    mods = {}
+    for name in ("pytorch_lightning", "pytorch_lightning.utilities", "pytorch_lightning.utilities.parsing", "yacs", "yacs.config"):
+        mods[name] = types.ModuleType(name)
+    AD = type("AttributeDict", (dict,), {"__module__": "pytorch_lightning.utilities.parsing"})
+    CN = type("CfgNode", (dict,), {"__module__": "yacs.config"})
+    mods["pytorch_lightning.utilities.parsing"].AttributeDict = AD
+    mods["yacs.config"].CfgNode = CN
+    hp = AD({k: (CN(v) if isinstance(v, dict) else v) for k, v in ck["hyper_parameters"].items()})
+    ck["hyper_parameters"] = hp
+    path = tmp_path / "ref_style.ckpt"
+    sys.modules.update(mods)
+    try:
+        torch.save(ck, path)
+    finally:
+        for name in mods:
+            sys.modules.pop(name, None)
+    assert "yacs" not in sys.modules and "pytorch_lightning" not in sys.modules
+    m2 = CTLModel.load_from_checkpoint(str(path))
+    assert "yacs" not in sys.modules and "pytorch_lightning" not in sys.modules          # stand-ins removed again
+    assert m2.hparams.num_classes == 7 and m2.hparams.num_query == 3 and m2.hparams.SOLVER.MARGIN == cfg.SOLVER.MARGIN
+    sd1, sd2 = model.state_dict(), m2.state_dict()
+    assert sd1.keys() == sd2.keys()
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+
+
+def test_backbone_load_param_prefix_rules(tmp_path):
+    """ResNet.load_param / ResNet_IBN.load_param (resnet.py:135-154, resnet_ibn_a.py:143-162): 'backbone.base.' and
+    'base.' prefixes are stripped, fc / classifier / bottleneck entries skipped, a wrapping {'state_dict': ...} opened."""
+    import torch
+    from centroids_reid_amd import backbone as bb
+    src = bb.ResNet(last_stride=1)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.normal_()
+    sd = src.state_dict()
+    for prefix, wrap in (("backbone.base.", True), ("base.", False), ("", False)):
+        d = {prefix + k: v.clone() for k, v in sd.items()}
+        d[prefix + "fc.weight"] = torch.zeros(3)                 # must be ignored
+        d["classifier.weight"] = torch.zeros(2)
+        path = tmp_path / f"w_{len(prefix)}.pth"
+        torch.save({"state_dict": d} if wrap else d, path)
+        dst = bb.ResNet(last_stride=1)
+        dst.load_param(str(path))
+        for k, v in dst.state_dict().items():
+            assert torch.equal(v, sd[k]), (prefix, k)
+    isrc = bb.resnet50_ibn_a(1)
+    isd = {("base." + k): v.clone() for k, v in isrc.state_dict().items()}
+    isd["classifier.weight"] = torch.zeros(2)
+    ipath = tmp_path / "ibn.pth"
+    torch.save(isd, ipath)
+    idst = bb.resnet50_ibn_a(1)
+    with torch.no_grad():
+        for p in idst.parameters():
+            p.add_(1.0)
+    idst.load_param(str(ipath))
+    for k, v in idst.state_dict().items():
+        if not k.startswith("fc."):
+            assert torch.equal(v, isrc.state_dict()[k]), k
