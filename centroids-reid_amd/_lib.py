@@ -35,6 +35,8 @@ SIGNATURES = {
     "creid_stream_poslist": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "creid_stream_count": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "creid_stream_finalize": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "creid_tune_set": (C.c_int, [_i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32]),
+    "creid_tune_clear": (C.c_int, []),
     "creid_loo_centroids_fwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "creid_loo_centroids_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "creid_triplet_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -120,7 +122,27 @@ def lib():
         if h.creid_abi_version() != 1:
             raise CreidError("libcreid_hip.so ABI version mismatch")
         _lib = h
+        load_tuned_plans()
     return _lib
+
+
+PLANS_PATH = os.path.join(_HERE, "tuned_plans.json")
+
+
+def load_tuned_plans(path=None):
+    """Register the measured per-shape launch plans (tools/tune_plans.py) with the library; CREID_TUNED_PLANS=0 skips
+    them (built-in rules everywhere).  Returns the number of plans registered."""
+    import json
+    if os.environ.get("CREID_TUNED_PLANS", "1") == "0":
+        return 0
+    path = path or PLANS_PATH
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        plans = json.load(f).get("plans", [])
+    for e in plans:
+        _lib.creid_tune_set(int(e["kind"]), *[int(v) for v in e["key"]], *[int(v) for v in e["plan"]])
+    return len(plans)
 
 
 def dtype_code(t: torch.Tensor) -> int:

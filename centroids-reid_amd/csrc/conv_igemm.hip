@@ -16,6 +16,7 @@
 // accumulators for the training-mode BatchNorm that follows every convolution.
 #include "conv_common.hpp"
 #include "wgrad_reduce.hpp"
+#include "tune.hpp"
 #include <stdlib.h>
 
 // defined in conv_wgrad.hip
@@ -1042,6 +1043,13 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   int bn = 128;
   static const int min_wgs = [] { const char* e = getenv("CREID_IGEMM_BN128_MIN_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
   if (g.N % 128 != 0 || (int64_t)tiles_m * (g.N / 128) < min_wgs) bn = 64;
+  // measured plan for this GEMM shape (tune.hpp): N tile and ring depth of the producer/consumer kernel
+  TunePlan tp;
+  int tuned_stages = 0;
+  if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, g.transposed, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
+      g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
+    bn = tp.p0; tuned_stages = tp.p1;
+  }
   if (g.N % bn != 0) return CREID_E_SHAPE;
   const int tiles_n = g.N / bn;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
@@ -1063,7 +1071,9 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
       if (parity_on && g.transposed && g.stride == 2 && g.kw == 3 && g.pad == 1 && (g.K >> g.log2span) == 9 &&
           g.OH % 2 == 0 && g.OW % 2 == 0 && (g.M / 4) % 128 == 0 && !g.add_compact && bnred.tiles_per_image == 0)
         gp.parity = 1;
-      const int ws_stages = use_ws == 2 ? ws_stages_env() : ((bn == 64 && g.K >= ws_min_k) ? 3 : 2);
+      int ws_stages = use_ws == 2 ? ws_stages_env() : ((bn == 64 && g.K >= ws_min_k) ? 3 : 2);
+      if (tuned_stages && use_ws != 2) ws_stages = tuned_stages;
+      if (ws_stages == 4 && bn == 128) ws_stages = 3;               // 4 x 32 KB does not leave room for the C staging
       const dim3 block_ws(512);
       const dim3 grid_ws((unsigned)(tiles_m * tiles_n + (wred.ws ? wred.nblocks : 0)));
 #define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \

@@ -15,6 +15,7 @@
 // wgrad_reduce_kernel<SL> sums them in a fixed order (deterministic) and scatters into the OIHW fp32 gradient.
 #include "conv_common.hpp"
 #include "wgrad_reduce.hpp"
+#include "tune.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -646,6 +647,22 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   const int ks = (dtype == CREID_BF16) ? WKS : WKF;
   const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   WgradPlan p;
+  TunePlan tp;
+  if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_WGRAD, M, NCO, K, 0, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
+      (tp.p1 == 64 || tp.p1 == 128) && NCO % tp.p0 == 0 && K % tp.p1 == 0 && tp.p2 >= 1) {
+    // measured plan for this shape: tile tp.p0 x tp.p1, tp.p2 pixel splits
+    p.tm = tp.p0; p.tn = tp.p1;
+    p.tiles_k = K / p.tn;
+    p.tiles = (NCO / p.tm) * p.tiles_k;
+    int splits = tp.p2;
+    const int max_splits = (M + ks - 1) / ks;
+    if (splits > max_splits) splits = max_splits;
+    p.m_per_split = ((M + splits - 1) / splits + ks - 1) / ks * ks;
+    p.splits = (M + p.m_per_split - 1) / p.m_per_split;
+    static const int xcd_mode = [] { const char* e = getenv("CREID_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    p.xcd = (xcd_mode && p.splits >= 8) ? 1 : 0;
+    return p;
+  }
   for (int ci = 0; ci < 3; ++ci) {
     int tm = cand[ci][0], tn = cand[ci][1];
     if (NCO % tm != 0) tm = 64;

@@ -120,6 +120,14 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
 int creid_stream_finalize(const int32_t* npos, const uint32_t* hist, int64_t m, int32_t cap, uint8_t* valid,
                           double* ap, int32_t* first, void* stream);
 
+/* Measured launch plans (optional).  kind 0 = weight gradient: key (M = batch*out_h*out_w, out_c, K = kh*kw*in_c, 0) ->
+ * (tile rows 64|128, tile cols 64|128, pixel splits); kind 1 = implicit-GEMM forward / data gradient: key (GEMM rows M,
+ * GEMM cols N, K, transposed 0|1) -> (N tile 64|128, LDS ring depth 2|3|4, 0).  A plan only selects among kernel variants
+ * the library already has; shapes without an entry use the built-in rules.  Not thread-safe against running launches:
+ * register before the first convolution (the Python binding does it at load time from tuned_plans.json). */
+int creid_tune_set(int32_t kind, int64_t a, int64_t b, int64_t c, int64_t d, int32_t p0, int32_t p1, int32_t p2);
+int creid_tune_clear(void);
+
 /* ------------------------------------------------------------------ stage B: centroids */
 
 /* train_ctl_model.py:79-104: leave-one-out per-PID centroids of a PID-contiguous [P,K] batch.

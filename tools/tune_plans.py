@@ -1,0 +1,113 @@
+"""Measure per-shape launch plans on the GPU box and write centroids-reid_amd/tuned_plans.json.
+
+    python tools/tune_plans.py [--batch 64 --h 256 --w 128]
+
+For every distinct convolution of the ResNet50 layer mix at the benchmark size: the weight gradient is timed over
+(tile, split) candidates (partial tiles + 0.4 x the stand-alone reduce: the reduction rides in the next launch in the
+training schedule and costs ~40 % of its stand-alone time there), the forward / data gradient over (N tile, ring
+depth) candidates.  A plan is recorded only when it beats the built-in rule by > 3 % (min of repeated measurements)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["CREID_TUNED_PLANS"] = "0"                       # measure against the built-in rules
+from bench import time_kernel                                # noqa: E402
+from centroids_reid_amd import _lib as L, layers as ly       # noqa: E402
+from centroids_reid_amd.bench_train import conv_shapes       # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64); ap.add_argument("--h", type=int, default=256); ap.add_argument("--w", type=int, default=128)
+ap.add_argument("--out", default=os.path.join(ROOT, "centroids-reid_amd", "tuned_plans.json"))
+ap.add_argument("--merge", default=None, help="existing plan file whose entries (other shapes) are kept")
+args = ap.parse_args()
+lib = L.lib()
+B = args.batch
+SPLITS = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 40, 48, 64, 96, 128, 192, 256, 384]
+
+
+def t_us(fn, reps=2, iters=10):
+    return min(time_kernel(fn, iters) for _ in range(reps)) * 1e3
+
+
+plans, log = [], []
+seen = {}
+for cin, cout, k, s, h, w in conv_shapes(B, args.h, args.w):
+    key = (cin, cout, k, s, h, w)
+    seen[key] = seen.get(key, 0) + 1
+for (cin, cout, k, s, h, w), cnt in seen.items():
+    pad = k // 2
+    x = torch.randn((B, h, w, cin), device="cuda").to(torch.bfloat16)
+    wt = torch.randn((cout, cin, k, k), device="cuda") / (cin * k * k) ** 0.5
+    krsc, crsk = ly.weight_prep(wt, torch.bfloat16)
+    y = ly.conv2d_fwd(x, krsc, s, pad)
+    oh, ow = y.shape[1], y.shape[2]
+    d, _, _ = ly.conv_desc(B, h, w, cin, cout, k, s, pad)
+    M, K = B * oh * ow, k * k * cin
+    dw = torch.zeros((cout, cin, k, k), device="cuda")
+    name = f"{cin}->{cout} k{k} s{s} {h}x{w}"
+
+    # ---------------- weight gradient
+    def wgrad_score():
+        nbytes = lib.creid_conv2d_wgrad_workspace_bytes(C.byref(d), L.BF16)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+        tp = t_us(lambda: L.check(lib.creid_conv2d_wgrad_partials(C.byref(d), L.ptr(x), L.ptr(y), L.ptr(ws), nbytes, L.BF16, L.stream()), "p"))
+        tr = t_us(lambda: L.check(lib.creid_conv2d_wgrad_reduce(C.byref(d), L.ptr(dw), 0, L.ptr(ws), nbytes, L.BF16, L.stream()), "r"))
+        return tp + 0.4 * tr, tp, tr
+    lib.creid_tune_clear()
+    base, bp, br = wgrad_score()
+    best = (base, None)
+    for tm, tn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+        if cout % tm or K % tn or cin < tn:
+            continue
+        tiles = (cout // tm) * (K // tn)
+        for sp in SPLITS:
+            if not (160 <= tiles * sp <= 1600) or sp > M // 64:
+                continue
+            lib.creid_tune_set(0, M, cout, K, 0, tm, tn, sp)
+            sc, _, _ = wgrad_score()
+            if sc < best[0]:
+                best = (sc, (tm, tn, sp))
+    lib.creid_tune_clear()
+    if best[1] is not None and best[0] < 0.97 * base:
+        plans.append({"kind": 0, "key": [M, cout, K, 0], "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2), "layer": name})
+    log.append(f"wgrad {name:28s} x{cnt} rule {base:6.1f} (partials {bp:5.1f} + reduce {br:5.1f})  best {best[0]:6.1f} {best[1]}")
+
+    # ---------------- forward and data gradient
+    for tag, fn, key in (("fwd", lambda: ly.conv2d_fwd(x, krsc, s, pad, with_stats=True), (M, cout, K, 0)),
+                         ("dgrad", lambda: ly.conv2d_dgrad(y, crsk, (h, w), s, pad), (B * h * w, cin, k * k * cout, 1))):
+        lib.creid_tune_clear()
+        base = t_us(fn)
+        best = (base, None)
+        for bn in (64, 128):
+            if key[1] % bn:
+                continue
+            for st in (2, 3, 4):
+                if bn == 128 and st == 4:
+                    continue
+                lib.creid_tune_set(1, *key, bn, st, 0)
+                sc = t_us(fn)
+                if sc < best[0]:
+                    best = (sc, (bn, st, 0))
+        lib.creid_tune_clear()
+        if best[1] is not None and best[0] < 0.97 * base:
+            plans.append({"kind": 1, "key": list(key), "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2), "layer": f"{tag} {name}"})
+        log.append(f"{tag:5s} {name:28s} x{cnt} rule {base:6.1f}  best {best[0]:6.1f} {best[1]}")
+    print(log[-3]); print(log[-2]); print(log[-1], flush=True)
+
+if args.merge and os.path.exists(args.merge):
+    old = json.load(open(args.merge)).get("plans", [])
+    have = {(e["kind"], tuple(e["key"])) for e in plans}
+    plans = [e for e in old if (e["kind"], tuple(e["key"])) not in have] + plans
+out = {"_comment": "measured launch plans (tools/tune_plans.py) for the ResNet50 layer mix on one MI355X (B=64 256x128 = BASELINE "
+                   "configs[1]; B=56 320x320 = configs[3]); kind 0 = weight gradient (M, out_c, K) -> (tile rows, tile cols, splits), "
+                   "kind 1 = forward / data gradient (M, N, K, transposed) -> (N tile, ring depth).  Shapes without an entry use the "
+                   "built-in rules.",
+       "device": torch.cuda.get_device_name(0), "plans": plans}
+json.dump(out, open(args.out, "w"), indent=1)
+print(f"{len(plans)} plans written to {args.out}")
