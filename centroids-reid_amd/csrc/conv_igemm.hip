@@ -1045,10 +1045,10 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   if (g.N % 128 != 0 || (int64_t)tiles_m * (g.N / 128) < min_wgs) bn = 64;
   // measured plan for this GEMM shape (tune.hpp): N tile and ring depth of the producer/consumer kernel
   TunePlan tp;
-  int tuned_stages = 0;
+  int tuned_stages = 0, tuned_dma = 0;
   if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, g.transposed, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
-    bn = tp.p0; tuned_stages = tp.p1;
+    bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1;
   }
   if (g.N % bn != 0) return CREID_E_SHAPE;
   const int tiles_n = g.N / bn;
@@ -1064,7 +1064,7 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
     // 3-deep ring, +2.4 % more from 2-deep rings -- two workgroups per CU -- on all other tiles; standalone sweeps in
     // profiles/r01_igemm_ws_sweep.md).  CREID_IGEMM_WS=0: the 4-wave DMA kernel; =2: force CREID_IGEMM_WS_STAGES.
     static const int ws_min_k = [] { const char* e = getenv("CREID_IGEMM_WS_MIN_K"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-    if (g.log2span >= 6 && use_ws >= 1) {
+    if (g.log2span >= 6 && use_ws >= 1 && !(tuned_dma && !wred.ws && !bnred.x)) {
       // stride-2 3x3 data gradients: parity-class row order, 9 tap-tiles per 4 output pixels instead of 36
       static const int parity_on = [] { const char* e = getenv("CREID_DGRAD_PARITY"); return e ? atoi(e) : 1; }();
       IGemmGeom gp = g;
@@ -1088,7 +1088,8 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
     if (wred.ws) { const int rc = wgrad_reduce_job_launch(wred, s); if (rc) return rc; wred.ws = nullptr; }
     // LDS ring depth (CREID_IGEMM_STAGES = 2..5, default 2 -- measured r01: deeper rings LOSE, the k-loop is bound
     // by the LDS->MFMA chain and by workgroups/CU, not by DMA latency; 3+ stages cost occupancy)
-    static const int stages = [] { const char* e = getenv("CREID_IGEMM_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 5) ? v : 2; }();
+    static const int stages_env = [] { const char* e = getenv("CREID_IGEMM_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 5) ? v : 2; }();
+    const int stages = (tuned_dma && tuned_stages) ? tuned_stages : stages_env;
 #define CREID_DMA_LAUNCH(BN_, NS_)                                                                                     \
   hipLaunchKernelGGL((igemm_bf16_dma_kernel<BN_, NS_>), grid, block, 0, s, g, (const unsigned short*)src,              \
                      (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n, \

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __r
 // ------------------------------------------------------------------------------------ host
 static int ilog2x(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return ((1LL << l) == v) ? l : -1; }
 
-struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split, xcd; };
+struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split, xcd, stages, ws; };   // stages / ws: 0 = default
 
 static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   // The fp32 partial tiles cost  workgroups x TM x TN x 8 bytes  of traffic per layer (write + re-read by the
@@ -647,11 +647,14 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   const int ks = (dtype == CREID_BF16) ? WKS : WKF;
   const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   WgradPlan p;
+  p.stages = 0; p.ws = 0;
   TunePlan tp;
   if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_WGRAD, M, NCO, K, 0, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       (tp.p1 == 64 || tp.p1 == 128) && NCO % tp.p0 == 0 && K % tp.p1 == 0 && tp.p2 >= 1) {
-    // measured plan for this shape: tile tp.p0 x tp.p1, tp.p2 pixel splits
+    // measured plan for this shape: tile tp.p0 x tp.p1, tp.p2 = pixel splits | ring depth << 16 | producer/consumer << 20
     p.tm = tp.p0; p.tn = tp.p1;
+    p.stages = (tp.p2 >> 16) & 15; p.ws = (tp.p2 >> 20) & 1;
+    tp.p2 &= 0xffff;
     p.tiles_k = K / p.tn;
     p.tiles = (NCO / p.tm) * p.tiles_k;
     int splits = tp.p2;
@@ -700,11 +703,13 @@ static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
   const dim3 grid_x(p.splits >= 8 ? (unsigned)(p.tiles * ((p.splits + 7) / 8) * 8) : (unsigned)(8 * ((p.tiles + share - 1) / share)));
   const dim3 grid_dma = xcd_on ? grid_x : grid;
   static const int use_dma = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
-  static const int stages = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
+  static const int stages_env = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
   static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
   const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0 && stem_dma;
   if (dtype == CREID_BF16 && use_dma && ((1 << g.log2span) >= TN || stem_geom)) {
-    static const int use_ws = [] { const char* e = getenv("CREID_WGRAD_WS"); return e ? atoi(e) : 0; }();
+    static const int use_ws_env = [] { const char* e = getenv("CREID_WGRAD_WS"); return e ? atoi(e) : 0; }();
+    const int use_ws = p.ws ? 1 : use_ws_env;
+    const int stages = (p.stages >= 2 && p.stages <= 4) ? p.stages : stages_env;
     if (use_ws && !stem_geom)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, true>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
                          (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);

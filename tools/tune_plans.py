@@ -62,6 +62,7 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
     lib.creid_tune_clear()
     base, bp, br = wgrad_score()
     best = (base, None)
+    cands = []
     for tm, tn in ((128, 128), (128, 64), (64, 128), (64, 64)):
         if cout % tm or K % tn or cin < tn:
             continue
@@ -71,8 +72,18 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
                 continue
             lib.creid_tune_set(0, M, cout, K, 0, tm, tn, sp)
             sc, _, _ = wgrad_score()
+            cands.append((sc, (tm, tn, sp)))
             if sc < best[0]:
                 best = (sc, (tm, tn, sp))
+    # ring depth 3 / producer-consumer split on the three best (tile, split) choices (plan word: splits | depth<<16 | ws<<20)
+    for sc0, (tm, tn, sp) in sorted(cands)[:3]:
+        for extra in ((3 << 16), (1 << 20)):
+            if (extra >> 16) == 3 and 3 * (tm + tn) * 128 > 160 * 1024:
+                continue
+            lib.creid_tune_set(0, M, cout, K, 0, tm, tn, sp | extra)
+            sc, _, _ = wgrad_score()
+            if sc < best[0]:
+                best = (sc, (tm, tn, sp | extra))
     lib.creid_tune_clear()
     if best[1] is not None and best[0] < 0.97 * base:
         plans.append({"kind": 0, "key": [M, cout, K, 0], "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2), "layer": name})
@@ -94,6 +105,11 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
                 sc = t_us(fn)
                 if sc < best[0]:
                     best = (sc, (bn, st, 0))
+                if tag == "fwd" and st <= 3:               # the 4-wave kernel (all waves issue DMA and multiply): forward only
+                    lib.creid_tune_set(1, *key, bn, st, 1)
+                    sc = t_us(fn)
+                    if sc < best[0]:
+                        best = (sc, (bn, st, 1))
         lib.creid_tune_clear()
         if best[1] is not None and best[0] < 0.97 * base:
             plans.append({"kind": 1, "key": list(key), "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2), "layer": f"{tag} {name}"})
