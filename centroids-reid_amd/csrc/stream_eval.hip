@@ -83,16 +83,22 @@ __global__ __launch_bounds__(PL_MAXC) void stream_poslist_kernel(
     float acc = 0.f;
     int k = 0;
     const int kend = D & ~15;
-    float4 n0, n1, n2, n3;                                 // the next 64 bytes of the row fly while this block is chained
+    // two 64-byte blocks of the row are in flight while a third is chained (the loop is bound by the load round trip
+    // to the Infinity Cache, not by the 16 dependent FMAs of a block)
+    float4 n0, n1, n2, n3, m0, m1, m2, m3;
     if (kend > 0) {
       n0 = *reinterpret_cast<const float4*>(grow); n1 = *reinterpret_cast<const float4*>(grow + 4);
       n2 = *reinterpret_cast<const float4*>(grow + 8); n3 = *reinterpret_cast<const float4*>(grow + 12);
+      const int k1 = min(16, kend - 16);
+      m0 = *reinterpret_cast<const float4*>(grow + k1); m1 = *reinterpret_cast<const float4*>(grow + k1 + 4);
+      m2 = *reinterpret_cast<const float4*>(grow + k1 + 8); m3 = *reinterpret_cast<const float4*>(grow + k1 + 12);
     }
     for (; k < kend; k += 16) {                            // the MFMA's own k order: one sequential fmaf chain
       const float4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
-      const int kn = min(k + 16, kend - 16);
-      n0 = *reinterpret_cast<const float4*>(grow + kn); n1 = *reinterpret_cast<const float4*>(grow + kn + 4);
-      n2 = *reinterpret_cast<const float4*>(grow + kn + 8); n3 = *reinterpret_cast<const float4*>(grow + kn + 12);
+      n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+      const int kn = min(k + 32, kend - 16);
+      m0 = *reinterpret_cast<const float4*>(grow + kn); m1 = *reinterpret_cast<const float4*>(grow + kn + 4);
+      m2 = *reinterpret_cast<const float4*>(grow + kn + 8); m3 = *reinterpret_cast<const float4*>(grow + kn + 12);
       acc = fmaf(qrow[k + 0], v0.x, acc); acc = fmaf(qrow[k + 1], v0.y, acc); acc = fmaf(qrow[k + 2], v0.z, acc); acc = fmaf(qrow[k + 3], v0.w, acc);
       acc = fmaf(qrow[k + 4], v1.x, acc); acc = fmaf(qrow[k + 5], v1.y, acc); acc = fmaf(qrow[k + 6], v1.z, acc); acc = fmaf(qrow[k + 7], v1.w, acc);
       acc = fmaf(qrow[k + 8], v2.x, acc); acc = fmaf(qrow[k + 9], v2.y, acc); acc = fmaf(qrow[k + 10], v2.z, acc); acc = fmaf(qrow[k + 11], v2.w, acc);
