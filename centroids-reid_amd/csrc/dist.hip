@@ -19,16 +19,33 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
   if (row >= rows) return;
   const float4* xr = reinterpret_cast<const float4*>(x + row * D);
   const int nv = (int)(D >> 2);
+  // rows up to 4096 elements stay in registers between the norm and the scaling (ONE read of the input instead of
+  // two: the pass is HBM-bound); longer rows are streamed twice
+  constexpr int RV = 16;
+  const bool resident = nv <= 64 * RV;
+  float4 keep[RV];
   float s = 0.f;
-  for (int i = lane; i < nv; i += 64) {
-    float4 v = xr[i];
-    s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+  if (resident) {
+#pragma unroll
+    for (int t = 0; t < RV; ++t) {
+      const int i = lane + 64 * t;
+      keep[t] = i < nv ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int t = 0; t < RV; ++t) {          // same accumulation order as the streaming loop below
+      const float4 v = keep[t];
+      if (lane + 64 * t < nv) { s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s); }
+    }
+  } else {
+    for (int i = lane; i < nv; i += 64) {
+      float4 v = xr[i];
+      s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+    }
   }
   s = wave_sum(s);
   const float denom = fmaxf(sqrtf(s), eps);
   float s2 = 0.f;
-  for (int i = lane; i < nv; i += 64) {
-    float4 v = xr[i];
+  auto emit = [&](int i, float4 v) {
     v.x /= denom; v.y /= denom; v.z /= denom; v.w /= denom;
     if constexpr (OUT_DT == CREID_F32) {
       reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + row * D)[i] = v;
@@ -46,6 +63,13 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
       v.x = __half2float(h0); v.y = __half2float(h1); v.z = __half2float(h2); v.w = __half2float(h3);
     }
     s2 = fmaf(v.x, v.x, s2); s2 = fmaf(v.y, v.y, s2); s2 = fmaf(v.z, v.z, s2); s2 = fmaf(v.w, v.w, s2);
+  };
+  if (resident) {
+#pragma unroll
+    for (int t = 0; t < RV; ++t)
+      if (lane + 64 * t < nv) emit(lane + 64 * t, keep[t]);
+  } else {
+    for (int i = lane; i < nv; i += 64) emit(i, xr[i]);
   }
   if (sqn) {
     s2 = wave_sum(s2);
