@@ -114,6 +114,15 @@ def pmc_traffic(key):
     return None
 
 
+def pmc_field(key, field):
+    """A per-kernel field of the committed counter passes (profiles/r02_pmc_traffic.json), e.g. "mfma_busy"."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")) as f:
+            return json.load(f)[key][field]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def run_eval(args, rank, world, steps=None, warmup=None):
     """BASELINE configs[4]: normalise + squared-L2 + rank + CMC/mAP over 2228 x 17661 x 2048 fp32.  Timed twice:
     the METRIC-ONLY path the validation hook uses (streamed: the m x n matrix is never written; `value`) and the
@@ -202,7 +211,8 @@ def run_eval(args, rank, world, steps=None, warmup=None):
         res["roofline"] = {"kernel": "sqdist_count_f32_kernel (contraction + in-register rank-by-counting epilogue)",
                            "bound": "mfma", "achieved": flops / (t_count * 1e-3) / 1e12, "peak": MFMA_F32_TFLOPS,
                            "unit": "TFLOP/s", "frac": flops / (t_count * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
-                           "traffic": pmc_traffic("sqdist_count_f32_kernel"), "ms": t_count}
+                           "traffic": pmc_traffic("sqdist_count_f32_kernel"), "ms": t_count,
+                           "mfma_busy_by_counter": pmc_field("sqdist_count_f32_kernel", "mfma_busy")}
         res["materialised"] = {
             "value": float(nq) * ng * world * steps / dt_m, "unit": "pairs/s", "ms_per_step": dt_m / steps * 1e3,
             "roofline": {"kernel": "sqdist_f32_kernel", "bound": "mfma", "achieved": flops / (t_dist * 1e-3) / 1e12,

@@ -107,6 +107,16 @@ def hbm_stage_rates(time_kernel, B, H, W):
             "peak_GBs": 8000.0}
 
 
+def pmc_field(key, field):
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        with open(os.path.join(root, "profiles", "r02_pmc_traffic.json")) as f:
+            return json.load(f)[key][field]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def pmc_traffic(key):
     """Average HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc passes
     (profiles/r02_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE -- FETCH_SIZE reads 0.5x on 16-byte streaming loads, see
@@ -353,6 +363,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
         res["roofline"] = {"kernel": "igemm_bf16_{dma,ws}_kernel (conv fwd + dgrad, 104 launches/step, real layer mix)",
                            "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": tf / MFMA_BF16_TFLOPS, "traffic": pmc_traffic("igemm_family"),
+                           "mfma_busy_by_counter": pmc_field("igemm_family", "mfma_busy"),   # in-situ style: every launch, cold operands
                            "ms_per_step": ig_ms, "slowest_TFs": slow, "fastest_TFs": fast}
         res["roofline_hbm_stages"] = hbm_stage_rates(time_kernel, P * K, H, W)
         if cpu_baseline_fn is not None and world == 1:          # the CPU leg is reported at N=1 only

@@ -48,6 +48,10 @@ for key in ("sqdist_f32_kernel", "sqdist_count_f32_kernel", "rank_rows_lds_kerne
         e["algorithmic_bytes"] = meta[key]["algorithmic_bytes"]
         e["traffic_over_algorithmic"] = (2 * f + w) / meta[key]["algorithmic_bytes"]
     out[key] = e
+for key, prefix in (("igemm_family", "igemm_bf16_"), ("wgrad_family", "wgrad_bf16_"), ("sqdist_f32_kernel", "sqdist_f32_kernel"),
+                    ("sqdist_count_f32_kernel", "sqdist_count_f32_kernel")):
+    mf, _ = fam(S, prefix, "SQ_VALU_MFMA_BUSY_CYCLES"); ga, _ = fam(S, prefix, "GRBM_GUI_ACTIVE")
+    out[key]["mfma_busy"] = mf / (ga / 8 * NSIMD)          # matrix-pipe busy fraction by counter (all launches of the family)
 json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
 
 lines = ["# rocprofv3 --pmc passes, round 2 (tools/pmc_run.sh over tools/pmc_kernels.py, one MI355X)", "",
