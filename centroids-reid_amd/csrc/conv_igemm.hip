@@ -23,6 +23,8 @@
 bool wgrad_make_reduce_job(const creid_conv_desc* d, int dtype, const void* ws, size_t ws_bytes, float* dw, int accumulate,
                            WRedJob& j);
 int wgrad_reduce_job_launch(const WRedJob& j, hipStream_t s);
+// defined in conv_stream.hip
+int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, hipStream_t s);
 
 // Out-of-image taps read this 128-byte page of zeros instead of selecting zeros per dword (saves 3 VALU
 // per load in the gather path).
@@ -1045,10 +1047,22 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   if (g.N % 128 != 0 || (int64_t)tiles_m * (g.N / 128) < min_wgs) bn = 64;
   // measured plan for this GEMM shape (tune.hpp): N tile and ring depth of the producer/consumer kernel
   TunePlan tp;
-  int tuned_stages = 0, tuned_dma = 0;
+  int tuned_stages = 0, tuned_dma = 0, tuned_stream = 0;
   if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, g.transposed, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
-    bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1;
+    bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2;
+  }
+  // persistent streaming kernel for the small-K 1x1 stride-1 forward convolutions (conv_stream.hip): plan kind 2, or
+  // CREID_STREAM1X1=1 for every GEMM it covers
+  {
+    const char* fe = getenv("CREID_STREAM1X1");                    // read per call: tests toggle it
+    const int force_stream = fe ? atoi(fe) : 0;
+    const bool plain_1x1 = dtype == CREID_BF16 && !g.transposed && g.K == (1 << g.log2span) && g.stride == 1 && g.pad == 0 &&
+                           g.kw == 1 && g.check_bounds && !add_src && !bnred.x && !wred.ws && g.pitch == g.K;
+    if (plain_1x1 && (force_stream || tuned_stream)) {
+      const int rc = launch_stream1x1(g.M, g.K, g.N, src, wgt, out, bn_part, s);
+      if (rc != CREID_E_SHAPE) return rc;
+    }
   }
   if (g.N % bn != 0) return CREID_E_SHAPE;
   const int tiles_n = g.N / bn;

@@ -1,0 +1,235 @@
+// Stage A: PERSISTENT streaming kernel for the small-K 1x1 stride-1 convolutions of layer1 / layer2
+// (modelling/backbones/resnet.py:56,60 conv1 / conv3 of the Bottleneck, :109 the stride-1 downsample) and their data
+// gradients.  These GEMMs -- C[M, N] = A[M, K] . W[N, K]^T with K = 64..256, M = 32 768..131 072 rows at B = 64 -- are
+// HBM-streaming work (64 -> 256 moves 84 MB for 4.3 GFLOP), and the tile-per-workgroup kernels of conv_igemm.hip run
+// them at 2-3 TB/s: a workgroup lives for one 128-row tile, i.e. prologue -> DMA -> wait a full load round trip -> 16
+// MFMAs -> epilogue, with nothing to overlap the round trip except a second short-lived workgroup, and it re-fetches
+// the whole weight matrix (a third of its LDS fill traffic at K = 64) for every tile.  Here:
+//   * a workgroup is resident for the whole launch and walks a strided sequence of row tiles;
+//   * the weight slab W[BN x K] (<= 64 KB) is loaded into LDS ONCE per workgroup;
+//   * four producer waves stream the A tiles of FUTURE row tiles into an LDS ring with the global->LDS DMA while four
+//     consumer waves multiply the current one and write it out, so the load round trip is off the critical path.
+// Same LDS image as conv_igemm.hip (row-major [row][64] bf16, 16-B chunks XOR-swizzled by (row >> 1) & 7 on the DMA
+// source side), same 32x32x16 MFMA fragment map, same epilogue arithmetic (bf16 C tile staged through LDS for 16-B
+// stores, per-tile (sum, sum of squares) partials of the fp32 accumulators for the BatchNorm that follows).
+// Every wave executes the same sequence of s_barrier's by construction: one per k-chunk, then a fixed number per
+// epilogue; all loop bounds are workgroup-uniform.
+#include "conv_common.hpp"
+#include <stdlib.h>
+
+__device__ __attribute__((aligned(128))) unsigned g_stream_zero_page[32];   // rows >= M fetch this page of zeros
+
+namespace {
+template <int N> __device__ __forceinline__ void st_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void st_barrier() { asm volatile("s_barrier" ::: "memory"); }
+}  // namespace
+
+// BN: output columns per workgroup (64 / 128 / 256); KCH: K / 64 (1, 2, 4); NSA: A-ring depth in 16 KB chunks.
+template <int BN, int KCH, int NSA>
+__global__ __launch_bounds__(512, 1) void igemm1x1_stream_kernel(const unsigned short* __restrict__ src, int M, int K, int N,
+                                                                  const unsigned short* __restrict__ wgt,
+                                                                  unsigned short* __restrict__ out,
+                                                                  float* __restrict__ bn_part, int tiles_m, int tiles_n) {
+  constexpr int TNW = BN / 64;                         // 32-wide column blocks per consumer wave (x 2 row blocks)
+  constexpr int HB = BN > 128 ? 128 : BN;              // columns staged / copied out at a time
+  constexpr int NH = BN / HB;                          // halves per tile
+  constexpr int CP = HB + 8;                           // staging pitch (elements)
+  constexpr int W_ELEMS = KCH * BN * 64, RING_ELEMS = NSA * 128 * 64, STAGE_ELEMS = 128 * CP;
+  static_assert(2 * (W_ELEMS + RING_ELEMS + STAGE_ELEMS) <= 160 * 1024, "LDS budget");
+  static_assert(NSA >= 2 && (NSA - 1) * 4 <= 63, "ring depth");
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[W_ELEMS + RING_ELEMS + STAGE_ELEMS];
+  unsigned short* Ws = smem;                           // [KCH][BN][64]
+  unsigned short* ring = smem + W_ELEMS;               // [NSA][128][64]
+  unsigned short* stage = smem + W_ELEMS + RING_ELEMS; // [128][CP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int lr8 = lane >> 3, lcp = lane & 7;
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+
+  // this workgroup: a fixed column slab, row tiles tile_m0, tile_m0 + stride, ...
+  const int groups = (int)gridDim.x / tiles_n;         // workgroups per column slab (grid is a multiple of tiles_n)
+  const int tile_n = (int)blockIdx.x % tiles_n, wg_in_group = (int)blockIdx.x / tiles_n;
+  const int col0 = tile_n * BN;
+  const int n_iter = wg_in_group < tiles_m ? (tiles_m - 1 - wg_in_group) / groups + 1 : 0;
+  const int n_chunks = n_iter * KCH;
+
+  // ---- weight slab -> LDS, once (all 8 waves; KCH * BN / 8 wave-instructions of 8 rows x 128 B)
+  {
+    constexpr int NW = KCH * (BN / 8);
+    for (int i = wave; i < NW; i += 8) {
+      const int kc = i / (BN / 8), r = (i - kc * (BN / 8)) * 8 + lr8;
+      const unsigned short* p = wgt + (int64_t)(col0 + r) * K + kc * 64 + ((lcp ^ ((r >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Ws + (kc * BN + (i - kc * (BN / 8)) * 8) * 64), 16, 0, 0);
+    }
+  }
+
+  f32x16 acc[2][TNW];
+  if (producer) {
+    // chunk c = (iteration c / KCH, k-chunk c % KCH) -> ring slot c % NSA; 4 DMA instructions per wave per chunk
+    const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_stream_zero_page);
+    int gch[4], rloc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rloc[i] = (i * 4 + cw) * 8 + lr8;
+      gch[i] = (lcp ^ ((rloc[i] >> 1) & 7)) << 3;
+    }
+    auto issue = [&](int c) {
+      const int it = c / KCH, kc = c - it * KCH;
+      const int row0 = (wg_in_group + it * groups) * 128;
+      unsigned short* la = ring + (c % NSA) * (128 * 64) + cw * 512;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = row0 + rloc[i];
+        const unsigned short* p = m < M ? src + (int64_t)m * K + kc * 64 + gch[i] : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(la + i * 2048), 16, 0, 0);
+      }
+    };
+    int issued = 0;
+#pragma unroll
+    for (int p = 0; p < NSA - 1; ++p)
+      if (p < n_chunks) { issue(p); ++issued; }
+    int c = 0;
+    for (int it = 0; it < n_iter; ++it) {
+      for (int kc = 0; kc < KCH; ++kc, ++c) {
+        // chunk c (and the weight slab, issued before it) has landed once at most the younger chunks are pending
+        const int younger = issued - c - 1;
+        if (younger >= 2) st_wait_vm<8>(); else if (younger == 1) st_wait_vm<4>(); else st_wait_vm<0>();
+        st_barrier();                                              // B1(c)
+        if (issued < n_chunks && issued - c < NSA) { issue(issued); ++issued; }   // into the slot chunk c-1 just left
+      }
+      // epilogue barriers (the consumers' copy-out); producers only keep step
+#pragma unroll
+      for (int h = 0; h < NH; ++h) { st_barrier(); st_barrier(); }
+      if (bn_part) { st_barrier(); st_barrier(); }
+    }
+    return;
+  }
+
+  // ---- consumers
+  st_wait_vm<0>();                                                 // this wave's share of the weight slab
+  int c = 0;
+  for (int it = 0; it < n_iter; ++it) {
+    const int tile_m = wg_in_group + it * groups, row0 = tile_m * 128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kc = 0; kc < KCH; ++kc, ++c) {
+      st_barrier();                                                // B1(c): chunk c is in LDS
+      const unsigned short* As = ring + (c % NSA) * (128 * 64);
+      const unsigned short* Bs = Ws + kc * BN * 64;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int ch = 2 * kk + kh;
+        s16x8 a[2], b[TNW];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = wm * 64 + i * 32 + l31;
+          a[i] = *reinterpret_cast<const s16x8*>(&As[r * 64 + ((ch ^ ((r >> 1) & 7)) << 3)]);
+        }
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          const int cc = wn * (BN / 2) + j * 32 + l31;
+          b[j] = *reinterpret_cast<const s16x8*>(&Bs[cc * 64 + ((ch ^ ((cc >> 1) & 7)) << 3)]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TNW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                acc[i][j], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: column statistics from the fp32 accumulators, then the C tile through LDS in HB-wide halves
+    float s1v[TNW], s2v[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s1 += v; s2 = fmaf(v, v, s2); }   // rows >= M are zero
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      s1v[j] = s1; s2v[j] = s2;
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      // this wave's columns wn*(BN/2) + j*32 .. : half h holds columns [h*HB, (h+1)*HB)
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) {
+        const int cglob = wn * (BN / 2) + j * 32;                  // first column of the 32-wide block
+        if (cglob / HB != h) continue;                             // compile-time after unrolling
+        const int cl = cglob - h * HB + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            stage[rl * CP + cl] = f32_to_bf16_bits(acc[i][j][r]);
+          }
+      }
+      st_barrier();                                                // E1: the half is staged
+      constexpr int CPR = HB / 8;                                  // 16-B chunks per staged row
+#pragma unroll
+      for (int i = 0; i < (128 * CPR) / 256; ++i) {
+        const int id = tid + 256 * i, rl = id / CPR, ch = id - rl * CPR;
+        const int rr = row0 + rl;
+        if (rr < M) {
+          const uint4 v = *reinterpret_cast<const uint4*>(&stage[rl * CP + ch * 8]);
+          *reinterpret_cast<uint4*>(out + (int64_t)rr * N + col0 + h * HB + ch * 8) = v;
+        }
+      }
+      st_barrier();                                                // E2: the staging area is free again
+    }
+    if (bn_part) {
+      float* red = reinterpret_cast<float*>(stage);                // [2 (wm)][2 (s1, s2)][BN]
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) {
+        const int cl = wn * (BN / 2) + j * 32 + l31;
+        if (kh == 0) { red[(wm * 2 + 0) * BN + cl] = s1v[j]; red[(wm * 2 + 1) * BN + cl] = s2v[j]; }
+      }
+      st_barrier();
+      for (int i = tid; i < 2 * BN; i += 256) {
+        const int which = i / BN, cl = i - which * BN;
+        bn_part[((int64_t)tile_m * 2 + which) * N + col0 + cl] = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl];
+      }
+      st_barrier();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ host
+// Returns CREID_E_SHAPE when the GEMM is outside the kernel's scope (the caller then uses conv_igemm.hip's kernels).
+int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, hipStream_t s) {
+  if (K != 64 && K != 128 && K != 256) return CREID_E_SHAPE;
+  int bn = N >= 256 ? 256 : N;
+  if (bn != 64 && bn != 128 && bn != 256) return CREID_E_SHAPE;
+  if (N % bn != 0) return CREID_E_SHAPE;
+  if (K == 256 && bn == 256) bn = 128;                 // the weight slab must fit: BN * K <= 32 K elements
+  if ((int64_t)bn * K > 32768) return CREID_E_SHAPE;
+  const int tiles_m = (M + 127) / 128, tiles_n = N / bn;
+  // persistent grid: one workgroup per CU (the LDS budget allows one), split evenly over the column slabs
+  int wgs = 256;                                       // read per call (tests shrink it to force many tiles per workgroup)
+  { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }
+  int groups = wgs / tiles_n;
+  if (groups < 1) groups = 1;
+  if (groups > tiles_m) groups = tiles_m;
+  const dim3 grid((unsigned)(groups * tiles_n)), block(512);
+#define CREID_ST_LAUNCH(BN_, KCH_, NSA_)                                                                              \
+  hipLaunchKernelGGL((igemm1x1_stream_kernel<BN_, KCH_, NSA_>), grid, block, 0, s, (const unsigned short*)src, M, K, N, \
+                     (const unsigned short*)wgt, (unsigned short*)out, bn_part, tiles_m, tiles_n)
+  if (K == 64) {
+    if (bn == 256) CREID_ST_LAUNCH(256, 1, 3); else if (bn == 128) CREID_ST_LAUNCH(128, 1, 3); else CREID_ST_LAUNCH(64, 1, 3);
+  } else if (K == 128) {
+    if (bn == 256) CREID_ST_LAUNCH(256, 2, 3); else if (bn == 128) CREID_ST_LAUNCH(128, 2, 3); else CREID_ST_LAUNCH(64, 2, 3);
+  } else {
+    if (bn == 128) CREID_ST_LAUNCH(128, 4, 3); else CREID_ST_LAUNCH(64, 4, 4);
+  }
+#undef CREID_ST_LAUNCH
+  return (int)hipGetLastError();
+}

@@ -110,6 +110,33 @@ def test_maxpool(dtype):
                                atol=2e-2 if dtype == torch.bfloat16 else 1e-6)
 
 
+@pytest.mark.parametrize("wgs", [256, 6])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 8, 64, 256), (3, 20, 10, 256, 64), (2, 16, 16, 256, 128), (2, 16, 16, 128, 512),
+                                            (5, 32, 16, 64, 64), (1, 10, 10, 64, 256), (7, 24, 12, 128, 128), (2, 12, 12, 64, 128)])
+def test_stream_1x1_forward_matches_tile_kernel(B, H, W, cin, cout, wgs, monkeypatch):
+    """The persistent streaming kernel for small-K 1x1 stride-1 convolutions (conv_stream.hip) against the
+    tile-per-workgroup kernel on the same inputs: identical bf16 outputs (same MFMA order over k, same rounding) and
+    identical statistics partials; `wgs = 6` makes every workgroup walk several row tiles (ring wrap-around, partial
+    last tile, two column slabs)."""
+    from centroids_reid_amd import layers as ly
+    rng = np.random.default_rng(B * 1000 + cin + cout)
+    x = torch.from_numpy(rng.standard_normal((B, H, W, cin)).astype(np.float32)).to(torch.bfloat16).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)).cuda()
+    krsc, _ = ly.weight_prep(w, torch.bfloat16)
+    monkeypatch.setenv("CREID_STREAM1X1", "0")
+    y0, p0 = ly.conv2d_fwd(x, krsc, 1, 0, with_stats=True)
+    y0n = ly.conv2d_fwd(x, krsc, 1, 0)
+    monkeypatch.setenv("CREID_STREAM1X1", "1")
+    monkeypatch.setenv("CREID_STREAM1X1_WGS", str(wgs))
+    y1, p1 = ly.conv2d_fwd(x, krsc, 1, 0, with_stats=True)
+    y1n = ly.conv2d_fwd(x, krsc, 1, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0) and torch.equal(y1n, y0n)
+    np.testing.assert_allclose(p1.cpu().numpy(), p0.cpu().numpy(), rtol=1e-6, atol=1e-5)
+    ref = torch.einsum("bhwc,oc->bhwo", x.float(), krsc.view(cout, cin).float())
+    np.testing.assert_allclose(y1.float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
 def _build(arch, dtype, seed=1234):
     from oracle import backbone_oracle as bo
     from centroids_reid_amd import backbone as bb
