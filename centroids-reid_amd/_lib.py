@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcreid_hip.so")
+LIB_PATH = os.environ.get("CREID_LIB_PATH") or os.path.join(_HERE, "lib", "libcreid_hip.so")   # override: A/B of two builds
 
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}

@@ -15,7 +15,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcreid_hip.so")
 OBJDIR = os.path.join(LIBDIR, "obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=off"]
+         "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage"]
+RES_KEYS = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+            "LDS Size [bytes/block]": "lds", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill"}
 
 
 def hipcc() -> str:
@@ -39,8 +41,26 @@ def _compile(src: str, obj: str, verbose: bool):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip() and verbose:
-        print(r.stderr, file=sys.stderr)
+    # per-kernel register / scratch / occupancy table next to the object: tests/test_build_cpu.py keeps the hot
+    # kernels inside their occupancy budget (a 512-thread igemm workgroup needs <= 128 VGPRs to run two per CU)
+    rows, cur, other = [], None, []
+    for line in r.stderr.splitlines():
+        if "remark:" not in line:
+            other.append(line)
+            continue
+        body = line.split("remark:", 1)[1].replace("[-Rpass-analysis=kernel-resource-usage]", "").strip()
+        if body.startswith("Function Name:"):
+            cur = {"name": body.split(":", 1)[1].strip()}
+            rows.append(cur)
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            if k.strip() in RES_KEYS:
+                cur[RES_KEYS[k.strip()]] = v.strip()
+    with open(obj[:-2] + ".res", "w") as f:
+        for row in rows:
+            f.write(" ".join(f"{k}={v}" for k, v in row.items()) + "\n")
+    if other and verbose:
+        print("\n".join(other), file=sys.stderr)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -15,6 +15,7 @@ typedef float  f32x4  __attribute__((ext_vector_type(4)));
 typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef short  s16x8  __attribute__((ext_vector_type(8)));
 typedef short  s16x4  __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -54,8 +55,12 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
   return __uint_as_float(((unsigned)b) << 16);
 }
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  return __builtin_bit_cast(unsigned short, (__bf16)f);   // gfx950: one v_cvt_pk_bf16_f32 (round to nearest even, quiet NaN)
+}
+// two floats -> packed bf16 pair (lo in bits 0..15): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned f32x2_to_bf16x2_bits(float lo, float hi) {
+  typedef float cvt_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 cvt_bf16x2 __attribute__((ext_vector_type(2)));
+  const cvt_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cvt_bf16x2));
 }

@@ -15,6 +15,7 @@
 // activation dtype, and optional per-tile per-channel (sum, sum of squares) partials of the fp32
 // accumulators for the training-mode BatchNorm that follows every convolution.
 #include "conv_common.hpp"
+#include <type_traits>
 #include "wgrad_reduce.hpp"
 #include "tune.hpp"
 #include <stdlib.h>
@@ -283,9 +284,9 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
                                                                  float* __restrict__ bn_part, int tiles_n,
                                                                  BnRedArgs bnred) {
   constexpr int BK = 64, TNW = BN / 64, NBI = BN / 32;          // NBI = B-tile DMA instructions per wave
-  constexpr int CP = BN + 8;
+  constexpr int CPT = 128 + 4;                                   // transposed C staging (see igemm_bf16_ws_kernel)
   constexpr int TILE_A = 128 * BK, TILE_B = BN * BK, STAGE = TILE_A + TILE_B;
-  constexpr int LDS_ELEMS = (NS * STAGE) > (128 * CP) ? (NS * STAGE) : (128 * CP);
+  constexpr int LDS_ELEMS = (NS * STAGE) > (BN * CPT) ? (NS * STAGE) : (BN * CPT);
   constexpr int LPT = 4 + NBI;                                   // DMA instructions per wave per k-tile
   static_assert((NS - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) unsigned short smem[LDS_ELEMS];
@@ -431,13 +432,22 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   // fused BN-backward reduction: its two operand tiles (x, act) are fetched NOW, so the loads fly while the
   // accumulators are staged through LDS (they used to start only after the C tile had been stored)
   constexpr int NPRE = (128 * (BN / 8)) / 256;
+  constexpr int CPR = BN / 8;
+  static_assert(16 % CPR == 0, "copy-out map: 8 or 16 column octets per tile row");
+  const int t4 = lane & 3, q4 = (lane >> 2) & 3, g4 = lane >> 4;
+  auto unit_of = [&](int i, int& rl, int& ch) {                  // copy-out map of igemm_bf16_ws_kernel, 4 waves
+    const int Q = (wave + 4 * i) * 16 + g4 * 4 + q4;
+    ch = Q % CPR;
+    rl = 4 * (Q / CPR) + t4;
+  };
   uint4 pre_x[NPRE], pre_a[NPRE];
   if (bnred.x && bnred.prefetch) {
     const unsigned short* bx0 = reinterpret_cast<const unsigned short*>(bnred.x);
     const unsigned short* ba0 = reinterpret_cast<const unsigned short*>(bnred.act);
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int id = tid + 256 * i, rl = id / (BN / 8), ch = id - rl * (BN / 8);
+      int rl, ch;
+      unit_of(i, rl, ch);
       const int rr = row0 + rl;
       pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
       pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
@@ -456,24 +466,41 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const float v = acc[i][j][r];
-        s1 += v; s2 = fmaf(v, v, s2);
-        smem[rl * CP + cl] = f32_to_bf16_bits(v);
+      for (int q = 0; q < 4; ++q) {
+        const int rl = wm * 64 + i * 32 + 8 * q + 4 * kh;
+        const float v0 = acc[i][j][4 * q], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
+        s1 += v0; s2 = fmaf(v0, v0, s2);
+        s1 += v1; s2 = fmaf(v1, v1, s2);
+        s1 += v2; s2 = fmaf(v2, v2, s2);
+        s1 += v3; s2 = fmaf(v3, v3, s2);
+        *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
       }
     }
     s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
     s1v[j] = s1; s2v[j] = s2;
   }
   __syncthreads();
-  constexpr int CPR = BN / 8;
+  constexpr int NIT = (128 * CPR) / 256;
+  u32x2 trlo[NIT], trhi[NIT];
+  {
+    const int sq = lane & 3, sj = (lane >> 2) & 3;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int Qs = (wave + 4 * i) * 16 + g4 * 4 + sq;
+      const unsigned addr = (unsigned)(uintptr_t)&smem[((Qs % CPR) * 8 + sj) * CPT + 4 * (Qs / CPR)];
+      asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                   : "=&v"(trlo[i]), "=&v"(trhi[i]) : "v"(addr), "i"(4 * CPT * 2) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) asm volatile("" : "+v"(trlo[i]), "+v"(trhi[i]));
+  }
   constexpr int NRG = 256 / CPR;                               // row groups among the threads sharing a chunk column
   const unsigned short* bx = reinterpret_cast<const unsigned short*>(bnred.x);
   const unsigned short* bact = reinterpret_cast<const unsigned short*>(bnred.act);
   float rs1[8], rs2[8], rmu[8], ris[8];
   if (bx) {
-    const int c0 = col0 + (tid % CPR) * 8;
+    const int c0 = col0 + ((g4 * 4 + q4) % CPR) * 8;
 #pragma unroll
     for (int k = 0; k < 8; k += 4) {
       const int64_t so = bnred.tiles_per_image ? (int64_t)(tile_m / bnred.tiles_per_image) * g.N : 0;   // per-image statistics (IBN)
@@ -486,11 +513,12 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     for (int k = 0; k < 8; ++k) { rs1[k] = 0.f; rs2[k] = 0.f; }
   }
 #pragma unroll
-  for (int i = 0; i < (128 * CPR) / 256; ++i) {
-    const int id = tid + 256 * i, rl = id / CPR, ch = id - rl * CPR;
+  for (int i = 0; i < NIT; ++i) {
+    int rl, ch;
+    unit_of(i, rl, ch);
     const int rr = row0 + rl;
     if (rr < g.M) {
-      uint4 v = *reinterpret_cast<const uint4*>(&smem[rl * CP + ch * 8]);
+      uint4 v = make_uint4(trlo[i].x, trlo[i].y, trhi[i].x, trhi[i].y);
       const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
       if (add_src) {
         int64_t aoff = off;
@@ -538,7 +566,8 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   if (bx) {
     __syncthreads();                                           // staged C tile no longer needed
     float* red2 = reinterpret_cast<float*>(smem);              // [NRG][2][BN]
-    const int rg = tid / CPR, cb = (tid % CPR) * 8;
+    const int cidx = g4 * 4 + q4;
+    const int rg = (wave * 4 + t4) * (16 / CPR) + cidx / CPR, cb = (cidx % CPR) * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { red2[(rg * 2 + 0) * BN + cb + k] = rs1[k]; red2[(rg * 2 + 1) * BN + cb + k] = rs2[k]; }
     __syncthreads();
@@ -585,11 +614,11 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
                                                                 BnRedArgs bnred, WRedJob wred) {
   constexpr int NT = 512;
   constexpr int BK = 64, TNW = BN / 64, NBI = BN / 32;
-  constexpr int CP = BN + 8;
+  constexpr int CPT = 128 + 4;                                   // transposed staging: [BN columns][128 rows + 4]
   constexpr int TILE_A = 128 * BK, TILE_B = BN * BK, STAGE = TILE_A + TILE_B;
   constexpr int CPR = BN / 8, NRG = NT / CPR;
   constexpr int RED_ELEMS = NRG * 2 * BN * 2;                    // fp32 reduction scratch, in 2-byte units
-  constexpr int LDS0 = (NS * STAGE) > (128 * CP) ? (NS * STAGE) : (128 * CP);
+  constexpr int LDS0 = (NS * STAGE) > (BN * CPT) ? (NS * STAGE) : (BN * CPT);
   constexpr int LDS_ELEMS = LDS0 > RED_ELEMS ? LDS0 : RED_ELEMS;
   constexpr int LPT = 4 + NBI;
   static_assert(NS >= 2 && (NS - 2) * LPT <= 63, "ring depth");
@@ -759,14 +788,23 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   // ---- epilogue: consumers stage the C tile (bf16) in LDS, all 512 threads copy it out
   // fused BN-backward reduction: its two operand tiles (x, act) are fetched NOW, so the loads fly while the
   // accumulators are staged through LDS (they used to start only after the C tile had been stored)
+  // copy-out map (see below): a 16-lane group owns 4 rows x 4 column octets; lane = 16*g4 + 4*q4 + t4 stores row t4 of the
+  // row quad, octet g4*4 + q4 of the wave's 16-octet strip
   constexpr int NPRE = (128 * (BN / 8)) / 512;
+  const int t4 = lane & 3, q4 = (lane >> 2) & 3, g4 = lane >> 4;
+  auto unit_of = [&](int i, int& rl, int& ch) {
+    const int Q = (wave + 8 * i) * 16 + g4 * 4 + q4;
+    ch = Q % CPR;
+    rl = 4 * (Q / CPR) + t4;
+  };
   uint4 pre_x[NPRE], pre_a[NPRE];
   if (bnred.x && bnred.prefetch) {
     const unsigned short* bx0 = reinterpret_cast<const unsigned short*>(bnred.x);
     const unsigned short* ba0 = reinterpret_cast<const unsigned short*>(bnred.act);
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int id = tid + 512 * i, rl = id / (BN / 8), ch = id - rl * (BN / 8);
+      int rl, ch;
+      unit_of(i, rl, ch);
       const int rr = row0 + rl;
       pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
       pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
@@ -777,6 +815,10 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       }
     }
   }
+  // The C tile is staged COLUMN-major: a lane's four consecutive accumulator rows of one column are one packed 8-byte
+  // LDS store (2 v_cvt_pk_bf16_f32 + 1 ds_write_b64 per 4 values; the row-major image took a 2-byte store per value),
+  // and the copy-out gets its row-major 16-byte chunks back through the transposing LDS read.  Column pitch 264 B:
+  // 16 consecutive columns start 2 banks apart (conflict-free b64 stores), the 4 x 4 units of a transposing read too.
   float s1v[TNW], s2v[TNW];
   if (!producer) {
 #pragma unroll
@@ -786,11 +828,14 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          const float v = acc[i][j][r];
-          s1 += v; s2 = fmaf(v, v, s2);
-          smem[rl * CP + cl] = f32_to_bf16_bits(v);
+        for (int q = 0; q < 4; ++q) {
+          const int rl = wm * 64 + i * 32 + 8 * q + 4 * kh;
+          const float v0 = acc[i][j][4 * q], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
+          s1 += v0; s2 = fmaf(v0, v0, s2);
+          s1 += v1; s2 = fmaf(v1, v1, s2);
+          s1 += v2; s2 = fmaf(v2, v2, s2);
+          s1 += v3; s2 = fmaf(v3, v3, s2);
+          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
         }
       }
       s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -798,11 +843,27 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     }
   }
   __syncthreads();
+  // transposing reads: in a 16-lane group lane s supplies the 8-byte unit (column 8 * octet(s & 3) + (s >> 2), the row quad)
+  // and lane l receives (row l & 3, columns 8 * octet(l >> 2) + 0..3); a second read 4 columns on completes the 16-byte chunk.
+  // Every lane takes part (the data crosses lanes), only the global store is predicated.
+  constexpr int NIT = (128 * CPR) / NT;
+  static_assert(16 % CPR == 0, "copy-out map: 8 or 16 column octets per tile row");
+  u32x2 trlo[NIT], trhi[NIT];
+  {
+    const int sq = lane & 3, sj = (lane >> 2) & 3;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int Qs = (wave + 8 * i) * 16 + g4 * 4 + sq;
+      const unsigned addr = (unsigned)(uintptr_t)&smem[((Qs % CPR) * 8 + sj) * CPT + 4 * (Qs / CPR)];
+      asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                   : "=&v"(trlo[i]), "=&v"(trhi[i]) : "v"(addr), "i"(4 * CPT * 2) : "memory");
+    }
+  }
   const unsigned short* bx = reinterpret_cast<const unsigned short*>(bnred.x);
   const unsigned short* bact = reinterpret_cast<const unsigned short*>(bnred.act);
   float rs1[8], rs2[8], rmu[8], ris[8];
   if (bx) {
-    const int c0 = col0 + (tid % CPR) * 8;
+    const int c0 = col0 + ((g4 * 4 + q4) % CPR) * 8;            // this thread's column octet is the same in every pass
 #pragma unroll
     for (int k = 0; k < 8; k += 4) {
       const int64_t so = bnred.tiles_per_image ? (int64_t)(tile_m / bnred.tiles_per_image) * g.N : 0;   // per-image statistics (IBN)
@@ -814,12 +875,16 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { rs1[k] = 0.f; rs2[k] = 0.f; }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < (128 * CPR) / NT; ++i) {
-    const int id = tid + NT * i, rl = id / CPR, ch = id - rl * CPR;
+  for (int i = 0; i < NIT; ++i) asm volatile("" : "+v"(trlo[i]), "+v"(trhi[i]));
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    int rl, ch;
+    unit_of(i, rl, ch);
     const int rr = row0 + rl;
     if (rr < g.M) {
-      uint4 v = *reinterpret_cast<const uint4*>(&smem[rl * CP + ch * 8]);
+      uint4 v = make_uint4(trlo[i].x, trlo[i].y, trhi[i].x, trhi[i].y);
       const int prow = pixel_of(rr);
       const int64_t off = (int64_t)prow * g.N + col0 + ch * 8;
       if (add_src) {
@@ -868,7 +933,8 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   if (bx) {
     __syncthreads();
     float* red2 = reinterpret_cast<float*>(smem);                // [NRG][2][BN]
-    const int rg = tid / CPR, cb = (tid % CPR) * 8;
+    const int cidx = g4 * 4 + q4;
+    const int rg = (wave * 4 + t4) * (16 / CPR) + cidx / CPR, cb = (cidx % CPR) * 8;   // threads that share an octet
 #pragma unroll
     for (int k = 0; k < 8; ++k) { red2[(rg * 2 + 0) * BN + cb + k] = rs1[k]; red2[(rg * 2 + 1) * BN + cb + k] = rs2[k]; }
     __syncthreads();

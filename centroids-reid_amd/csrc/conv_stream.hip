@@ -29,7 +29,7 @@ template <int BN, int KCH, int NSA>
 __global__ __launch_bounds__(512, 1) void igemm1x1_stream_kernel(const unsigned short* __restrict__ src, int M, int K, int N,
                                                                   const unsigned short* __restrict__ wgt,
                                                                   unsigned short* __restrict__ out,
-                                                                  float* __restrict__ bn_part, int tiles_m, int tiles_n) {
+                                                                  float* __restrict__ bn_part, int tiles_m, int tiles_n, int dbg) {
   constexpr int TNW = BN / 64;                         // 32-wide column blocks per consumer wave (x 2 row blocks)
   constexpr int HB = BN > 128 ? 128 : BN;              // columns staged / copied out at a time
   constexpr int NH = BN / HB;                          // halves per tile
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(512, 1) void igemm1x1_stream_kernel(const unsigned 
           const int cc = wn * (BN / 2) + j * 32 + l31;
           b[j] = *reinterpret_cast<const s16x8*>(&Bs[cc * 64 + ((ch ^ ((cc >> 1) & 7)) << 3)]);
         }
+        if (dbg & 4) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(512, 1) void igemm1x1_stream_kernel(const unsigned 
         const int cglob = wn * (BN / 2) + j * 32;                  // first column of the 32-wide block
         if (cglob / HB != h) continue;                             // compile-time after unrolling
         const int cl = cglob - h * HB + l31;
+        if (dbg & 2) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(512, 1) void igemm1x1_stream_kernel(const unsigned 
       for (int i = 0; i < (128 * CPR) / 256; ++i) {
         const int id = tid + 256 * i, rl = id / CPR, ch = id - rl * CPR;
         const int rr = row0 + rl;
-        if (rr < M) {
+        if (rr < M && !(dbg & 1)) {
           const uint4 v = *reinterpret_cast<const uint4*>(&stage[rl * CP + ch * 8]);
           *reinterpret_cast<uint4*>(out + (int64_t)rr * N + col0 + h * HB + ch * 8) = v;
         }
@@ -216,13 +218,15 @@ int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void
   // persistent grid: one workgroup per CU (the LDS budget allows one), split evenly over the column slabs
   int wgs = 256;                                       // read per call (tests shrink it to force many tiles per workgroup)
   { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }
+  int dbg = 0;
+  { const char* e = getenv("CREID_STREAM1X1_DBG"); if (e) dbg = atoi(e); }
   int groups = wgs / tiles_n;
   if (groups < 1) groups = 1;
   if (groups > tiles_m) groups = tiles_m;
   const dim3 grid((unsigned)(groups * tiles_n)), block(512);
 #define CREID_ST_LAUNCH(BN_, KCH_, NSA_)                                                                              \
   hipLaunchKernelGGL((igemm1x1_stream_kernel<BN_, KCH_, NSA_>), grid, block, 0, s, (const unsigned short*)src, M, K, N, \
-                     (const unsigned short*)wgt, (unsigned short*)out, bn_part, tiles_m, tiles_n)
+                     (const unsigned short*)wgt, (unsigned short*)out, bn_part, tiles_m, tiles_n, dbg)
   if (K == 64) {
     if (bn == 256) CREID_ST_LAUNCH(256, 1, 3); else if (bn == 128) CREID_ST_LAUNCH(128, 1, 3); else CREID_ST_LAUNCH(64, 1, 3);
   } else if (K == 128) {
