@@ -781,7 +781,11 @@ bool wgrad_make_reduce_job(const creid_conv_desc* d, int dtype, const void* ws, 
   const int M = (int)(d->batch * d->out_h * d->out_w), K = (int)(d->kh * d->kw * d->in_c), NCO = (int)d->out_c;
   const WgradPlan p = plan_wgrad(M, NCO, K, dtype);
   if (ws_bytes < (size_t)p.splits * NCO * K * sizeof(float)) return false;
-  return wred_make_job(j, (const float*)ws, dw, p.splits, NCO, K, (int)d->in_c, d->kh, d->kw, accumulate);
+  const bool ok = wred_make_job(j, (const float*)ws, dw, p.splits, NCO, K, (int)d->in_c, d->kh, d->kw, accumulate);
+  // timing experiments only: the carrier workgroups are launched but do nothing (gradients are then WRONG)
+  static const int dry = [] { const char* e = getenv("CREID_WRED_DRY"); return e ? atoi(e) : 0; }();
+  if (ok && dry) { j.K = 0; j.splits = 0; }
+  return ok;
 }
 
 extern "C" {

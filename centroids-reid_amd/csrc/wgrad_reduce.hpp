@@ -15,6 +15,7 @@ struct WRedJob {
   int accumulate;
   int nblocks;           // workgroups that carry the job
   int rows_per_block;    // output channels per workgroup
+  int split_lanes;       // 1x1 flat path: threads that share one output (power of two)
 };
 
 // One workgroup of NT threads reduces output channels [block*rows_per_block, ...).  Per channel: phase 1 sums the
@@ -23,10 +24,52 @@ struct WRedJob {
 // lds: >= NT*16 + K*4 bytes.
 template <int NT>
 __device__ __forceinline__ void wgrad_reduce_block(const WRedJob& j, int block, float* lds) {
-  float4* red = reinterpret_cast<float4*>(lds);              // [SL][G]  (NT float4)
-  float* row = lds + 4 * NT;                                 // [K]
   const int tid = threadIdx.x;
   const int nf4 = j.K >> 2;
+  if (j.taps == 1) {
+    // 1x1: the partial layout [co][c] IS the OIHW layout -- a flat stream of 16-byte outputs.  A workgroup covers
+    // G = NT / SL outputs x SL split lanes (SL = j.split_lanes, chosen on the host so that a thread sums <= 8 splits):
+    // every load of a pass is issued back to back (one memory round trip per workgroup, where the per-channel form
+    // took one per channel), the lanes meet in LDS and lane 0 adds them in a fixed order.
+    const int64_t total4 = (int64_t)j.NCO * nf4;
+    const float4* wsp = reinterpret_cast<const float4*>(j.ws);
+    float4* dw4 = reinterpret_cast<float4*>(j.dw);
+    float4* red = reinterpret_cast<float4*>(lds);            // [SL][G]
+    const int SL = j.split_lanes < NT ? j.split_lanes : NT, G = NT / SL;
+    const int gi = tid % G, sl = tid / G;
+    for (int64_t f0 = (int64_t)block * G; f0 < total4; f0 += (int64_t)j.nblocks * G) {   // uniform trip count
+      const int64_t f = f0 + gi;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < total4) {
+        int sp = sl;
+        for (; sp + 7 * SL < j.splits; sp += 8 * SL) {
+          float4 v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = wsp[(int64_t)(sp + q * SL) * total4 + f];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
+        }
+        for (; sp < j.splits; sp += SL) {
+          const float4 v = wsp[(int64_t)sp * total4 + f];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+      if (SL > 1) {
+        red[sl * G + gi] = acc;
+        __syncthreads();
+        if (sl == 0)
+          for (int q = 1; q < SL; ++q) { const float4 v = red[q * G + gi]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      }
+      if (sl == 0 && f < total4) {
+        if (j.accumulate) { const float4 o = dw4[f]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        dw4[f] = acc;
+      }
+      if (SL > 1) __syncthreads();
+    }
+    return;
+  }
+  float4* red = reinterpret_cast<float4*>(lds);              // [SL][G]  (NT float4)
+  float* row = lds + 4 * NT;                                 // [K]
   int SL = 1;                                                // split lanes: largest power of two <= splits that fits
   while (SL * 2 <= j.splits && SL * 2 * (nf4 < NT ? nf4 : NT) <= NT) SL *= 2;
   const int G = NT / SL;                                     // 16-byte column groups per pass
@@ -97,5 +140,13 @@ static inline bool wred_make_job(WRedJob& j, const float* ws, float* dw, int spl
   const int rpb = 1;
   j.rows_per_block = rpb;
   j.nblocks = (NCO + rpb - 1) / rpb;
+  j.split_lanes = 1;
+  if (j.taps == 1) {                                         // flat path: 512 / split_lanes outputs per workgroup
+    while (j.split_lanes < 64 && splits > 8 * j.split_lanes) j.split_lanes *= 2;
+    const int64_t total4 = (int64_t)NCO * (K >> 2);
+    const int64_t per_wg = 512 / j.split_lanes;
+    int64_t nb = (total4 + per_wg - 1) / per_wg;
+    j.nblocks = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+  }
   return true;
 }
