@@ -574,6 +574,12 @@ static inline unsigned ew_blocks(int64_t total_threads_needed, int64_t mult) {
     else return CREID_E_DTYPE;                          \
   } while (0)
 
+// timing experiments only (results are then WRONG): CREID_BN_FIN_DRY bit 0 skips the forward finalize launches, bit 1 the
+// backward ones -- measures what the 106 tiny launches cost inside a captured step
+static bool fin_dry(int bit) {
+  static const int v = [] { const char* e = getenv("CREID_BN_FIN_DRY"); return e ? atoi(e) : 0; }();
+  return (v & bit) != 0;
+}
 extern "C" {
 
 int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t count, float* running_mean,
@@ -581,6 +587,7 @@ int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t c
                         const float* beta, float* mean_out, float* invstd_out, float* scale_shift, void* stream) {
   CREID_CHECK_ARG(C > 0 && mean_out && invstd_out && scale_shift &&
                   (training ? (partial && rows > 0 && count > 0) : (running_mean && running_var)));
+  if (!fin_dry(1))
   hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, as_stream(stream), partial,
                      (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, gamma, beta,
                      mean_out, invstd_out, scale_shift);
@@ -629,6 +636,7 @@ int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* m
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
                                 invstd, M, (int)C, 128, partial));
+  if (!fin_dry(2))
   hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, rows, (int)C,
                      (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,
