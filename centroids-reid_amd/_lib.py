@@ -133,9 +133,10 @@ def load_tuned_plans(path=None):
     """Register the measured per-shape launch plans (tools/tune_plans.py) with the library; CREID_TUNED_PLANS=0 skips
     them (built-in rules everywhere).  Returns the number of plans registered."""
     import json
-    if os.environ.get("CREID_TUNED_PLANS", "1") == "0":
+    sel = os.environ.get("CREID_TUNED_PLANS", "1")
+    if sel == "0":
         return 0
-    path = path or PLANS_PATH
+    path = path or (sel if sel not in ("", "1") else PLANS_PATH)      # a path: A/B of two plan files
     if not os.path.exists(path):
         return 0
     with open(path) as f:
