@@ -251,6 +251,9 @@ class BackboneEngine:
             self._group_first[o] = k
             o += len(layer)
         self.saved = None
+        # training forward writes each ReLU's mask as bits (1 byte per 8 channels); the BatchNorm backward and the fused
+        # data-gradient epilogue read that instead of re-reading the activation (CREID_RELU_BITMASK=0: read the activation)
+        self.relu_bitmask = dtype == torch.bfloat16 and os.environ.get("CREID_RELU_BITMASK", "1") == "1"
         self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
         self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
@@ -403,8 +406,13 @@ class BackboneEngine:
                                         1 if training else 0, bn.momentum, bn.eps, L.ptr(bn.weight), L.ptr(bn.bias),
                                         L.ptr(mean), L.ptr(invstd), L.ptr(ss), st), "bn2d_finalize")
         a = self._empty(M, u.cout)
-        L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(ss), L.ptr(residual), 1 if relu else 0, M, u.cout, self.dt,
-                                     L.ptr(a), st), "bn2d_apply")
+        mask = None
+        if training and relu and self.relu_bitmask:
+            mask = torch.empty(M * u.cout // 8, dtype=torch.uint8, device=self.device)
+        L.check(lib.creid_bn2d_apply_mask(L.ptr(x), L.ptr(ss), L.ptr(residual), 1 if relu else 0, M, u.cout, self.dt,
+                                          L.ptr(a), L.ptr(mask), st), "bn2d_apply")
+        if mask is not None:
+            a._relu_mask = mask            # travels with the saved activation to _bn_bwd / _dgrad
         return a, mean, invstd
 
     # ---- forward
@@ -481,9 +489,10 @@ class BackboneEngine:
         bn = u.bn
         dgam = self._grad_of(bn.weight) if bn.weight.requires_grad else None
         dbet = self._grad_of(bn.bias) if bn.bias.requires_grad else None
-        L.check(lib.creid_bn2d_bwd(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(bn.weight), M, u.cout,
-                                   self.dt, L.ptr(part), ready, L.ptr(sums), L.ptr(dgam), L.ptr(dbet), L.ptr(dx), L.ptr(gm),
-                                   st), "bn2d_bwd")
+        mask = getattr(act, "_relu_mask", None) if act is not None else None
+        L.check(lib.creid_bn2d_bwd_mask(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mask), L.ptr(mean), L.ptr(invstd),
+                                        L.ptr(bn.weight), M, u.cout, self.dt, L.ptr(part), ready, L.ptr(sums), L.ptr(dgam),
+                                        L.ptr(dbet), L.ptr(dx), L.ptr(gm), st), "bn2d_bwd")
         return dx, gm
 
     def _wgrad(self, u, a_in, dy, B, H, W):
@@ -544,22 +553,17 @@ class BackboneEngine:
         d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         M = B * H * W
         dx = self._empty(M, u.cin)
-        if self._wred_pending:
-            rd, rgw, rws, rbytes = self._wred_pending.pop(0)
-            fuse_bn = bnred is not None and self.fuse_bn_reduce
+        fuse_bn = bnred is not None and self.fuse_bn_reduce
+        if self._wred_pending or fuse_bn:
+            rd, rgw, rws, rbytes = self._wred_pending.pop(0) if self._wred_pending else (None, None, None, 0)
             x, act, mean, invstd = bnred if fuse_bn else (None, None, None, None)
+            mask = getattr(act, "_relu_mask", None) if act is not None else None
             part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32) if fuse_bn else None
             L.check(lib.creid_conv2d_dgrad_fused_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src),
-                                                      add_src_stride, L.ptr(x), L.ptr(act), L.ptr(mean), L.ptr(invstd),
-                                                      L.ptr(part), stat_image_rows if fuse_bn else 0, C.byref(rd), L.ptr(rgw), 1,
+                                                      add_src_stride, L.ptr(x), L.ptr(act), L.ptr(mask), L.ptr(mean),
+                                                      L.ptr(invstd), L.ptr(part), stat_image_rows if fuse_bn else 0,
+                                                      C.byref(rd) if rd is not None else None, L.ptr(rgw), 1,
                                                       L.ptr(rws), rbytes, self.dt, st), "conv2d_dgrad_fused")
-            return dx, part
-        if bnred is not None and self.fuse_bn_reduce:
-            x, act, mean, invstd = bnred
-            part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32)
-            L.check(lib.creid_conv2d_dgrad_bnred_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src),
-                                                      L.ptr(x), L.ptr(act), L.ptr(mean), L.ptr(invstd), L.ptr(part),
-                                                      stat_image_rows, add_src_stride, self.dt, st), "conv2d_dgrad_bnred")
             return dx, part
         L.check(lib.creid_conv2d_dgrad_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src), self.dt, st),
                 "conv2d_dgrad")

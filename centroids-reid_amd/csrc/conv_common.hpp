@@ -77,6 +77,7 @@ struct BnRedArgs {
   int prefetch;          // fetch x / act before the C tile is staged (A/B knob CREID_BNRED_PREFETCH, default 1)
   int tiles_per_image;   // 0: mean/invstd are per channel [N]; > 0: per (image, channel) [B][N] (IBN), this many
                          // 128-row tiles per image
+  const unsigned char* mask;   // nullable: ReLU mask as bits (creid_bn2d_apply_mask), one byte per 8 channels; replaces `act`
 };
 
 // XCD-aware bijective remap of the linear workgroup id (consecutive ids land on different XCDs;

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     rl = 4 * (Q / CPR) + t4;
   };
   uint4 pre_x[NPRE], pre_a[NPRE];
+  unsigned pre_m[NPRE];                                          // ReLU mask bits of the chunk (bnred.mask) instead of pre_a
   if (bnred.x && bnred.prefetch) {
     const unsigned short* bx0 = reinterpret_cast<const unsigned short*>(bnred.x);
     const unsigned short* ba0 = reinterpret_cast<const unsigned short*>(bnred.act);
@@ -451,10 +452,12 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       const int rr = row0 + rl;
       pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
       pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      pre_m[i] = 0xffu;
       if (rr < g.M) {
         const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
         pre_x[i] = *reinterpret_cast<const uint4*>(bx0 + off);
-        if (ba0) pre_a[i] = *reinterpret_cast<const uint4*>(ba0 + off);
+        if (bnred.mask) pre_m[i] = bnred.mask[off >> 3];
+        else if (ba0) pre_a[i] = *reinterpret_cast<const uint4*>(ba0 + off);
       }
     }
   }
@@ -544,10 +547,12 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       *reinterpret_cast<uint4*>(out + off) = v;
       if (bx) {                                                // fused BN-backward column reduction
         uint4 xv = pre_x[i], av = pre_a[i];
+        unsigned mb = pre_m[i];
         if (!bnred.prefetch) {
           xv = *reinterpret_cast<const uint4*>(bx + off);
           av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-          if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
+          if (bnred.mask) mb = bnred.mask[off >> 3];
+          else if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
         }
         const unsigned* vw = &v.x; const unsigned* xw = &xv.x; const unsigned* aw = &av.x;
 #pragma unroll
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
           float g0 = __uint_as_float(vw[q] << 16), g1 = __uint_as_float(vw[q] & 0xffff0000u);
           const float a0 = __uint_as_float(aw[q] << 16), a1 = __uint_as_float(aw[q] & 0xffff0000u);
           const float x0 = __uint_as_float(xw[q] << 16), x1 = __uint_as_float(xw[q] & 0xffff0000u);
-          g0 = a0 > 0.f ? g0 : 0.f; g1 = a1 > 0.f ? g1 : 0.f;
+          g0 = (a0 > 0.f && ((mb >> (2 * q)) & 1u)) ? g0 : 0.f; g1 = (a1 > 0.f && ((mb >> (2 * q + 1)) & 1u)) ? g1 : 0.f;
           rs1[2 * q] += g0; rs1[2 * q + 1] += g1;
           rs2[2 * q] = fmaf(g0, (x0 - rmu[2 * q]) * ris[2 * q], rs2[2 * q]);
           rs2[2 * q + 1] = fmaf(g1, (x1 - rmu[2 * q + 1]) * ris[2 * q + 1], rs2[2 * q + 1]);
@@ -798,6 +803,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     rl = 4 * (Q / CPR) + t4;
   };
   uint4 pre_x[NPRE], pre_a[NPRE];
+  unsigned pre_m[NPRE];                                          // ReLU mask bits of the chunk (bnred.mask) instead of pre_a
   if (bnred.x && bnred.prefetch) {
     const unsigned short* bx0 = reinterpret_cast<const unsigned short*>(bnred.x);
     const unsigned short* ba0 = reinterpret_cast<const unsigned short*>(bnred.act);
@@ -808,10 +814,12 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       const int rr = row0 + rl;
       pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
       pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      pre_m[i] = 0xffu;
       if (rr < g.M) {
         const int64_t off = (int64_t)pixel_of(rr) * g.N + col0 + ch * 8;
         pre_x[i] = *reinterpret_cast<const uint4*>(bx0 + off);
-        if (ba0) pre_a[i] = *reinterpret_cast<const uint4*>(ba0 + off);
+        if (bnred.mask) pre_m[i] = bnred.mask[off >> 3];
+        else if (ba0) pre_a[i] = *reinterpret_cast<const uint4*>(ba0 + off);
       }
     }
   }
@@ -911,10 +919,12 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       *reinterpret_cast<uint4*>(out + off) = v;
       if (bx) {
         uint4 xv = pre_x[i], av = pre_a[i];
+        unsigned mb = pre_m[i];
         if (!bnred.prefetch) {
           xv = *reinterpret_cast<const uint4*>(bx + off);
           av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-          if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
+          if (bnred.mask) mb = bnred.mask[off >> 3];
+          else if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
         }
         const unsigned* vw = &v.x; const unsigned* xw = &xv.x; const unsigned* aw = &av.x;
 #pragma unroll
@@ -922,7 +932,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
           float g0 = __uint_as_float(vw[q] << 16), g1 = __uint_as_float(vw[q] & 0xffff0000u);
           const float a0 = __uint_as_float(aw[q] << 16), a1 = __uint_as_float(aw[q] & 0xffff0000u);
           const float x0 = __uint_as_float(xw[q] << 16), x1 = __uint_as_float(xw[q] & 0xffff0000u);
-          g0 = a0 > 0.f ? g0 : 0.f; g1 = a1 > 0.f ? g1 : 0.f;
+          g0 = (a0 > 0.f && ((mb >> (2 * q)) & 1u)) ? g0 : 0.f; g1 = (a1 > 0.f && ((mb >> (2 * q + 1)) & 1u)) ? g1 : 0.f;
           rs1[2 * q] += g0; rs1[2 * q + 1] += g1;
           rs2[2 * q] = fmaf(g0, (x0 - rmu[2 * q]) * ris[2 * q], rs2[2 * q]);
           rs2[2 * q + 1] = fmaf(g1, (x1 - rmu[2 * q + 1]) * ris[2 * q + 1], rs2[2 * q + 1]);
@@ -1282,12 +1292,13 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
 
 /* Data gradient with everything that can ride in the same launch: "+ add_src" (full or stride-2 compact), the NEXT
  * BatchNorm-backward's column reduction (bn_x != NULL; bf16), and the split reduction of the PREVIOUS weight-gradient
+ * (bn_mask != NULL: the ReLU mask comes as bits from creid_bn2d_apply_mask, one byte per 8 channels, and bn_act is not read)
  * launch (wred_desc != NULL: creid_conv2d_wgrad_partials of that convolution wrote wred_ws; the first workgroups of
  * this launch sum the partials into wred_dw).  Where the fused kernel does not apply (fp32 parity mode, stem) the
  * reduction runs as its own launch first -- same result. */
 int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
                                   const void* add_src, int add_src_stride, const void* bn_x, const void* bn_act,
-                                  const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                                  const uint8_t* bn_mask, const float* bn_mean, const float* bn_invstd, float* bn_partial,
                                   int64_t bn_stat_image_rows, const creid_conv_desc* wred_desc, float* wred_dw,
                                   int wred_accumulate, const void* wred_ws, size_t wred_ws_bytes, int dtype, void* stream) {
   int rc = check_desc(d);
@@ -1314,8 +1325,8 @@ int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, cons
   igemm_finish_geom(g);
   static const int prefetch = [] { const char* e = getenv("CREID_BNRED_PREFETCH"); return e ? atoi(e) : 1; }();
   g.add_compact = add_src_stride == 2;
-  BnRedArgs br{bn_x, bn_act, bn_mean, bn_invstd, bn_partial, prefetch, (int)(bn_stat_image_rows / 128)};
-  if (!bn_x) br = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  BnRedArgs br{bn_x, bn_mask ? nullptr : bn_act, bn_mean, bn_invstd, bn_partial, prefetch, (int)(bn_stat_image_rows / 128), bn_mask};
+  if (!bn_x) br = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
   return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream), br, have_job ? &job : nullptr);
 }
 

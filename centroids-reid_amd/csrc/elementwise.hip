@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift,
                                                          const T* __restrict__ res, int relu, int64_t M, int C,
-                                                         T* __restrict__ y) {
+                                                         T* __restrict__ y, uint8_t* __restrict__ mask_out) {
+  // mask_out (bf16 only, V = 8): bit k of byte i = (y[8 i + k] > 0) -- the ReLU mask the backward needs, at 1/16 of the
+  // bytes of re-reading y there
   constexpr int V = Vec16<T>::N;
   const int cpr = C / V;
   const int64_t total = M * cpr, nthreads = (int64_t)gridDim.x * 256;
@@ -169,6 +171,12 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x
       if (relu) v[k] = fmaxf(v[k], 0.f);
     }
     Vec16<T>::store(y + i * V, v);
+    if (mask_out) {
+      unsigned m = 0;
+#pragma unroll
+      for (int k = 0; k < V; ++k) m |= (v[k] > 0.f ? 1u : 0u) << k;
+      mask_out[i] = (uint8_t)m;
+    }
     if (two) {
 #pragma unroll
       for (int k = 0; k < V; ++k) {
@@ -176,6 +184,12 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x
         if (relu) w[k] = fmaxf(w[k], 0.f);
       }
       Vec16<T>::store(y + i2 * V, w);
+      if (mask_out) {
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) m |= (w[k] > 0.f ? 1u : 0u) << k;
+        mask_out[i2] = (uint8_t)m;
+      }
     }
   }
 }
@@ -187,7 +201,8 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
                                                               const T* __restrict__ act,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, int64_t M, int C,
-                                                              int rows_per_block, float* __restrict__ partial) {
+                                                              int rows_per_block, float* __restrict__ partial,
+                                                              const uint8_t* __restrict__ mask) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][256 * V];
   const int cpr = C / V, cw = cpr < 32 ? cpr : 32, nrl = 256 / cw;
@@ -209,7 +224,11 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
       float xv[V], gv[V];
       Vec16<T>::load(x + r * C + c0, xv);
       Vec16<T>::load(g + r * C + c0, gv);
-      if (act) {
+      if (mask) {                                  // ReLU mask as bits (bn2d_apply_kernel's mask_out), 8 channels per byte
+        const unsigned m = mask[(r * C + c0) / V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) gv[k] = ((m >> k) & 1u) ? gv[k] : 0.f;
+      } else if (act) {
         float av[V];
         Vec16<T>::load(act + r * C + c0, av);
 #pragma unroll
@@ -290,7 +309,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                              const T* __restrict__ act,
                                                              const float* __restrict__ coef, int64_t M, int C,
-                                                             T* __restrict__ dx, T* __restrict__ gm_out) {
+                                                             T* __restrict__ dx, T* __restrict__ gm_out,
+                                                             const uint8_t* __restrict__ mask) {
   constexpr int V = Vec16<T>::N;
   const int cpr = C / V;
   const int64_t total = M * cpr, nthreads = (int64_t)gridDim.x * 256;
@@ -310,7 +330,11 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict
     float xv[V], gv[V];
     Vec16<T>::load(x + i * V, xv);
     Vec16<T>::load(g + i * V, gv);
-    if (act) {
+    if (mask) {
+      const unsigned m = mask[i];
+#pragma unroll
+      for (int k = 0; k < V; ++k) gv[k] = ((m >> k) & 1u) ? gv[k] : 0.f;
+    } else if (act) {
       float av[V];
       Vec16<T>::load(act + i * V, av);
 #pragma unroll
@@ -608,45 +632,61 @@ int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* parti
   CREID_LAUNCH_RET();
 }
 
-int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M, int64_t C,
-                     int dtype, void* y, void* stream) {
+int creid_bn2d_apply_mask(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M, int64_t C,
+                          int dtype, void* y, uint8_t* mask_out, void* stream) {
   CREID_CHECK_ARG(x && scale_shift && y && M > 0 && C > 0 && C % 8 == 0);
+  if (mask_out && dtype == CREID_F32) return CREID_E_DTYPE;    // the bit mask is defined per 8-channel (16-byte bf16/f16) chunk
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
-                                (const float*)x, scale_shift, (const float*)residual, relu, M, (int)C, (float*)y),
+                                (const float*)x, scale_shift, (const float*)residual, relu, M, (int)C, (float*)y,
+                                (uint8_t*)nullptr),
              hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, (const unsigned short*)residual, relu, M,
-                                (int)C, (unsigned short*)y));
+                                (int)C, (unsigned short*)y, mask_out));
   CREID_LAUNCH_RET();
+}
+
+int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M, int64_t C,
+                     int dtype, void* y, void* stream) {
+  return creid_bn2d_apply_mask(x, scale_shift, residual, relu, M, C, dtype, y, nullptr, stream);
 }
 
 int64_t creid_bn2d_bwd_rows(int64_t M) { int64_t r = (M + 127) / 128; return r < 1 ? 1 : r; }
 
-int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
-                   const float* gamma, int64_t M, int64_t C, int dtype, float* partial, int partial_ready, float* sums,
-                   float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out, void* stream) {
+int creid_bn2d_bwd_mask(const void* x, const void* g, const void* act, const uint8_t* mask, const float* mean,
+                        const float* invstd, const float* gamma, int64_t M, int64_t C, int dtype, float* partial,
+                        int partial_ready, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out,
+                        void* stream) {
   CREID_CHECK_ARG(x && g && mean && invstd && partial && sums && dx && M > 0 && C > 0 && C % 8 == 0);
+  if (mask && dtype == CREID_F32) return CREID_E_DTYPE;
   const int rows = (int)creid_bn2d_bwd_rows(M);
   hipStream_t s = as_stream(stream);
   if (!partial_ready)
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
-                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 128, partial),
+                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 128, partial, (const uint8_t*)nullptr),
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
-                                invstd, M, (int)C, 128, partial));
+                                invstd, M, (int)C, 128, partial, mask));
   if (!fin_dry(2))
   hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, rows, (int)C,
                      (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, sums, M, (int)C,
-                                (float*)dx, (float*)gm_out),
+                                (float*)dx, (float*)gm_out, (const uint8_t*)nullptr),
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, sums, M,
-                                (int)C, (unsigned short*)dx, (unsigned short*)gm_out));
+                                (int)C, (unsigned short*)dx, (unsigned short*)gm_out, mask));
   CREID_LAUNCH_RET();
+}
+
+int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
+                   const float* gamma, int64_t M, int64_t C, int dtype, float* partial, int partial_ready, float* sums,
+                   float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out, void* stream) {
+  return creid_bn2d_bwd_mask(x, g, act, nullptr, mean, invstd, gamma, M, C, dtype, partial, partial_ready, sums, dgamma_accum,
+                             dbeta_accum, dx, gm_out, stream);
 }
 
 int creid_maxpool3x3s2_fwd(const void* x, int64_t B, int64_t H, int64_t W, int64_t C, int dtype, void* y, uint8_t* idx,

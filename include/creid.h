@@ -291,11 +291,12 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
  * creid_conv2d_wgrad_partials call filled wred_ws; the first workgroups of this launch sum those partials into
  * wred_dw (OIHW fp32; wred_accumulate as in creid_conv2d_wgrad_nhwc) while the rest compute gradient tiles, so the
  * 5-25 us stand-alone reduce launch per layer disappears.  In fp32 parity mode the reduction runs as its own launch
- * first (same result). */
+ * first (same result).  bn_mask != NULL: the ReLU mask of that BatchNorm's output as bits (creid_bn2d_apply_mask) --
+ * one byte per 8 channels is read instead of the 16 bytes of bn_act. */
 int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
                                   const void* add_src, int add_src_stride, const void* bn_x, const void* bn_act,
-                                  const float* bn_mean, const float* bn_invstd, float* bn_partial,
-                                  int64_t bn_stat_image_rows, const creid_conv_desc* wred_desc, float* wred_dw,
+                                  const uint8_t* bn_mask, const float* bn_mean, const float* bn_invstd,
+                                  float* bn_partial, int64_t bn_stat_image_rows, const creid_conv_desc* wred_desc, float* wred_dw,
                                   int wred_accumulate, const void* wred_ws, size_t wred_ws_bytes, int dtype,
                                   void* stream);
 /* weight gradient into the fp32 OIHW tensor (the reference's nn.Parameter layout), optionally
@@ -349,10 +350,20 @@ int64_t creid_col_stats_rows(int64_t M);
 int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* partial, void* stream);
 int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M,
                      int64_t C, int dtype, void* y, void* stream);
+/* creid_bn2d_apply that also writes the ReLU mask the backward needs as BITS: mask_out (nullable; bf16 / f16 only) =
+ * uint8[M * C / 8], bit k of byte i = (y[8 i + k] > 0).  The backward then reads 1 byte per 8 channels instead of
+ * re-reading y (modelling/backbones/resnet.py:71,75,85 -- the three ReLUs of a Bottleneck). */
+int creid_bn2d_apply_mask(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M,
+                          int64_t C, int dtype, void* y, uint8_t* mask_out, void* stream);
 int64_t creid_bn2d_bwd_rows(int64_t M);
 int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
                    const float* gamma, int64_t M, int64_t C, int dtype, float* partial, int partial_ready,
                    float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out, void* stream);
+/* creid_bn2d_bwd with the ReLU mask as bits (mask != NULL: creid_bn2d_apply_mask's output, act is then not read). */
+int creid_bn2d_bwd_mask(const void* x, const void* g, const void* act, const uint8_t* mask, const float* mean,
+                        const float* invstd, const float* gamma, int64_t M, int64_t C, int dtype, float* partial,
+                        int partial_ready, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx,
+                        void* gm_out, void* stream);
 
 /* IBN of ResNet50-IBN-a (modelling/backbones/resnet_ibn_a.py:18-32): channels [0, c_in) InstanceNorm2d
  * (affine, per-(image, channel) statistics over H*W, eps 1e-5, no running stats), channels [c_in, C)

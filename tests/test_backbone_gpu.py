@@ -469,3 +469,65 @@ def test_non_power_of_two_feature_maps_vs_oracle(arch, H, W, B):
     for n in ("layer4.2.conv3.weight", "layer3.0.conv2.weight", "layer2.0.downsample.0.weight", "layer1.0.conv1.weight",
               "conv1.weight", "layer4.0.bn2.weight"):
         close(n)
+
+
+def test_relu_bitmask_kernels_match_activation_path():
+    """creid_bn2d_apply_mask writes bit k of byte i = (y[8i+k] > 0); the BatchNorm backward fed with those bits gives
+    bit-identical dx / gm / dgamma / dbeta to the one that re-reads the activation."""
+    from centroids_reid_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(5)
+    M, Cc = 4096 + 128, 256                       # not a multiple of the elementwise kernels' stride
+    x = torch.randn((M, Cc), device="cuda").to(torch.bfloat16)
+    res = torch.randn((M, Cc), device="cuda").to(torch.bfloat16)
+    ss = torch.stack([torch.rand(Cc, device="cuda") + 0.5, torch.randn(Cc, device="cuda") * 0.3]).contiguous()
+    y = torch.empty_like(x); y2 = torch.empty_like(x)
+    mask = torch.zeros(M * Cc // 8, dtype=torch.uint8, device="cuda")
+    L.check(lib.creid_bn2d_apply_mask(L.ptr(x), L.ptr(ss), L.ptr(res), 1, M, Cc, L.BF16, L.ptr(y), L.ptr(mask), L.stream()), "apply_mask")
+    L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(ss), L.ptr(res), 1, M, Cc, L.BF16, L.ptr(y2), L.stream()), "apply")
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    bits = (y.float() > 0).view(M * Cc // 8, 8).to(torch.int32)
+    want = (bits << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(mask, want)
+    assert 0.2 < float(bits.float().mean()) < 0.8
+    # the bit mask refuses fp32 tensors (it is defined per 8-channel chunk)
+    xf = x.float(); yf = torch.empty_like(xf)
+    assert lib.creid_bn2d_apply_mask(L.ptr(xf), L.ptr(ss), None, 1, M, Cc, L.F32, L.ptr(yf), L.ptr(mask), L.stream()) == -2   # CREID_E_DTYPE
+
+    g = torch.randn((M, Cc), device="cuda").to(torch.bfloat16)
+    mean, invstd = torch.randn(Cc, device="cuda") * 0.1, torch.rand(Cc, device="cuda") + 0.5
+    gamma = torch.rand(Cc, device="cuda") + 0.5
+    rows = lib.creid_bn2d_bwd_rows(M)
+    outs = []
+    for use_mask in (False, True):
+        part = torch.empty((rows, 2, Cc), device="cuda"); sums = torch.empty((3, Cc), device="cuda")
+        dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        dx, gm = torch.empty_like(x), torch.empty_like(x)
+        L.check(lib.creid_bn2d_bwd_mask(L.ptr(x), L.ptr(g), None if use_mask else L.ptr(y), L.ptr(mask) if use_mask else None,
+                                        L.ptr(mean), L.ptr(invstd), L.ptr(gamma), M, Cc, L.BF16, L.ptr(part), 0, L.ptr(sums),
+                                        L.ptr(dg), L.ptr(db), L.ptr(dx), L.ptr(gm), L.stream()), "bwd_mask")
+        outs.append((dx.view(torch.int16).clone(), gm.view(torch.int16).clone(), dg.clone(), db.clone(), part.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@_NEEDS_DMA
+@pytest.mark.parametrize("arch", ["resnet50", "resnet50_ibn_a"])
+def test_relu_bitmask_schedule_is_bit_identical(arch):
+    """Whole backward with the ReLU masks carried as bits (default) against the schedule that re-reads the activations
+    (CREID_RELU_BITMASK=0 / eng.relu_bitmask = False): same masks, same arithmetic -> identical gradients."""
+    from oracle import backbone_oracle as bo
+    from centroids_reid_amd import ops
+    x = bo.synthetic_images(4, 128, 64, seed=23).cuda()
+    coef = torch.from_numpy(np.random.default_rng(6).standard_normal((4, 2048)).astype(np.float32)).cuda()
+    grads = []
+    for bits in (True, False):
+        net, eng, _ = _build(arch, torch.bfloat16)
+        eng.relu_bitmask = bits
+        _, feat = eng.forward(x, training=True)
+        if bits:
+            assert any(getattr(s["a3"], "_relu_mask", None) is not None for s in eng.saved["blocks"])
+        eng.backward(coef)
+        grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
