@@ -82,7 +82,7 @@ SIGNATURES = {
     "creid_bn2d_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
     "creid_bn2d_bwd_mask": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
     "creid_conv2d_dgrad_bnred_nhwc": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p]),
-    "creid_conv2d_dgrad_fused_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _p, _i64, _p, _p, C.c_int, _p, _sz,
+    "creid_conv2d_dgrad_fused_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, C.c_int, _p, _sz,
                                                 C.c_int, _p]),
     "creid_ibn_rows_per_image": (_i64, [_i64]),
     "creid_ibn_fwd": (C.c_int, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, C.c_int, _f32, _f32, C.c_int, C.c_int,

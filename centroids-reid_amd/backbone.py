@@ -254,6 +254,7 @@ class BackboneEngine:
         # training forward writes each ReLU's mask as bits (1 byte per 8 channels); the BatchNorm backward and the fused
         # data-gradient epilogue read that instead of re-reading the activation (CREID_RELU_BITMASK=0: read the activation)
         self.relu_bitmask = dtype == torch.bfloat16 and os.environ.get("CREID_RELU_BITMASK", "1") == "1"
+        self.drop_gm = os.environ.get("CREID_DROP_GM", "1") == "1"     # A/B knob: 0 = bn3's backward still writes the masked copy
         self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
         self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
@@ -476,8 +477,9 @@ class BackboneEngine:
             p.grad = torch.zeros_like(p)
         return p.grad
 
-    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False, part=None):
-        """BN backward; `part` = column-reduction partials already produced by a fused dgrad epilogue."""
+    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False, part=None, mask=None):
+        """BN backward; `part` = column-reduction partials already produced by a fused dgrad epilogue; `mask` = ReLU bits
+        to apply to g (default: the ones that travel with `act`)."""
         lib, st = L.lib(), L.stream()
         rows = lib.creid_bn2d_bwd_rows(M)
         ready = 1 if part is not None else 0
@@ -489,7 +491,8 @@ class BackboneEngine:
         bn = u.bn
         dgam = self._grad_of(bn.weight) if bn.weight.requires_grad else None
         dbet = self._grad_of(bn.bias) if bn.bias.requires_grad else None
-        mask = getattr(act, "_relu_mask", None) if act is not None else None
+        if mask is None and act is not None:
+            mask = getattr(act, "_relu_mask", None)
         L.check(lib.creid_bn2d_bwd_mask(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mask), L.ptr(mean), L.ptr(invstd),
                                         L.ptr(bn.weight), M, u.cout, self.dt, L.ptr(part), ready, L.ptr(sums), L.ptr(dgam),
                                         L.ptr(dbet), L.ptr(dx), L.ptr(gm), st), "bn2d_bwd")
@@ -545,7 +548,7 @@ class BackboneEngine:
             L.check(lib.creid_conv2d_wgrad_reduce(C.byref(d), L.ptr(gw), 1, L.ptr(ws), nbytes, self.dt, L.stream()),
                     "conv2d_wgrad_reduce")
 
-    def _dgrad(self, u, dy, B, H, W, add_src=None, bnred=None, stat_image_rows=0, add_src_stride=1):
+    def _dgrad(self, u, dy, B, H, W, add_src=None, bnred=None, stat_image_rows=0, add_src_stride=1, add_mask=None):
         """Data gradient.  bnred = (x, act, mean, invstd) of the BN layer that consumes the result: its column
         reduction is fused into the epilogue (bf16) and the partials are returned.  stat_image_rows = H*W when
         mean / invstd are per-(image, channel) (IBN), 0 for BatchNorm."""
@@ -554,13 +557,13 @@ class BackboneEngine:
         M = B * H * W
         dx = self._empty(M, u.cin)
         fuse_bn = bnred is not None and self.fuse_bn_reduce
-        if self._wred_pending or fuse_bn:
+        if self._wred_pending or fuse_bn or add_mask is not None:
             rd, rgw, rws, rbytes = self._wred_pending.pop(0) if self._wred_pending else (None, None, None, 0)
             x, act, mean, invstd = bnred if fuse_bn else (None, None, None, None)
             mask = getattr(act, "_relu_mask", None) if act is not None else None
             part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32) if fuse_bn else None
             L.check(lib.creid_conv2d_dgrad_fused_nhwc(C.byref(d), L.ptr(dy), L.ptr(u.w_crsk), L.ptr(dx), L.ptr(add_src),
-                                                      add_src_stride, L.ptr(x), L.ptr(act), L.ptr(mask), L.ptr(mean),
+                                                      add_src_stride, L.ptr(add_mask), L.ptr(x), L.ptr(act), L.ptr(mask), L.ptr(mean),
                                                       L.ptr(invstd), L.ptr(part), stat_image_rows if fuse_bn else 0,
                                                       C.byref(rd) if rd is not None else None, L.ptr(rgw), 1,
                                                       L.ptr(rws), rbytes, self.dt, st), "conv2d_dgrad_fused")
@@ -587,7 +590,13 @@ class BackboneEngine:
             b, s = blocks[bi]
             prev = blocks[bi - 1] if bi > 0 else None          # the block whose output gradient we produce
             M3 = B * s["h2"] * s["w2"]
-            dx3, gm = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, want_gm=True, part=part3)
+            # the block's incoming gradient g is masked by the final ReLU on three paths (bn3, the residual add, the
+            # downsample BN).  With the mask as bits every consumer applies it itself and the masked copy `gm` is never
+            # written; otherwise bn3's backward writes it once.
+            m3 = getattr(s["a3"], "_relu_mask", None) if (self.fuse_bn_reduce and self.drop_gm) else None
+            dx3, gm = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, want_gm=m3 is None, part=part3)
+            if m3 is not None:
+                gm = g
             self._wgrad(b["c3"], s["a2"], dx3, B, s["h2"], s["w2"])
             da2, p2 = self._dgrad(b["c3"], dx3, B, s["h2"], s["w2"], bnred=(s["x2"], s["a2"], s["m2"], s["i2"]))
             dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3, part=p2)
@@ -606,7 +615,7 @@ class BackboneEngine:
             self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"])
             nxt = None if prev is None else (prev[1]["x3"], prev[1]["a3"], prev[1]["m3"], prev[1]["i3"])
             if b["ds"] is not None:
-                dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3)
+                dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3, mask=m3)
                 self._wgrad(b["ds"], s["a_in"], dxd, B, s["hin"], s["win"])
                 dsu = b["ds"]
                 if (dsu.stride == 2 and dsu.k == 1 and nxt is not None and self.fuse_bn_reduce
@@ -621,7 +630,7 @@ class BackboneEngine:
                     tmp, _ = self._dgrad(dsu, dxd, B, s["hin"], s["win"])
                     g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt)
             else:
-                g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm, bnred=nxt)
+                g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm, bnred=nxt, add_mask=m3)
             if self.on_group_done is not None and bi in self._group_first:
                 assert not self._wred_pending            # the layer's last split reduction rode on the launch above
                 self.on_group_done(self._group_first[bi])

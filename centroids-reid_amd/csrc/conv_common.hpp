@@ -28,6 +28,9 @@ struct IGemmGeom {
   int parity;               // transposed stride-2 (data gradient): GEMM rows are enumerated parity-class major --
                             // row m = class*(M/4) + (b, y/2, x/2), class = (y&1)*2 + (x&1) -- so a 128-row tile holds
                             // one class and only that class's taps (1, 2, 2 or 4 of 9 for 3x3) are visited
+  const unsigned char* add_mask;   // nullable (full-resolution add_src only): bit mask applied to add_src before the add,
+                                   // one byte per 8 channels -- the residual-branch gradient is then the UNMASKED incoming
+                                   // gradient plus the ReLU bits, and no masked copy has to be written and re-read
 };
 
 static inline void igemm_finish_geom(IGemmGeom& g) {
@@ -35,6 +38,7 @@ static inline void igemm_finish_geom(IGemmGeom& g) {
   g.inv_ow = 1.0f / (float)g.OW;
   g.add_compact = 0;
   g.parity = 0;
+  g.add_mask = nullptr;
 }
 
 // Source pixel of output row (oy, ox) under tap (r, s); returns false when it falls outside.

@@ -535,12 +535,15 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
         }
         if (has) {
           const uint4 a = *reinterpret_cast<const uint4*>(add_src + aoff);
+          const unsigned am = g.add_mask ? (unsigned)g.add_mask[aoff >> 3] : 0xffu;
           unsigned* vw = &v.x; const unsigned* aw = &a.x;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
-            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
-            vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+            const float alo = ((am >> (2 * q)) & 1u) ? __uint_as_float(aw[q] << 16) : 0.f;
+            const float ahi = ((am >> (2 * q + 1)) & 1u) ? __uint_as_float(aw[q] & 0xffff0000u) : 0.f;
+            const float lo = __uint_as_float(vw[q] << 16) + alo;
+            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + ahi;
+            vw[q] = f32x2_to_bf16x2_bits(lo, hi);
           }
         }
       }
@@ -907,12 +910,15 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
         }
         if (has) {
           const uint4 a = *reinterpret_cast<const uint4*>(add_src + aoff);
+          const unsigned am = g.add_mask ? (unsigned)g.add_mask[aoff >> 3] : 0xffu;
           unsigned* vw = &v.x; const unsigned* aw = &a.x;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
-            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
-            vw[q] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+            const float alo = ((am >> (2 * q)) & 1u) ? __uint_as_float(aw[q] << 16) : 0.f;
+            const float ahi = ((am >> (2 * q + 1)) & 1u) ? __uint_as_float(aw[q] & 0xffff0000u) : 0.f;
+            const float lo = __uint_as_float(vw[q] << 16) + alo;
+            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + ahi;
+            vw[q] = f32x2_to_bf16x2_bits(lo, hi);
           }
         }
       }
@@ -1194,8 +1200,8 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
                         default: CREID_DMA_LAUNCH(64, 2); break; }
     }
 #undef CREID_DMA_LAUNCH
-  } else if (bnred.x) {
-    return CREID_E_DTYPE;          // the fused reduction exists only in the bf16 LDS-DMA kernel
+  } else if (bnred.x || g.add_mask) {
+    return CREID_E_DTYPE;          // the fused reduction / masked add exist only in the bf16 LDS-DMA kernels
   } else if (wred.ws && wgrad_reduce_job_launch(wred, s) != 0) {
     return (int)hipGetLastError();
   } else if (dtype == CREID_BF16) {
@@ -1297,8 +1303,8 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
  * this launch sum the partials into wred_dw).  Where the fused kernel does not apply (fp32 parity mode, stem) the
  * reduction runs as its own launch first -- same result. */
 int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
-                                  const void* add_src, int add_src_stride, const void* bn_x, const void* bn_act,
-                                  const uint8_t* bn_mask, const float* bn_mean, const float* bn_invstd, float* bn_partial,
+                                  const void* add_src, int add_src_stride, const uint8_t* add_mask, const void* bn_x,
+                                  const void* bn_act, const uint8_t* bn_mask, const float* bn_mean, const float* bn_invstd, float* bn_partial,
                                   int64_t bn_stat_image_rows, const creid_conv_desc* wred_desc, float* wred_dw,
                                   int wred_accumulate, const void* wred_ws, size_t wred_ws_bytes, int dtype, void* stream) {
   int rc = check_desc(d);
@@ -1310,6 +1316,7 @@ int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, cons
   if (add_src_stride == 2 && (!add_src || d->in_h % 2 || d->in_w % 2)) return CREID_E_SHAPE;
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
   if (bn_x && (dtype != CREID_BF16 || !use_dma)) return CREID_E_DTYPE;
+  if (add_mask && (!add_src || add_src_stride != 1 || dtype != CREID_BF16 || !use_dma)) return CREID_E_ARG;
   WRedJob job{};
   bool have_job = false;
   if (wred_desc) {
@@ -1325,6 +1332,7 @@ int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, cons
   igemm_finish_geom(g);
   static const int prefetch = [] { const char* e = getenv("CREID_BNRED_PREFETCH"); return e ? atoi(e) : 1; }();
   g.add_compact = add_src_stride == 2;
+  g.add_mask = add_mask;
   BnRedArgs br{bn_x, bn_mask ? nullptr : bn_act, bn_mean, bn_invstd, bn_partial, prefetch, (int)(bn_stat_image_rows / 128), bn_mask};
   if (!bn_x) br = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
   return launch_igemm(g, dy, w_crsk, dx, add_src, nullptr, dtype, as_stream(stream), br, have_job ? &job : nullptr);

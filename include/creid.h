@@ -292,10 +292,12 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
  * wred_dw (OIHW fp32; wred_accumulate as in creid_conv2d_wgrad_nhwc) while the rest compute gradient tiles, so the
  * 5-25 us stand-alone reduce launch per layer disappears.  In fp32 parity mode the reduction runs as its own launch
  * first (same result).  bn_mask != NULL: the ReLU mask of that BatchNorm's output as bits (creid_bn2d_apply_mask) --
- * one byte per 8 channels is read instead of the 16 bytes of bn_act. */
+ * one byte per 8 channels is read instead of the 16 bytes of bn_act.  add_mask != NULL (add_src_stride 1, bf16): add_src
+ * is multiplied by those ReLU bits before the add -- the residual branch then takes the block's UNMASKED incoming
+ * gradient, and the masked copy creid_bn2d_bwd would write through gm_out is never materialised. */
 int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
-                                  const void* add_src, int add_src_stride, const void* bn_x, const void* bn_act,
-                                  const uint8_t* bn_mask, const float* bn_mean, const float* bn_invstd,
+                                  const void* add_src, int add_src_stride, const uint8_t* add_mask, const void* bn_x,
+                                  const void* bn_act, const uint8_t* bn_mask, const float* bn_mean, const float* bn_invstd,
                                   float* bn_partial, int64_t bn_stat_image_rows, const creid_conv_desc* wred_desc, float* wred_dw,
                                   int wred_accumulate, const void* wred_ws, size_t wred_ws_bytes, int dtype,
                                   void* stream);
