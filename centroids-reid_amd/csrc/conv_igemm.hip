@@ -1169,7 +1169,8 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
         gp.parity = 1;
       int ws_stages = use_ws == 2 ? ws_stages_env() : ((bn == 64 && g.K >= ws_min_k) ? 3 : 2);
       if (tuned_stages && use_ws != 2) ws_stages = tuned_stages;
-      if (ws_stages == 4 && bn == 128) ws_stages = 3;               // 4 x 32 KB does not leave room for the C staging
+      // 4 x 32 KB at BN = 128 is one workgroup per CU (the C staging reuses the ring): only on request of a measured plan
+      if (ws_stages == 4 && bn == 128 && !(tuned_stages == 4 && use_ws != 2)) ws_stages = 3;
       const dim3 block_ws(512);
       const dim3 grid_ws((unsigned)(tiles_m * tiles_n + (wred.ws ? wred.nblocks : 0)));
 #define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
