@@ -254,6 +254,10 @@ class BackboneEngine:
         # training forward writes each ReLU's mask as bits (1 byte per 8 channels); the BatchNorm backward and the fused
         # data-gradient epilogue read that instead of re-reading the activation (CREID_RELU_BITMASK=0: read the activation)
         self.relu_bitmask = dtype == torch.bfloat16 and os.environ.get("CREID_RELU_BITMASK", "1") == "1"
+        self.stem_fuse_pool = os.environ.get("CREID_STEM_FUSE", "1") == "1"    # bn1 + maxpool in one pass (38 vs 51 us)
+        # the backward counterpart (max-pool gradient gathered inside the BN backward passes) is correct but slower:
+        # the gather is VALU-bound and runs twice (146 vs 116 us, tools/debug/stem_tail_probe.py) -- off by default
+        self.stem_fuse_pool_bwd = os.environ.get("CREID_STEM_FUSE_BWD", "0") == "1"
         self.drop_gm = os.environ.get("CREID_DROP_GM", "1") == "1"     # A/B knob: 0 = bn3's backward still writes the masked copy
         self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
@@ -439,11 +443,24 @@ class BackboneEngine:
         part = self._empty(rows * 2, 64, dtype=torch.float32) if training else None
         L.check(lib.creid_stem_conv_fwd(B, H, W, L.ptr(xpad), L.ptr(self.stem.w_krsc), L.ptr(x0), L.ptr(part), self.dt, st),
                 "stem_conv_fwd")
-        y0, mean0, invstd0 = self._bn_tail(self.stem, x0, part, rows, M0, training, self.net.stem_relu, None)
         H2, W2 = H1 // 2, W1 // 2
         p0 = self._empty(B * H2 * W2, 64)
         idx0 = self._empty(B * H2 * W2, 64, dtype=torch.uint8)
-        L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, self.dt, L.ptr(p0), L.ptr(idx0), st), "maxpool_fwd")
+        if self.stem_fuse_pool and not self.net.stem_relu:
+            # bn1 + maxpool in one pass over the raw conv output: the normalised 64-channel full-resolution tensor is read
+            # by nothing else (no stem ReLU -> the backward needs no mask of it either) and is never written
+            bn = self.stem.bn
+            mean0 = self._empty(64, dtype=torch.float32); invstd0 = self._empty(64, dtype=torch.float32)
+            ss = self._empty(2, 64, dtype=torch.float32)
+            L.check(lib.creid_bn2d_finalize(L.ptr(part), rows, 64, M0, L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                            1 if training else 0, bn.momentum, bn.eps, L.ptr(bn.weight), L.ptr(bn.bias),
+                                            L.ptr(mean0), L.ptr(invstd0), L.ptr(ss), st), "bn2d_finalize")
+            L.check(lib.creid_bn2d_apply_maxpool3x3s2(L.ptr(x0), L.ptr(ss), 0, B, H1, W1, 64, self.dt, L.ptr(p0), L.ptr(idx0),
+                                                      st), "bn2d_apply_maxpool")
+            y0 = None
+        else:
+            y0, mean0, invstd0 = self._bn_tail(self.stem, x0, part, rows, M0, training, self.net.stem_relu, None)
+            L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, self.dt, L.ptr(p0), L.ptr(idx0), st), "maxpool_fwd")
         sv["stem"] = (xpad, x0, y0, mean0, invstd0, idx0)
         a, h, w = p0, H2, W2
         sv["blocks"] = []
@@ -638,9 +655,21 @@ class BackboneEngine:
         xpad, x0, y0, mean0, invstd0, idx0 = sv["stem"]
         H, W = sv["H"], sv["W"]
         H1, W1 = H // 2, W // 2
-        dy0 = self._empty(B * H1 * W1, 64)
-        L.check(lib.creid_maxpool3x3s2_bwd(L.ptr(g), L.ptr(idx0), B, H1, W1, 64, self.dt, L.ptr(dy0), st), "maxpool_bwd")
-        dx0, _ = self._bn_bwd(self.stem, x0, dy0, y0 if self.net.stem_relu else None, mean0, invstd0, B * H1 * W1)
+        if self.stem_fuse_pool_bwd and not self.net.stem_relu:
+            # the max-pool gradient is gathered inside the BatchNorm backward passes, the full-resolution dy0 is never written
+            bn, M0 = self.stem.bn, B * H1 * W1
+            part0 = self._empty(lib.creid_bn2d_bwd_rows(M0) * 2, 64, dtype=torch.float32)
+            sums0 = self._empty(3, 64, dtype=torch.float32)
+            dx0 = self._empty(M0, 64)
+            dgam = self._grad_of(bn.weight) if bn.weight.requires_grad else None
+            dbet = self._grad_of(bn.bias) if bn.bias.requires_grad else None
+            L.check(lib.creid_bn2d_bwd_pooled(L.ptr(x0), L.ptr(g), L.ptr(idx0), B, H1, W1, None, L.ptr(mean0), L.ptr(invstd0),
+                                              L.ptr(bn.weight), 64, self.dt, L.ptr(part0), L.ptr(sums0), L.ptr(dgam), L.ptr(dbet),
+                                              L.ptr(dx0), st), "bn2d_bwd_pooled")
+        else:
+            dy0 = self._empty(B * H1 * W1, 64)
+            L.check(lib.creid_maxpool3x3s2_bwd(L.ptr(g), L.ptr(idx0), B, H1, W1, 64, self.dt, L.ptr(dy0), st), "maxpool_bwd")
+            dx0, _ = self._bn_bwd(self.stem, x0, dy0, y0 if self.net.stem_relu else None, mean0, invstd0, B * H1 * W1)
         if self.stem.conv.weight.requires_grad:
             with (self._fork_side(xpad, dx0) if self.wgrad_stream else contextlib.nullcontext()):
                 nbytes = lib.creid_stem_conv_wgrad_workspace_bytes(B, H, W, self.dt)

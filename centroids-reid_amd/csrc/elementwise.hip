@@ -14,6 +14,7 @@ template <> struct Vec16<float> {
   static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
 };
 template <> struct Vec16<unsigned short> {
   static constexpr int N = 8;
@@ -26,9 +27,10 @@ template <> struct Vec16<unsigned short> {
   static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
     unsigned w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = f32x2_to_bf16x2_bits(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
+  static __device__ __forceinline__ float rnd(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }   // value as stored
 };
 
 // ------------------------------------------------------------------ BN statistics finalize
@@ -194,6 +196,47 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x
   }
 }
 
+// Gradient of the max-pool at input pixel (b, iy, ix), channels [cc*V, cc*V+V): the (up to four) windows that contain the
+// pixel, each contributing where its saved argmax tap points here -- maxpool_bwd_kernel's gather as a device function, so
+// that the stem's BatchNorm backward can consume the pooled gradient without the full-resolution copy being written.
+template <typename T>
+__device__ __forceinline__ void pool_grad_gather(const T* __restrict__ dy, const uint8_t* __restrict__ idx, int b, int iy,
+                                                 int ix, int cc, int OH, int OW, int cpr, float (&acc)[Vec16<T>::N]) {
+  constexpr int V = Vec16<T>::N;
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int t = iy + 1 - r;
+    if (t < 0 || (t & 1)) continue;
+    const int oy = t >> 1;
+    if (oy >= OH) continue;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int u = ix + 1 - s;
+      if (u < 0 || (u & 1)) continue;
+      const int ox = u >> 1;
+      if (ox >= OW) continue;
+      const int64_t o = ((((int64_t)b * OH + oy) * OW + ox) * cpr + cc) * V;
+      float g[V];
+      Vec16<T>::load(dy + o, g);
+      uint8_t tap[V];
+      if constexpr (V == 8) *reinterpret_cast<uint2*>(tap) = *reinterpret_cast<const uint2*>(idx + o);
+      else *reinterpret_cast<unsigned*>(tap) = *reinterpret_cast<const unsigned*>(idx + o);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += (tap[k] == (uint8_t)(r * 3 + s)) ? g[k] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = Vec16<T>::rnd(acc[k]);     // the value maxpool_bwd_kernel would have stored
+}
+
+struct PoolGrad {              // non-null dy: the BatchNorm backward's incoming gradient is max-pool-backward(dy, idx)
+  const void* dy;
+  const uint8_t* idx;
+  int H, W;                    // the BatchNorm tensor's spatial size (pool input)
+};
+
 // ------------------------------------------------------------------ BN backward
 // dy = g * (act > 0 if act) ; partial[(blockIdx.y)][2][C] = (sum dy, sum dy * xhat)
 template <typename T>
@@ -202,7 +245,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, int64_t M, int C,
                                                               int rows_per_block, float* __restrict__ partial,
-                                                              const uint8_t* __restrict__ mask) {
+                                                              const uint8_t* __restrict__ mask, PoolGrad pg) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][256 * V];
   const int cpr = C / V, cw = cpr < 32 ? cpr : 32, nrl = 256 / cw;
@@ -223,7 +266,12 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
     for (int64_t r = r0 + rl; r < r1; r += nrl) {
       float xv[V], gv[V];
       Vec16<T>::load(x + r * C + c0, xv);
-      Vec16<T>::load(g + r * C + c0, gv);
+      if (pg.dy) {                                 // g = max-pool backward of the pooled gradient, gathered here
+        const int hw = pg.H * pg.W, bb = (int)(r / hw), rem = (int)(r - (int64_t)bb * hw);
+        pool_grad_gather<T>(reinterpret_cast<const T*>(pg.dy), pg.idx, bb, rem / pg.W, rem % pg.W, c0 / V, pg.H / 2, pg.W / 2, cpr, gv);
+      } else {
+        Vec16<T>::load(g + r * C + c0, gv);
+      }
       if (mask) {                                  // ReLU mask as bits (bn2d_apply_kernel's mask_out), 8 channels per byte
         const unsigned m = mask[(r * C + c0) / V];
 #pragma unroll
@@ -310,7 +358,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict
                                                              const T* __restrict__ act,
                                                              const float* __restrict__ coef, int64_t M, int C,
                                                              T* __restrict__ dx, T* __restrict__ gm_out,
-                                                             const uint8_t* __restrict__ mask) {
+                                                             const uint8_t* __restrict__ mask, PoolGrad pg) {
   constexpr int V = Vec16<T>::N;
   const int cpr = C / V;
   const int64_t total = M * cpr, nthreads = (int64_t)gridDim.x * 256;
@@ -329,7 +377,14 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict
   for (int64_t i = gtid; i < total; i += nthreads) {
     float xv[V], gv[V];
     Vec16<T>::load(x + i * V, xv);
-    Vec16<T>::load(g + i * V, gv);
+    if (pg.dy) {
+      const int64_t r = i / cpr;
+      const int hw = pg.H * pg.W, bb = (int)(r / hw), rem = (int)(r - (int64_t)bb * hw);
+      pool_grad_gather<T>(reinterpret_cast<const T*>(pg.dy), pg.idx, bb, rem / pg.W, rem % pg.W, (int)(i - r * cpr), pg.H / 2,
+                          pg.W / 2, cpr, gv);
+    } else {
+      Vec16<T>::load(g + i * V, gv);
+    }
     if (mask) {
       const unsigned m = mask[i];
 #pragma unroll
@@ -376,6 +431,51 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
           for (int k = 0; k < V; ++k)
             if (v[k] > best[k]) { best[k] = v[k]; bi[k] = (uint8_t)(r * 3 + s); }   // first max wins
+        }
+      }
+    Vec16<T>::store(y + i * V, best);
+    uint8_t* ip = idx + i * V;
+#pragma unroll
+    for (int k = 0; k < V; ++k) ip[k] = bi[k];
+  }
+}
+
+// BatchNorm apply (+ReLU) fused into the 3x3 s2 p1 max-pool of the stem (modelling/backbones/resnet.py:123-126: conv1 -> bn1
+// -> [relu] -> maxpool): the normalised [B, H, W, C] tensor is only ever read by the pool, so it is never written.  Every
+// tap value is rounded to the storage type before the comparison -- the pooled values and argmax taps are bit-identical to
+// bn2d_apply_kernel followed by maxpool_fwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift,
+                                                               int relu, int B, int H, int W, int C, T* __restrict__ y,
+                                                               uint8_t* __restrict__ idx) {
+  constexpr int V = Vec16<T>::N;
+  const int OH = H / 2, OW = W / 2, cpr = C / V;
+  const int64_t total = (int64_t)B * OH * OW * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    int64_t p = i / cpr;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    float sc[V], sh[V], best[V];
+    uint8_t bi[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sc[k] = scale_shift[cc * V + k]; sh[k] = scale_shift[C + cc * V + k]; best[k] = -INFINITY; bi[k] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iy = oy * 2 + r - 1, ix = ox * 2 + s - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          float v[V];
+          Vec16<T>::load(x + (((int64_t)b * H + iy) * W + ix) * C + cc * V, v);
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            float yv = fmaf(v[k], sc[k], sh[k]);
+            if (relu) yv = fmaxf(yv, 0.f);
+            yv = Vec16<T>::rnd(yv);
+            if (yv > best[k]) { best[k] = yv; bi[k] = (uint8_t)(r * 3 + s); }   // first max wins
+          }
         }
       }
     Vec16<T>::store(y + i * V, best);
@@ -654,31 +754,62 @@ int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residu
 
 int64_t creid_bn2d_bwd_rows(int64_t M) { int64_t r = (M + 127) / 128; return r < 1 ? 1 : r; }
 
-int creid_bn2d_bwd_mask(const void* x, const void* g, const void* act, const uint8_t* mask, const float* mean,
-                        const float* invstd, const float* gamma, int64_t M, int64_t C, int dtype, float* partial,
-                        int partial_ready, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out,
-                        void* stream) {
-  CREID_CHECK_ARG(x && g && mean && invstd && partial && sums && dx && M > 0 && C > 0 && C % 8 == 0);
+static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const uint8_t* mask, PoolGrad pg, const float* mean,
+                         const float* invstd, const float* gamma, int64_t M, int64_t C, int dtype, float* partial,
+                         int partial_ready, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out,
+                         void* stream) {
+  CREID_CHECK_ARG(x && (g || pg.dy) && mean && invstd && partial && sums && dx && M > 0 && C > 0 && C % 8 == 0);
   if (mask && dtype == CREID_F32) return CREID_E_DTYPE;
   const int rows = (int)creid_bn2d_bwd_rows(M);
   hipStream_t s = as_stream(stream);
   if (!partial_ready)
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
-                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 128, partial, (const uint8_t*)nullptr),
+                                (const float*)x, (const float*)g, (const float*)act, mean, invstd, M, (int)C, 128, partial,
+                                (const uint8_t*)nullptr, pg),
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
-                                invstd, M, (int)C, 128, partial, mask));
+                                invstd, M, (int)C, 128, partial, mask, pg));
   if (!fin_dry(2))
   hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, rows, (int)C,
                      (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, sums, M, (int)C,
-                                (float*)dx, (float*)gm_out, (const uint8_t*)nullptr),
+                                (float*)dx, (float*)gm_out, (const uint8_t*)nullptr, pg),
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, sums, M,
-                                (int)C, (unsigned short*)dx, (unsigned short*)gm_out, mask));
+                                (int)C, (unsigned short*)dx, (unsigned short*)gm_out, mask, pg));
+  CREID_LAUNCH_RET();
+}
+
+int creid_bn2d_bwd_mask(const void* x, const void* g, const void* act, const uint8_t* mask, const float* mean,
+                        const float* invstd, const float* gamma, int64_t M, int64_t C, int dtype, float* partial,
+                        int partial_ready, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out,
+                        void* stream) {
+  CREID_CHECK_ARG(g);
+  return bn2d_bwd_impl(x, g, act, mask, PoolGrad{nullptr, nullptr, 0, 0}, mean, invstd, gamma, M, C, dtype, partial, partial_ready,
+                       sums, dgamma_accum, dbeta_accum, dx, gm_out, stream);
+}
+
+int creid_bn2d_bwd_pooled(const void* x, const void* dy_pooled, const uint8_t* idx, int64_t B, int64_t H, int64_t W,
+                          const void* act, const float* mean, const float* invstd, const float* gamma, int64_t C, int dtype,
+                          float* partial, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* stream) {
+  CREID_CHECK_ARG(dy_pooled && idx && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
+  return bn2d_bwd_impl(x, nullptr, act, nullptr, PoolGrad{dy_pooled, idx, (int)H, (int)W}, mean, invstd, gamma, B * H * W, C, dtype,
+                       partial, 0, sums, dgamma_accum, dbeta_accum, dx, nullptr, stream);
+}
+
+int creid_bn2d_apply_maxpool3x3s2(const void* x, const float* scale_shift, int relu, int64_t B, int64_t H, int64_t W, int64_t C,
+                                  int dtype, void* y, uint8_t* idx, void* stream) {
+  CREID_CHECK_ARG(x && scale_shift && y && idx && B > 0 && H > 0 && W > 0 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn_apply_maxpool_kernel<float>, dim3(ew_blocks(B * H * W * C / 16, 1)), dim3(256), 0, s,
+                                (const float*)x, scale_shift, relu, (int)B, (int)H, (int)W, (int)C, (float*)y, idx),
+             hipLaunchKernelGGL(bn_apply_maxpool_kernel<unsigned short>, dim3(ew_blocks(B * H * W * C / 32, 1)), dim3(256), 0, s,
+                                (const unsigned short*)x, scale_shift, relu, (int)B, (int)H, (int)W, (int)C, (unsigned short*)y,
+                                idx));
   CREID_LAUNCH_RET();
 }
 

@@ -388,6 +388,18 @@ int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* me
                   float* d_in_b, float* d_bn_w, float* d_bn_b, void* dx, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:98) NHWC, with the argmax tap saved for the backward. */
+/* The stem's tail without its full-resolution intermediates (modelling/backbones/resnet.py:123-126, conv1 -> bn1 -> [relu] ->
+ * maxpool): creid_bn2d_apply_maxpool3x3s2 = creid_bn2d_apply (no residual) + creid_maxpool3x3s2_fwd in one pass over the raw
+ * conv output x [B, H, W, C] -- the normalised tensor is never written; y [B, H/2, W/2, C], idx as creid_maxpool3x3s2_fwd;
+ * bit-identical to the two separate calls.  creid_bn2d_bwd_pooled = creid_maxpool3x3s2_bwd + creid_bn2d_bwd (no ReLU
+ * mask unless act is given) with the pool gradient gathered inside the BatchNorm passes: dy_pooled [B, H/2, W/2, C] and
+ * idx go in, the full-resolution gradient is never written; partial / sums as creid_bn2d_bwd; dx [B, H, W, C]. */
+int creid_bn2d_apply_maxpool3x3s2(const void* x, const float* scale_shift, int relu, int64_t B, int64_t H, int64_t W,
+                                  int64_t C, int dtype, void* y, uint8_t* idx, void* stream);
+int creid_bn2d_bwd_pooled(const void* x, const void* dy_pooled, const uint8_t* idx, int64_t B, int64_t H, int64_t W,
+                          const void* act, const float* mean, const float* invstd, const float* gamma, int64_t C,
+                          int dtype, float* partial, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx,
+                          void* stream);
 int creid_maxpool3x3s2_fwd(const void* x, int64_t B, int64_t H, int64_t W, int64_t C, int dtype, void* y,
                            uint8_t* idx, void* stream);
 int creid_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, int64_t B, int64_t H, int64_t W, int64_t C,

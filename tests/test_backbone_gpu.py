@@ -531,3 +531,66 @@ def test_relu_bitmask_schedule_is_bit_identical(arch):
         grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_stem_tail_fused_kernels_match_separate_passes(dtype):
+    """creid_bn2d_apply_maxpool3x3s2 == creid_bn2d_apply + creid_maxpool3x3s2_fwd and creid_bn2d_bwd_pooled ==
+    creid_maxpool3x3s2_bwd + creid_bn2d_bwd, bit for bit (pooled values, argmax taps, dx, dgamma, dbeta)."""
+    from centroids_reid_amd import _lib as L
+    lib = L.lib()
+    dt = L._DT[dtype]
+    torch.manual_seed(9)
+    B, H, W, Cc = 3, 24, 12, 64
+    M = B * H * W
+    x = (torch.randn((M, Cc), device="cuda") * 2).to(dtype)
+    ss = torch.stack([torch.randn(Cc, device="cuda"), torch.randn(Cc, device="cuda") * 0.3]).contiguous()   # negative scales too
+    for relu in (0, 1):
+        y = torch.empty_like(x)
+        L.check(lib.creid_bn2d_apply(L.ptr(x), L.ptr(ss), None, relu, M, Cc, dt, L.ptr(y), L.stream()), "apply")
+        p_ref = torch.empty((B * H * W // 4, Cc), device="cuda", dtype=dtype); i_ref = torch.empty((B * H * W // 4, Cc), device="cuda", dtype=torch.uint8)
+        L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y), B, H, W, Cc, dt, L.ptr(p_ref), L.ptr(i_ref), L.stream()), "pool")
+        p, i = torch.empty_like(p_ref), torch.empty_like(i_ref)
+        L.check(lib.creid_bn2d_apply_maxpool3x3s2(L.ptr(x), L.ptr(ss), relu, B, H, W, Cc, dt, L.ptr(p), L.ptr(i), L.stream()), "fused")
+        assert torch.equal(p.float(), p_ref.float()) and torch.equal(i, i_ref)
+    # backward: pooled gradient -> BatchNorm backward
+    g = torch.randn((B * H * W // 4, Cc), device="cuda").to(dtype)
+    mean, invstd = torch.randn(Cc, device="cuda") * 0.1, torch.rand(Cc, device="cuda") + 0.5
+    gamma = torch.rand(Cc, device="cuda") + 0.5
+    rows = lib.creid_bn2d_bwd_rows(M)
+    dy = torch.empty_like(x)
+    L.check(lib.creid_maxpool3x3s2_bwd(L.ptr(g), L.ptr(i_ref), B, H, W, Cc, dt, L.ptr(dy), L.stream()), "pool_bwd")
+    outs = []
+    for fused in (False, True):
+        part = torch.empty((rows, 2, Cc), device="cuda"); sums = torch.empty((3, Cc), device="cuda")
+        dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        dx = torch.empty_like(x)
+        if fused:
+            L.check(lib.creid_bn2d_bwd_pooled(L.ptr(x), L.ptr(g), L.ptr(i_ref), B, H, W, None, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), Cc, dt,
+                                              L.ptr(part), L.ptr(sums), L.ptr(dg), L.ptr(db), L.ptr(dx), L.stream()), "bwd_pooled")
+        else:
+            L.check(lib.creid_bn2d_bwd(L.ptr(x), L.ptr(dy), None, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), M, Cc, dt, L.ptr(part), 0,
+                                       L.ptr(sums), L.ptr(dg), L.ptr(db), L.ptr(dx), None, L.stream()), "bwd")
+        outs.append((dx.float().clone(), dg.clone(), db.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_stem_fusion_schedule_is_bit_identical(dtype):
+    """ResNet50 (no stem ReLU): forward features and every gradient with the fused stem tail equal the unfused schedule."""
+    from oracle import backbone_oracle as bo
+    x = bo.synthetic_images(4, 128, 64, seed=24).cuda()
+    coef = torch.from_numpy(np.random.default_rng(7).standard_normal((4, 2048)).astype(np.float32)).cuda()
+    res = []
+    for fuse in (True, False):
+        net, eng, _ = _build("resnet50", dtype)
+        eng.stem_fuse_pool = fuse
+        eng.stem_fuse_pool_bwd = fuse               # the (off by default) pooled BatchNorm backward as well
+        _, feat = eng.forward(x, training=True)
+        assert (eng.saved["stem"][2] is None) == fuse
+        eng.backward(coef)
+        res.append((feat.clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
