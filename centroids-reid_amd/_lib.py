@@ -39,6 +39,9 @@ SIGNATURES = {
     "creid_tune_clear": (C.c_int, []),
     "creid_loo_centroids_fwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "creid_loo_centroids_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
+    "creid_loo_emb_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p]),
+    "creid_loo_emb_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
+    "creid_ctl_step_stats": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p]),
     "creid_triplet_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_triplet_bwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _f32, _p, _p]),
     "creid_triplet_fwd_batched": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _p]),

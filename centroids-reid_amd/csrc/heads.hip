@@ -667,6 +667,110 @@ __global__ __launch_bounds__(256) void clamp_sqrt_kernel(float* __restrict__ d, 
     d[i] = sqrtf(fmaxf(d[i], lo));
 }
 
+// ---- the centroid rounds' operands in one pass (train_ctl_model.py:79-124): emb[i] = cat(queries of round i, centroids of
+// round i) = [K][2P][D], lab[i] = labels of the P identities twice.  grid (P, K): workgroup (p, i) writes the query row
+// emb[i][p] = feat[p][i], the leave-one-out centroid emb[i][P + p] (same s-order sum as loo_centroids_fwd_kernel, also to
+// cent[i][p]) and the two label slots -- what torch did with two strided copies, a cat and a contiguous().
+__global__ __launch_bounds__(256) void loo_emb_fwd_kernel(const float* __restrict__ feat, const uint8_t* __restrict__ is_real,
+                                                          const int64_t* __restrict__ labels, int P, int K, int D,
+                                                          float* __restrict__ cent, int32_t* __restrict__ valid,
+                                                          float* __restrict__ emb, int64_t* __restrict__ lab,
+                                                          float* __restrict__ cnorm) {
+  __shared__ float wsum[4];
+  const int p = blockIdx.x, i = blockIdx.y;
+  const bool qreal = is_real[p * K + i] != 0;
+  int cnt = 0;
+  if (qreal)
+    for (int s = 0; s < K; ++s) cnt += (s != i && is_real[p * K + s]) ? 1 : 0;
+  if (threadIdx.x == 0) {
+    valid[i * P + p] = cnt;
+    const int64_t l = labels[p * K + i];
+    lab[(int64_t)i * 2 * P + p] = l;
+    lab[(int64_t)i * 2 * P + P + p] = l;
+  }
+  const float den = (float)max(cnt, 1);
+  float* oc = cent + ((int64_t)i * P + p) * D;
+  float* eq = emb + ((int64_t)i * 2 * P + p) * D;
+  float* ec = emb + ((int64_t)i * 2 * P + P + p) * D;
+  const float* fq = feat + ((int64_t)p * K + i) * D;
+  float nrm = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    if (qreal)
+      for (int s = 0; s < K; ++s)
+        if (s != i && is_real[p * K + s]) acc += feat[((int64_t)p * K + s) * D + d];
+    const float c = acc / den;
+    oc[d] = c; ec[d] = c;
+    eq[d] = fq[d];
+    nrm = fmaf(c, c, nrm);
+  }
+  nrm = wave_sum(nrm);                                            // L2 norm of the centroid row (logged as l2_mean_centroid)
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = nrm;
+  __syncthreads();
+  if (threadIdx.x == 0) cnorm[i * P + p] = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+}
+
+// dfeat[p][s] += demb[s][p]  (the round's query rows)  +  sum_{i != s, real} demb[i][P + p] / max(cnt_i, 1)  (its share of the
+// other rounds' centroids) -- in that order, i.e. the torch add_ followed by loo_centroids_bwd_kernel.  grid (P, K = s).
+__global__ __launch_bounds__(256) void loo_emb_bwd_kernel(const float* __restrict__ demb, const uint8_t* __restrict__ is_real,
+                                                          int P, int K, int D, float* __restrict__ dfeat) {
+  const int p = blockIdx.x, s = blockIdx.y;
+  float* out = dfeat + ((int64_t)p * K + s) * D;
+  const float* dq = demb + ((int64_t)s * 2 * P + p) * D;
+  const bool sreal = is_real[p * K + s] != 0;
+  // per round i: divisor max(cnt_i, 1), or 0 when round i contributes nothing to slot s -- once per thread, not per element
+  constexpr int KMAX = 16;
+  float den[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) {
+    den[i] = 0.f;
+    if (i < K && i != s && sreal && is_real[p * K + i]) {
+      int cnt = 0;
+      for (int t = 0; t < K; ++t) cnt += (t != i && is_real[p * K + t]) ? 1 : 0;
+      den[i] = (float)max(cnt, 1);
+    }
+  }
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float o = out[d] + dq[d];
+    if (sreal) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i)
+        if (den[i] != 0.f) acc += demb[((int64_t)i * 2 * P + P + p) * D + d] / den[i];
+      o += acc;
+    }
+    out[d] = o;
+  }
+}
+
+// Scalars of one training step (train_ctl_model.py:143-177) in one launch: terms = scal * w, total = sum(terms),
+// step = sum of the K round losses (terms[4], terms[8], ...), rounds = mean over the K rows of out4[1:], l2 = mean of the
+// centroid row norms (loo_emb_fwd_kernel's cnorm).  out: [n] terms, then {total, step, rounds[0..3], l2}.  One wave.
+__global__ __launch_bounds__(64) void ctl_step_stats_kernel(const float* __restrict__ scal, const float* __restrict__ w, int n,
+                                                            int K, const float* __restrict__ cnorm, int rows,
+                                                            float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  float l2 = 0.f;
+  for (int r = lane; r < rows; r += 64) l2 += cnorm[r];
+  l2 = wave_sum(l2);
+  if (lane == 0) {
+    float total = 0.f, step = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float t = scal[i] * w[i];
+      out[i] = t;
+      total += t;
+      if (i >= 4 && i < 4 * (K + 1) && (i & 3) == 0) step += t;
+    }
+    out[n] = total; out[n + 1] = step;
+    for (int c = 0; c < 4; ++c) {
+      float a = 0.f;
+      for (int k = 1; k <= K; ++k) a += scal[4 * k + c];
+      out[n + 2 + c] = a / (float)K;
+    }
+    out[n + 6] = l2 / (float)rows;
+  }
+}
+
 // ======================================================================================
 extern "C" {
 
@@ -683,6 +787,31 @@ int creid_loo_centroids_bwd(const float* dcentroids, const uint8_t* is_real, int
   CREID_CHECK_ARG(dcentroids && is_real && dfeat_accum && P > 0 && K > 0 && D > 0);
   hipLaunchKernelGGL(loo_centroids_bwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream),
                      dcentroids, is_real, (int)P, (int)K, (int)D, dfeat_accum);
+  CREID_LAUNCH_RET();
+}
+
+int creid_loo_emb_fwd(const float* feat, const uint8_t* is_real, const int64_t* labels, int64_t P, int64_t K, int64_t D,
+                      float* centroids, int32_t* valid, float* emb, int64_t* lab, float* cnorm, void* stream) {
+  CREID_CHECK_ARG(feat && is_real && labels && centroids && valid && emb && lab && cnorm && P > 0 && K > 0 && D > 0);
+  hipLaunchKernelGGL(loo_emb_fwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream), feat, is_real, labels,
+                     (int)P, (int)K, (int)D, centroids, valid, emb, lab, cnorm);
+  CREID_LAUNCH_RET();
+}
+
+int creid_loo_emb_bwd(const float* demb, const uint8_t* is_real, int64_t P, int64_t K, int64_t D, float* dfeat_accum,
+                      void* stream) {
+  CREID_CHECK_ARG(demb && is_real && dfeat_accum && P > 0 && K > 0 && D > 0);
+  if (K > 16) return CREID_E_SHAPE;
+  hipLaunchKernelGGL(loo_emb_bwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream), demb, is_real, (int)P,
+                     (int)K, (int)D, dfeat_accum);
+  CREID_LAUNCH_RET();
+}
+
+int creid_ctl_step_stats(const float* scal, const float* weights, int64_t n, int64_t K, const float* cnorm, int64_t rows,
+                         float* out, void* stream) {
+  CREID_CHECK_ARG(scal && weights && cnorm && out && n >= 4 * (K + 1) && K > 0 && rows > 0);
+  hipLaunchKernelGGL(ctl_step_stats_kernel, dim3(1), dim3(64), 0, as_stream(stream), scal, weights, (int)n, (int)K, cnorm,
+                     (int)rows, out);
   CREID_LAUNCH_RET();
 }
 

@@ -228,33 +228,31 @@ class CTLModel(ModelBase):
         # ---- leave-one-out centroids and the K centroid rounds (:79-148)
         cent = torch.empty((K, P, D), **f32)
         valid = torch.empty((K, P), **i32)
-        L.check(lib.creid_loo_centroids_fwd(L.ptr(feat), L.ptr(self._all_real_u8(B, dev)), P, K, D, L.ptr(cent),
-                                            L.ptr(valid), st), "creid_loo_centroids_fwd")
-        emb = torch.empty((K, 2 * P, D), **f32)
-        emb[:, :P].copy_(feat.view(P, K, D).transpose(0, 1))
-        emb[:, P:].copy_(cent)
-        lt = labels.view(P, K).t()
-        lab = torch.cat((lt, lt), dim=1).contiguous()                          # [K, 2P]
+        emb = torch.empty((K, 2 * P, D), **f32)                                # round i: P queries, then P centroids
+        lab = torch.empty((K, 2 * P), dtype=torch.int64, device=dev)
+        real = self._all_real_u8(B, dev)
+        cnorm = torch.empty(K * P, **f32)
+        L.check(lib.creid_loo_emb_fwd(L.ptr(feat), L.ptr(real), L.ptr(labels), P, K, D, L.ptr(cent), L.ptr(valid), L.ptr(emb),
+                                      L.ptr(lab), L.ptr(cnorm), st), "creid_loo_emb_fwd")
         demb = zbuf[B * D:].view(K, 2 * P, D)
         g_round = hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT / K
         keep.append(triplet(emb, lab, K, 2 * P, out4[1:], g_round, demb))      # the K rounds: one launch per kernel
-        dfeat.view(P, K, D).add_(demb[:, :P].transpose(0, 1))
-        dcent = demb[:, P:].contiguous()
-        L.check(lib.creid_loo_centroids_bwd(L.ptr(dcent), L.ptr(self._all_real_u8(B, dev)), P, K, D, L.ptr(dfeat), st),
-                "creid_loo_centroids_bwd")
+        L.check(lib.creid_loo_emb_bwd(L.ptr(demb), L.ptr(real), P, K, D, L.ptr(dfeat), st), "creid_loo_emb_bwd")
 
         eng.backward(dfeat)                                                    # manual_backward (:152)
 
         # weighted terms with ONE multiply: w is a cached constant vector aligned with `scal`
         # (query triplet loss, round losses / K, center loss, xent) -- the logged values are views of the product
         wv = self._loss_weight_vector(K, dev)
-        terms = scal * wv
+        n = scal.numel()
+        stats = torch.empty(n + 7, **f32)                                      # terms[n], total, step, rounds[4], l2
+        L.check(lib.creid_ctl_step_stats(L.ptr(scal), L.ptr(wv), n, K, L.ptr(cnorm), K * P, L.ptr(stats), st), "creid_ctl_step_stats")
+        terms = stats[:n]
         contrastive_loss_query = terms[0]
-        contrastive_loss_step = terms[4:4 * (K + 1):4].sum()
         center_loss, xent_query = terms[4 * (K + 1)], terms[4 * (K + 1) + 1]
-        total_loss = terms.sum()                                               # :150 (unweighted slots have weight 0)
-        rounds = out4[1:].mean(dim=0)                                          # {loss, mean ap, mean an, n}
-        l2_mean = torch.linalg.vector_norm(cent, dim=2).mean()
+        total_loss, contrastive_loss_step = stats[n], stats[n + 1]              # :150 (unweighted slots have weight 0)
+        rounds = stats[n + 2:n + 6]                                            # {loss, mean ap, mean an, n}
+        l2_mean = stats[n + 6]
         for name, val in zip(self.losses_names, (xent_query, contrastive_loss_query, center_loss, contrastive_loss_step)):
             self.losses_dict[name].append(val)
         log_data = {"step_dist_ap": rounds[1], "step_dist_an": rounds[2], "l2_mean_centroid": l2_mean}

@@ -138,6 +138,18 @@ int creid_loo_centroids_fwd(const float* feat, const uint8_t* is_real, int64_t P
 /* adjoint of the above: dfeat_accum[P*K, D] += J^T dcentroids. */
 int creid_loo_centroids_bwd(const float* dcentroids, const uint8_t* is_real, int64_t P, int64_t K,
                             int64_t D, float* dfeat_accum, void* stream);
+/* The centroid rounds' operands and scalars without framework glue (train_ctl_model.py:79-124, 143-177):
+ * creid_loo_emb_fwd = creid_loo_centroids_fwd that ALSO lays out the K stacked triplet problems: emb [K][2P][D] (round i:
+ * the P i-th instances, then the P leave-one-out centroids), lab int64 [K][2P]; creid_loo_emb_bwd adds demb's query rows and
+ * the leave-one-out backward of its centroid rows into dfeat [P*K][D]; cnorm [K][P] = L2 norm of every centroid row;
+ * creid_ctl_step_stats: out[0..n) = scal * weights, out[n..n+7) = {sum, sum of the K round losses (slots 4, 8, ..), mean over
+ * the K rows of scal[4..4K+4) (4 values), mean of the `rows` entries of cnorm}. */
+int creid_loo_emb_fwd(const float* feat, const uint8_t* is_real, const int64_t* labels, int64_t P, int64_t K, int64_t D,
+                      float* centroids, int32_t* valid, float* emb, int64_t* lab, float* cnorm, void* stream);
+int creid_loo_emb_bwd(const float* demb, const uint8_t* is_real, int64_t P, int64_t K, int64_t D, float* dfeat_accum,
+                      void* stream);
+int creid_ctl_step_stats(const float* scal, const float* weights, int64_t n, int64_t K, const float* cnorm,
+                         int64_t rows, float* out, void* stream);
 
 /* ------------------------------------------------------------------ stage C: losses */
 

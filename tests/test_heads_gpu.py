@@ -182,3 +182,50 @@ def test_general_distances_and_mining_golden(golden, mods):
     np.testing.assert_array_equal(dm.grad.cpu().numpy(), ref)
     ap2, an2 = losses.hard_example_mining(dm.detach(), labels)
     assert torch.equal(ap2, ap.detach()) and torch.equal(an2, an.detach())
+
+
+@pytest.mark.parametrize("P,K,D,fakes", [(16, 4, 2048, ()), (8, 4, 64, (8, 9, 30)), (6, 3, 36, (0, 1, 2))])
+def test_loo_emb_kernels_equal_centroid_kernels_plus_glue(P, K, D, fakes):
+    """creid_loo_emb_fwd / _bwd = creid_loo_centroids_fwd / _bwd + the strided copies, cat and add_ the training step used to
+    do with torch ops; creid_ctl_step_stats = the step's scalar bookkeeping (train_ctl_model.py:143-177)."""
+    from centroids_reid_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(P + K + D)
+    f32 = dict(dtype=torch.float32, device="cuda")
+    feat = torch.from_numpy(rng.standard_normal((P * K, D)).astype(np.float32)).cuda()
+    real = torch.ones(P * K, dtype=torch.uint8, device="cuda")
+    for j in fakes:
+        real[j] = 0
+    labels = torch.arange(P, device="cuda").repeat_interleave(K) * 7 + 3
+    cent0 = torch.empty((K, P, D), **f32); valid0 = torch.empty((K, P), dtype=torch.int32, device="cuda")
+    L.check(lib.creid_loo_centroids_fwd(L.ptr(feat), L.ptr(real), P, K, D, L.ptr(cent0), L.ptr(valid0), L.stream()), "fwd0")
+    cent = torch.empty_like(cent0); valid = torch.empty_like(valid0)
+    emb = torch.empty((K, 2 * P, D), **f32); lab = torch.empty((K, 2 * P), dtype=torch.int64, device="cuda")
+    cnorm = torch.empty(K * P, **f32)
+    L.check(lib.creid_loo_emb_fwd(L.ptr(feat), L.ptr(real), L.ptr(labels), P, K, D, L.ptr(cent), L.ptr(valid), L.ptr(emb), L.ptr(lab),
+                                  L.ptr(cnorm), L.stream()), "fwd")
+    assert torch.equal(cent, cent0) and torch.equal(valid, valid0)
+    assert torch.equal(emb[:, :P], feat.view(P, K, D).transpose(0, 1)) and torch.equal(emb[:, P:], cent0)
+    lt = labels.view(P, K).t()
+    assert torch.equal(lab, torch.cat((lt, lt), dim=1))
+    np.testing.assert_allclose(cnorm.cpu().numpy(), torch.linalg.vector_norm(cent0, dim=2).flatten().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    # backward: dfeat += query rows of demb, then the leave-one-out adjoint of its centroid rows
+    demb = torch.from_numpy(rng.standard_normal((K, 2 * P, D)).astype(np.float32)).cuda()
+    base = torch.from_numpy(rng.standard_normal((P * K, D)).astype(np.float32)).cuda()
+    ref = base.clone()
+    ref.view(P, K, D).add_(demb[:, :P].transpose(0, 1))
+    dcent = demb[:, P:].contiguous()
+    L.check(lib.creid_loo_centroids_bwd(L.ptr(dcent), L.ptr(real), P, K, D, L.ptr(ref), L.stream()), "bwd0")
+    got = base.clone()
+    L.check(lib.creid_loo_emb_bwd(L.ptr(demb), L.ptr(real), P, K, D, L.ptr(got), L.stream()), "bwd")
+    assert torch.equal(got, ref)
+    # scalars
+    n = 4 * (K + 1) + 2
+    scal = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    w = torch.zeros(n, **f32); w[0] = 1.0; w[4:4 * (K + 1):4] = 1.0 / K; w[4 * (K + 1)] = 5e-4; w[4 * (K + 1) + 1] = 1.0
+    out = torch.empty(n + 7, **f32)
+    L.check(lib.creid_ctl_step_stats(L.ptr(scal), L.ptr(w), n, K, L.ptr(cnorm), K * P, L.ptr(out), L.stream()), "stats")
+    terms = scal * w
+    np.testing.assert_array_equal(out[:n].cpu().numpy(), terms.cpu().numpy())
+    want = torch.cat([terms.sum().view(1), terms[4:4 * (K + 1):4].sum().view(1), scal[4:4 * (K + 1)].view(K, 4).mean(0), cnorm.mean().view(1)])
+    np.testing.assert_allclose(out[n:].cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=1e-6)
