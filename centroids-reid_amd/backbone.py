@@ -242,6 +242,11 @@ class BackboneEngine:
         # (creid_conv2d_dgrad_fused_nhwc) instead of 53 stand-alone 5-25 us launches; CREID_WRED_PIGGYBACK=0: round-1 path
         self.wred_piggyback = os.environ.get("CREID_WRED_PIGGYBACK", "1") == "1" and not self.wgrad_stream \
             and not self.reduce_stream
+        # BatchNorm-backward finalizes ride in the first workgroups of a weight-gradient launch issued between the data
+        # gradient that produced their column sums and the apply that needs them (CREID_BNFIN_PIGGYBACK=0: own launches)
+        self.bnfin_piggyback = self.wred_piggyback and dtype == torch.bfloat16 \
+            and os.environ.get("CREID_BNFIN_PIGGYBACK", "1") == "1"
+        self._bn_sums = {}             # id(unit) -> coefficient tensor whose finalize has already been issued
         self._wred_pending = []        # FIFO of (desc, grad tensor, workspace, nbytes)
         self._wred_ws = [None, None, None]
         self._wred_flip = 0
@@ -500,9 +505,13 @@ class BackboneEngine:
         lib, st = L.lib(), L.stream()
         rows = lib.creid_bn2d_bwd_rows(M)
         ready = 1 if part is not None else 0
-        if part is None:
+        sums = self._bn_sums.pop(id(u), None)
+        if sums is not None:
+            ready = 2                      # finalize already issued (it rode in a weight-gradient launch): apply only
+        elif part is None:
             part = self._empty(rows * 2, u.cout, dtype=torch.float32)
-        sums = self._empty(3, u.cout, dtype=torch.float32)
+        if sums is None:
+            sums = self._empty(3, u.cout, dtype=torch.float32)
         dx = self._empty(M, u.cout)
         gm = self._empty(M, u.cout) if want_gm else None
         bn = u.bn
@@ -515,16 +524,18 @@ class BackboneEngine:
                                         L.ptr(dbet), L.ptr(dx), L.ptr(gm), st), "bn2d_bwd")
         return dx, gm
 
-    def _wgrad(self, u, a_in, dy, B, H, W):
+    def _wgrad(self, u, a_in, dy, B, H, W, fin=None):
+        """Weight gradient.  fin = (unit, partials, M) of a BatchNorm whose backward finalize should ride in this launch
+        (ignored -- the BatchNorm backward then runs its own finalize -- where the carrier does not apply)."""
         if not u.conv.weight.requires_grad:
             return
         if self.wgrad_stream:
             with self._fork_side(a_in, dy):
                 self._wgrad_launch(u, a_in, dy, B, H, W)
         else:
-            self._wgrad_launch(u, a_in, dy, B, H, W)
+            self._wgrad_launch(u, a_in, dy, B, H, W, fin)
 
-    def _wgrad_launch(self, u, a_in, dy, B, H, W):
+    def _wgrad_launch(self, u, a_in, dy, B, H, W, fin=None):
         lib, st = L.lib(), L.stream()
         d, _, _ = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         nbytes = lib.creid_conv2d_wgrad_workspace_bytes(C.byref(d), self.dt)
@@ -537,10 +548,22 @@ class BackboneEngine:
                 self._keep.append(self._wred_ws[k])
                 self._wred_ws[k] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
             ws = self._wred_ws[k]
-            L.check(lib.creid_conv2d_wgrad_partials(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(ws), nbytes, self.dt, st),
-                    "conv2d_wgrad_partials")
+            if fin is not None and self.bnfin_piggyback and fin[1] is not None:
+                fu, fpart, fM, mean, invstd = fin
+                fbn = fu.bn
+                sums = self._empty(3, fu.cout, dtype=torch.float32)
+                dgam = self._grad_of(fbn.weight) if fbn.weight.requires_grad else None
+                dbet = self._grad_of(fbn.bias) if fbn.bias.requires_grad else None
+                L.check(lib.creid_conv2d_wgrad_partials_bnfin(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(ws), nbytes, self.dt,
+                                                              L.ptr(fpart), lib.creid_bn2d_bwd_rows(fM), fu.cout, fM,
+                                                              L.ptr(mean), L.ptr(invstd), L.ptr(fbn.weight), L.ptr(sums),
+                                                              L.ptr(dgam), L.ptr(dbet), st), "conv2d_wgrad_partials_bnfin")
+                self._bn_sums[id(fu)] = sums
+            else:
+                L.check(lib.creid_conv2d_wgrad_partials(C.byref(d), L.ptr(a_in), L.ptr(dy), L.ptr(ws), nbytes, self.dt, st),
+                        "conv2d_wgrad_partials")
             self._wred_pending.append((d, gw, ws, nbytes))
-            assert len(self._wred_pending) <= 2
+            assert len(self._wred_pending) <= 3
             return
         if not self.reduce_stream:
             ws = self._workspace(nbytes)
@@ -596,6 +619,7 @@ class BackboneEngine:
         sv = self.saved
         assert sv is not None and sv["training"], "backward() needs a training-mode forward first"
         lib, st = L.lib(), L.stream()
+        self._bn_sums.clear()
         B = sv["B"]
         h, w = sv["final"]
         dfeat = dfeat.contiguous().float()
@@ -614,10 +638,13 @@ class BackboneEngine:
             dx3, gm = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, want_gm=m3 is None, part=part3)
             if m3 is not None:
                 gm = g
-            self._wgrad(b["c3"], s["a2"], dx3, B, s["h2"], s["w2"])
+            # per convolution: data gradient first (it feeds the dependent chain dgrad -> BN finalize -> BN apply -> dgrad),
+            # then the weight gradient, which is off that chain and carries the finalize of the BatchNorm whose column sums
+            # the data gradient just produced (and, via the pending queue, gets its own split reduction carried by the
+            # NEXT data gradient)
             da2, p2 = self._dgrad(b["c3"], dx3, B, s["h2"], s["w2"], bnred=(s["x2"], s["a2"], s["m2"], s["i2"]))
+            self._wgrad(b["c3"], s["a2"], dx3, B, s["h2"], s["w2"], fin=(b["c2"], p2, M3, s["m2"], s["i2"]))
             dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3, part=p2)
-            self._wgrad(b["c2"], s["a1"], dx2, B, s["h1"], s["w1"])
             ibn1 = b["c1"].ibn is not None
             hw1 = s["h1"] * s["w1"]
             ibn_fused = ibn1 and hw1 % 128 == 0          # per-image statistics: the 128-row tiles must not straddle images
@@ -625,15 +652,15 @@ class BackboneEngine:
                                   bnred=None if (ibn1 and not ibn_fused) else (s["x1"], s["a1"], s["m1"], s["i1"]),
                                   stat_image_rows=hw1 if ibn_fused else 0)
             M1 = B * s["h1"] * s["w1"]
+            self._wgrad(b["c2"], s["a1"], dx2, B, s["h1"], s["w1"],
+                        fin=None if ibn1 else (b["c1"], p1, M1, s["m1"], s["i1"]))
             if ibn1:
                 dx1, _ = self._ibn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], B, hw1, part=p1)
             else:
                 dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1, part=p1)
-            self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"])
             nxt = None if prev is None else (prev[1]["x3"], prev[1]["a3"], prev[1]["m3"], prev[1]["i3"])
             if b["ds"] is not None:
                 dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3, mask=m3)
-                self._wgrad(b["ds"], s["a_in"], dxd, B, s["hin"], s["win"])
                 dsu = b["ds"]
                 if (dsu.stride == 2 and dsu.k == 1 and nxt is not None and self.fuse_bn_reduce
                         and s["hin"] % 2 == 0 and s["win"] % 2 == 0):
@@ -642,14 +669,19 @@ class BackboneEngine:
                     from types import SimpleNamespace
                     shim = SimpleNamespace(cin=dsu.cin, cout=dsu.cout, k=1, stride=1, pad=0, w_crsk=dsu.w_crsk)
                     tmp, _ = self._dgrad(shim, dxd, B, s["h2"], s["w2"])        # (also carries a pending split reduction)
+                    self._wgrad(b["ds"], s["a_in"], dxd, B, s["hin"], s["win"])
                     g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt, add_src_stride=2)
                 else:
                     tmp, _ = self._dgrad(dsu, dxd, B, s["hin"], s["win"])
+                    self._wgrad(b["ds"], s["a_in"], dxd, B, s["hin"], s["win"])
                     g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=tmp, bnred=nxt)
             else:
                 g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm, bnred=nxt, add_mask=m3)
+            Min = B * s["hin"] * s["win"]
+            self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"],
+                        fin=None if (prev is None or part3 is None) else (prev[0]["c3"], part3, Min, prev[1]["m3"], prev[1]["i3"]))
             if self.on_group_done is not None and bi in self._group_first:
-                assert not self._wred_pending            # the layer's last split reduction rode on the launch above
+                self._flush_wred()                       # the layer's last split reduction: nothing left to carry it
                 self.on_group_done(self._group_first[bi])
         # stem
         xpad, x0, y0, mean0, invstd0, idx0 = sv["stem"]

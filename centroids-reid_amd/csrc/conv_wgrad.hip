@@ -15,6 +15,7 @@
 // wgrad_reduce_kernel<SL> sums them in a fixed order (deterministic) and scatters into the OIHW fp32 gradient.
 #include "conv_common.hpp"
 #include "wgrad_reduce.hpp"
+#include "bn_fin.hpp"
 #include "tune.hpp"
 #include <stdlib.h>
 
@@ -188,7 +189,7 @@ template <int TM, int TN, int NS, bool WS = false>
 __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024) ? (WS ? 4 : 2) : (WS ? 2 : 1)) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
                                                                  const unsigned short* __restrict__ x, int NCO,
                                                                  float* __restrict__ ws, int tiles_k, int m_per_split,
-                                                                 int xcd_tiles, int xcd_splits) {
+                                                                 int xcd_tiles, int xcd_splits, BnBwdFinJob fin) {
   constexpr int IM = TM / 64, JN = TN / 64;
   constexpr int LPR_A = TM / 8, LPR_B = TN / 8;                // lanes (16-B chunks) per tile row
   constexpr int RPI_A = 64 / LPR_A, RPI_B = 64 / LPR_B;        // rows per wave-instruction
@@ -206,14 +207,25 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024)
   // With the tile-major placement each XCD touched every pixel range and the operand re-reads (35x the unique bytes
   // for a 512 -> 512 3x3 layer) all missed to the fabric.
   // Fewer than 8 splits (xcd_splits in {1, 2, 4}): the 8 / splits XCDs that share a pixel range interleave its tiles.
+  // carried job (bn_fin.hpp): the first workgroups (a multiple of 8, so the tiles keep their XCD) finalize the BatchNorm
+  // backward that the NEXT launch in the stream needs; 1-D grid only
+  int bid0 = (int)blockIdx.x;
+  if (fin.partial) {
+    const int nf8 = (fin.nblocks + 7) & ~7;
+    if (bid0 < nf8) {
+      if (bid0 < fin.nblocks) bn_bwd_finalize_block<WS ? 512 : 256>(fin, bid0, smem);
+      return;
+    }
+    bid0 -= nf8;
+  }
   int tile, split;
   if (xcd_tiles > 0 && xcd_splits >= 8) {
-    const int bid = blockIdx.x, j = bid >> 3, ls = j / xcd_tiles;
+    const int bid = bid0, j = bid >> 3, ls = j / xcd_tiles;
     tile = j - ls * xcd_tiles;
     split = (bid & 7) + 8 * ls;
     if (split >= xcd_splits) return;
   } else if (xcd_tiles > 0) {
-    const int bid = blockIdx.x, x8 = bid & 7, share = 8 / xcd_splits;
+    const int bid = bid0, x8 = bid & 7, share = 8 / xcd_splits;
     split = x8 % xcd_splits;
     tile = x8 / xcd_splits + share * (bid >> 3);
     if (tile >= xcd_tiles) return;
@@ -693,14 +705,23 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   return p;
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_finalize_job_kernel(BnBwdFinJob j) {
+  __shared__ __attribute__((aligned(16))) double fin_lds[4 * 2 * 16];
+  bn_bwd_finalize_block<256>(j, (int)blockIdx.x, fin_lds);
+}
+
 template <int TM, int TN>
-static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* ws, const WgradPlan& p,
-                           int dtype, hipStream_t s) {
+// returns true when the launch carried the BatchNorm-backward finalize job `fin_in` (bn_fin.hpp) in its first workgroups
+static bool launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* ws, const WgradPlan& p,
+                           int dtype, hipStream_t s, const BnBwdFinJob* fin_in = nullptr) {
   dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(256);
   const bool xcd_on = p.xcd != 0;
   const int xt = xcd_on ? p.tiles : 0;
   const int share = p.splits >= 8 ? 1 : 8 / p.splits;
-  const dim3 grid_x(p.splits >= 8 ? (unsigned)(p.tiles * ((p.splits + 7) / 8) * 8) : (unsigned)(8 * ((p.tiles + share - 1) / share)));
+  BnBwdFinJob fin{};
+  if (fin_in && xcd_on) fin = *fin_in;                            // the carried job needs the 1-D grid
+  const unsigned nf8 = fin.partial ? (unsigned)((fin.nblocks + 7) & ~7) : 0u;
+  const dim3 grid_x((p.splits >= 8 ? (unsigned)(p.tiles * ((p.splits + 7) / 8) * 8) : (unsigned)(8 * ((p.tiles + share - 1) / share))) + nf8);
   const dim3 grid_dma = xcd_on ? grid_x : grid;
   static const int use_dma = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
   static const int stages_env = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
@@ -712,16 +733,17 @@ static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
     const int stages = (p.stages >= 2 && p.stages <= 4) ? p.stages : stages_env;
     if (use_ws && !stem_geom)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, true>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin);
     else if (stages == 2)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin);
     else if (stages == 3)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 3>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin);
     else
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 4>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits);
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin);
+    return fin.partial != nullptr;
   }
   else if (dtype == CREID_BF16)
     hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN>), grid, block, 0, s, g, (const unsigned short*)dy,
@@ -729,20 +751,24 @@ static void launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
   else
     hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN>), grid, block, 0, s, g, (const float*)dy, (const float*)x, NCO, ws,
                        p.tiles_k, p.m_per_split);
+  return false;
 }
 
 static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* dw, int kw_taps, int cpitch,
                      int cin, int kh, int kw, int accumulate, void* ws, size_t ws_bytes, int dtype, hipStream_t s,
-                     int phases = 3) {
+                     int phases = 3, const BnBwdFinJob* fin = nullptr) {
   if (dtype != CREID_BF16 && dtype != CREID_F32) return CREID_E_DTYPE;
   const WgradPlan p = plan_wgrad(g.M, NCO, g.K, dtype);
   const size_t need = (size_t)p.splits * NCO * g.K * sizeof(float);
   if (ws_bytes < need) return CREID_E_WS;
   if (phases & 1) {
-    if (p.tm == 128 && p.tn == 128) launch_wgrad_t<128, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
-    else if (p.tm == 128 && p.tn == 64) launch_wgrad_t<128, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
-    else if (p.tm == 64 && p.tn == 128) launch_wgrad_t<64, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s);
-    else launch_wgrad_t<64, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s);
+    bool carried;
+    if (p.tm == 128 && p.tn == 128) carried = launch_wgrad_t<128, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s, fin);
+    else if (p.tm == 128 && p.tn == 64) carried = launch_wgrad_t<128, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s, fin);
+    else if (p.tm == 64 && p.tn == 128) carried = launch_wgrad_t<64, 128>(g, dy, x, NCO, (float*)ws, p, dtype, s, fin);
+    else carried = launch_wgrad_t<64, 64>(g, dy, x, NCO, (float*)ws, p, dtype, s, fin);
+    if (fin && !carried)                                         // kernel variants without the carrier: stand-alone launch
+      hipLaunchKernelGGL(bn_bwd_finalize_job_kernel, dim3((unsigned)fin->nblocks), dim3(256), 0, s, *fin);
   }
   if (!(phases & 2)) return (int)hipGetLastError();
   if (kh * kw == 9 && cpitch == cin && (1 << g.log2span) == cin && kw_taps == kw && p.splits <= 16 &&
@@ -798,7 +824,7 @@ size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype) {
 }
 
 static int conv_wgrad_phases(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
-                             void* ws, size_t ws_bytes, int dtype, void* stream, int phases);
+                             void* ws, size_t ws_bytes, int dtype, void* stream, int phases, const BnBwdFinJob* fin = nullptr);
 
 int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
                             void* ws, size_t ws_bytes, int dtype, void* stream) {
@@ -812,6 +838,16 @@ int creid_conv2d_wgrad_partials(const creid_conv_desc* d, const void* x, const v
   return conv_wgrad_phases(d, x, dy, nullptr, 0, ws, ws_bytes, dtype, stream, 1);
 }
 
+int creid_conv2d_wgrad_partials_bnfin(const creid_conv_desc* d, const void* x, const void* dy, void* ws, size_t ws_bytes,
+                                      int dtype, const float* bn_partial, int64_t bn_rows, int64_t bn_C, int64_t bn_count,
+                                      const float* bn_mean, const float* bn_invstd, const float* bn_gamma, float* bn_sums,
+                                      float* bn_dgamma, float* bn_dbeta, void* stream) {
+  CREID_CHECK_ARG(x && dy && bn_partial && bn_mean && bn_invstd && bn_sums && bn_rows > 0 && bn_C > 0 && bn_count > 0);
+  BnBwdFinJob fin{bn_partial, (int)bn_rows, (int)bn_C, (float)(1.0 / (double)bn_count), bn_mean, bn_invstd, bn_gamma, bn_sums,
+                  bn_dgamma, bn_dbeta, (int)((bn_C + 15) / 16)};
+  return conv_wgrad_phases(d, x, dy, nullptr, 0, ws, ws_bytes, dtype, stream, 1, &fin);
+}
+
 int creid_conv2d_wgrad_reduce(const creid_conv_desc* d, float* dw_oihw, int accumulate, const void* ws, size_t ws_bytes,
                               int dtype, void* stream) {
   CREID_CHECK_ARG(dw_oihw);
@@ -819,7 +855,7 @@ int creid_conv2d_wgrad_reduce(const creid_conv_desc* d, float* dw_oihw, int accu
 }
 
 static int conv_wgrad_phases(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
-                             void* ws, size_t ws_bytes, int dtype, void* stream, int phases) {
+                             void* ws, size_t ws_bytes, int dtype, void* stream, int phases, const BnBwdFinJob* fin) {
   CREID_CHECK_ARG(d && ws);
   if (ilog2x(d->in_c) < 0 || d->in_c < 64 || d->out_c % 64 != 0) return CREID_E_SHAPE;
   IGemmGeom g;
@@ -830,7 +866,7 @@ static int conv_wgrad_phases(const creid_conv_desc* d, const void* x, const void
   { static const int noinc = [] { const char* e = getenv("CREID_WGRAD_NOINC"); return e ? atoi(e) : 0; }(); if (noinc) g.check_bounds = 2; }
   igemm_finish_geom(g);
   return run_wgrad(g, dy, x, (int)d->out_c, dw_oihw, d->kw, (int)d->in_c, (int)d->in_c, d->kh, d->kw, accumulate, ws,
-                   ws_bytes, dtype, as_stream(stream), phases);
+                   ws_bytes, dtype, as_stream(stream), phases, fin);
 }
 
 size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype) {

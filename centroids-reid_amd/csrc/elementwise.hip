@@ -758,10 +758,12 @@ static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const ui
                          const float* invstd, const float* gamma, int64_t M, int64_t C, int dtype, float* partial,
                          int partial_ready, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out,
                          void* stream) {
-  CREID_CHECK_ARG(x && (g || pg.dy) && mean && invstd && partial && sums && dx && M > 0 && C > 0 && C % 8 == 0);
+  CREID_CHECK_ARG(x && (g || pg.dy) && mean && invstd && (partial || partial_ready == 2) && sums && dx && M > 0 && C > 0 && C % 8 == 0);
   if (mask && dtype == CREID_F32) return CREID_E_DTYPE;
   const int rows = (int)creid_bn2d_bwd_rows(M);
   hipStream_t s = as_stream(stream);
+  // partial_ready: 0 = run the column pass here; 1 = `partial` already filled (fused dgrad epilogue); 2 = `sums` already
+  // final (the finalize rode in a weight-gradient launch, creid_conv2d_wgrad_partials_bnfin): apply only
   if (!partial_ready)
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
@@ -770,7 +772,7 @@ static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const ui
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
                                 invstd, M, (int)C, 128, partial, mask, pg));
-  if (!fin_dry(2))
+  if (partial_ready != 2 && !fin_dry(2))
   hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, rows, (int)C,
                      (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   DISPATCH_T(dtype,

@@ -322,6 +322,15 @@ int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void*
  * reduce is a short, memory-light kernel that a caller may put on a second stream beside the next data gradient. */
 int creid_conv2d_wgrad_partials(const creid_conv_desc* d, const void* x, const void* dy, void* ws,
                                 size_t ws_bytes, int dtype, void* stream);
+/* creid_conv2d_wgrad_partials whose launch also carries a BatchNorm-backward FINALIZE in its first workgroups: the weight
+ * gradient is independent of the chain dgrad -> finalize -> apply -> dgrad, so issued between a data gradient and the next
+ * BatchNorm's apply it hides that 4-128-workgroup, latency-bound step (bn_*: the arguments creid_bn2d_bwd's finalize
+ * takes -- partial [bn_rows][2][bn_C] as written by the fused data gradient, count = rows of the statistics).  Afterwards
+ * call creid_bn2d_bwd_mask(..., partial_ready = 2, sums = bn_sums, ...): apply only. */
+int creid_conv2d_wgrad_partials_bnfin(const creid_conv_desc* d, const void* x, const void* dy, void* ws, size_t ws_bytes,
+                                      int dtype, const float* bn_partial, int64_t bn_rows, int64_t bn_C, int64_t bn_count,
+                                      const float* bn_mean, const float* bn_invstd, const float* bn_gamma, float* bn_sums,
+                                      float* bn_dgamma, float* bn_dbeta, void* stream);
 int creid_conv2d_wgrad_reduce(const creid_conv_desc* d, float* dw_oihw, int accumulate, const void* ws,
                               size_t ws_bytes, int dtype, void* stream);
 

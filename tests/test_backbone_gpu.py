@@ -594,3 +594,27 @@ def test_stem_fusion_schedule_is_bit_identical(dtype):
     assert torch.equal(res[0][0], res[1][0])
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+@_NEEDS_DMA
+@pytest.mark.parametrize("arch", ["resnet50", "resnet50_ibn_a"])
+def test_bn_finalize_carried_by_wgrad_matches_own_launch(arch):
+    """The BatchNorm-backward finalizes ride in the first workgroups of a weight-gradient launch
+    (creid_conv2d_wgrad_partials_bnfin + partial_ready = 2); same fp64 sums with another grouping of the additions ->
+    gradients equal to fp32 rounding."""
+    from oracle import backbone_oracle as bo
+    x = bo.synthetic_images(4, 128, 64, seed=25).cuda()
+    coef = torch.from_numpy(np.random.default_rng(8).standard_normal((4, 2048)).astype(np.float32)).cuda()
+    grads = []
+    for carried in (True, False):
+        net, eng, _ = _build(arch, torch.bfloat16)
+        assert eng.bnfin_piggyback
+        eng.bnfin_piggyback = carried
+        for _ in range(2):
+            _, feat = eng.forward(x, training=True)
+            eng.backward(coef)
+        assert not eng._wred_pending and not eng._bn_sums
+        grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        a, b = grads[0][n].double(), grads[1][n].double()
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9, (n, float((a - b).norm()), float(b.norm()))
