@@ -714,12 +714,13 @@ class BackboneEngine:
         self.saved = None
 
     def _flush_wred(self):
-        """Split reductions that found no data-gradient launch to ride on (never in the ResNet schedules)."""
+        """Split reductions that found no data-gradient launch to ride on (the last one of the backward pass and, with a
+        group hook, of every layer group): the same job as the carried form, as its own launch."""
         lib, st = L.lib(), L.stream()
         while self._wred_pending:
             rd, rgw, rws, rbytes = self._wred_pending.pop(0)
-            L.check(lib.creid_conv2d_wgrad_reduce(C.byref(rd), L.ptr(rgw), 1, L.ptr(rws), rbytes, self.dt, st),
-                    "conv2d_wgrad_reduce")
+            L.check(lib.creid_conv2d_wgrad_reduce_job(C.byref(rd), L.ptr(rgw), 1, L.ptr(rws), rbytes, self.dt, st),
+                    "conv2d_wgrad_reduce_job")
 
 
 class _BackboneFn(torch.autograd.Function):

@@ -854,6 +854,18 @@ int creid_conv2d_wgrad_reduce(const creid_conv_desc* d, float* dw_oihw, int accu
   return conv_wgrad_phases(d, nullptr, nullptr, dw_oihw, accumulate, const_cast<void*>(ws), ws_bytes, dtype, stream, 2);
 }
 
+/* The split reduction as the SAME job a data-gradient launch would have carried (wgrad_reduce_block, identical summation
+ * order), as its own launch: for the reductions that find no carrier (end of a layer group / of the backward pass), so that
+ * a schedule with and without carriers gives bit-identical gradients. */
+int creid_conv2d_wgrad_reduce_job(const creid_conv_desc* d, float* dw_oihw, int accumulate, const void* ws, size_t ws_bytes,
+                                  int dtype, void* stream) {
+  CREID_CHECK_ARG(d && dw_oihw && ws);
+  WRedJob j{};
+  if (!wgrad_make_reduce_job(d, dtype, ws, ws_bytes, dw_oihw, accumulate, j))
+    return creid_conv2d_wgrad_reduce(d, dw_oihw, accumulate, ws, ws_bytes, dtype, stream);
+  return wgrad_reduce_job_launch(j, as_stream(stream));
+}
+
 static int conv_wgrad_phases(const creid_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int accumulate,
                              void* ws, size_t ws_bytes, int dtype, void* stream, int phases, const BnBwdFinJob* fin) {
   CREID_CHECK_ARG(d && ws);

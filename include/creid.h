@@ -322,6 +322,10 @@ int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void*
  * reduce is a short, memory-light kernel that a caller may put on a second stream beside the next data gradient. */
 int creid_conv2d_wgrad_partials(const creid_conv_desc* d, const void* x, const void* dy, void* ws,
                                 size_t ws_bytes, int dtype, void* stream);
+/* creid_conv2d_wgrad_reduce with the summation order of the carried form (the job creid_conv2d_dgrad_fused_nhwc runs in its
+ * last workgroups): a reduction that finds no carrier gives bit-identical gradients to one that did. */
+int creid_conv2d_wgrad_reduce_job(const creid_conv_desc* d, float* dw_oihw, int accumulate, const void* ws,
+                                  size_t ws_bytes, int dtype, void* stream);
 /* creid_conv2d_wgrad_partials whose launch also carries a BatchNorm-backward FINALIZE in its first workgroups: the weight
  * gradient is independent of the chain dgrad -> finalize -> apply -> dgrad, so issued between a data gradient and the next
  * BatchNorm's apply it hides that 4-128-workgroup, latency-bound step (bn_*: the arguments creid_bn2d_bwd's finalize
