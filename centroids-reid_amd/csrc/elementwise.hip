@@ -490,41 +490,42 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           int B, int H, int W, int C, T* __restrict__ dx) {
+  // A pixel lies in 1 (even coordinate) or 2 (odd) windows per axis.  The row parity is uniform over the workgroup; the
+  // column parity is made uniform per pass (even columns, then odd ones), so no wave executes window taps that only
+  // some of its lanes need -- with mixed parities every wave walked all three column taps under partial masks.
   constexpr int V = Vec16<T>::N;
   const int OH = H / 2, OW = W / 2, cpr = C / V;
   const int row = blockIdx.x;                       // b * H + iy
   const int b = row / H, iy = row - b * H;
-  const int nvec = W * cpr;
   T* drow = dx + (int64_t)row * W * C;
-  for (int v = threadIdx.x; v < nvec; v += 256) {
-    const int ix = v / cpr, cc = v - ix * cpr;
-    float acc[V];
+  const int nr = (iy & 1) ? 2 : 1;
+  const int rr0 = (iy & 1) ? 0 : 1, rstep = 2;      // kernel rows r = rr0, rr0 + 2 (odd iy) or r = 1 (even iy)
+  for (int par = 0; par < 2; ++par) {
+    const int ns = par ? 2 : 1, ss0 = par ? 0 : 1;
+    for (int v = threadIdx.x; v < (W / 2) * cpr; v += 256) {
+      const int ix = 2 * (v / cpr) + par, cc = v % cpr;
+      float acc[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) acc[k] = 0.f;
-    // output windows containing (iy, ix): oy*2 + r - 1 == iy, r in 0..2
+      for (int k = 0; k < V; ++k) acc[k] = 0.f;
+      for (int ri = 0; ri < nr; ++ri) {
+        const int r = rr0 + ri * rstep, oy = (iy + 1 - r) >> 1;
+        if (oy >= OH) continue;
+        for (int si = 0; si < ns; ++si) {
+          const int sx = ss0 + si * 2, ox = (ix + 1 - sx) >> 1;
+          if (ox >= OW) continue;
+          const int64_t o = ((((int64_t)b * OH + oy) * OW + ox) * cpr + cc) * V;
+          float g[V];
+          Vec16<T>::load(dy + o, g);
+          uint8_t tap[V];
+          if constexpr (V == 8) *reinterpret_cast<uint2*>(tap) = *reinterpret_cast<const uint2*>(idx + o);
+          else *reinterpret_cast<unsigned*>(tap) = *reinterpret_cast<const unsigned*>(idx + o);
+          const uint8_t want = (uint8_t)(r * 3 + sx);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int t = iy + 1 - r;
-      if (t < 0 || (t & 1)) continue;
-      const int oy = t >> 1;
-      if (oy >= OH) continue;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int u = ix + 1 - s;
-        if (u < 0 || (u & 1)) continue;
-        const int ox = u >> 1;
-        if (ox >= OW) continue;
-        const int64_t o = ((((int64_t)b * OH + oy) * OW + ox) * cpr + cc) * V;
-        float g[V];
-        Vec16<T>::load(dy + o, g);
-        uint8_t tap[V];
-        if constexpr (V == 8) *reinterpret_cast<uint2*>(tap) = *reinterpret_cast<const uint2*>(idx + o);
-        else *reinterpret_cast<unsigned*>(tap) = *reinterpret_cast<const unsigned*>(idx + o);
-#pragma unroll
-        for (int k = 0; k < V; ++k) acc[k] += (tap[k] == (uint8_t)(r * 3 + s)) ? g[k] : 0.f;
+          for (int k = 0; k < V; ++k) acc[k] += (tap[k] == want) ? g[k] : 0.f;
+        }
       }
+      Vec16<T>::store(drow + ((int64_t)ix * cpr + cc) * V, acc);
     }
-    Vec16<T>::store(drow + (int64_t)v * V, acc);
   }
 }
 
