@@ -18,16 +18,17 @@ struct BnBwdFinJob {
   float* sums;               // [3][C] coefficients of dx = A*dy + B*x + C
   float* dgamma;             // nullable, accumulated
   float* dbeta;              // nullable, accumulated
-  int nblocks;               // workgroups that carry the job: ceil(C / 16)
+  int nblocks;               // workgroups that carry the job: ceil(C / cw)
+  int cw;                    // channels per workgroup: 16, or 4 when C is small and the partial rows are many
 };
 
-// One workgroup of NT threads finalizes channels [block*16, block*16 + 16).  lds: >= NT*4 bytes.
-template <int NT>
-__device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinJob& j, int block, void* lds) {
-  constexpr int RG = NT / 16, NW = NT / 64;
-  double* red = reinterpret_cast<double*>(lds);              // [NW][2][16]
-  const int tid = threadIdx.x, cl = tid & 15, rg = tid >> 4;
-  const int c = block * 16 + cl, C = j.C;
+// One workgroup of NT threads finalizes channels [block*CW, block*CW + CW).  lds: >= NT*4 bytes.
+template <int NT, int CW>
+__device__ __forceinline__ void bn_bwd_finalize_block_cw(const BnBwdFinJob& j, int block, void* lds) {
+  constexpr int RG = NT / CW, NW = NT / 64;
+  double* red = reinterpret_cast<double*>(lds);              // [NW][2][CW]
+  const int tid = threadIdx.x, cl = tid % CW, rg = tid / CW;
+  const int c = block * CW + cl, C = j.C;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     int r = rg;
@@ -44,9 +45,9 @@ __device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinJob& j, int 
       s2 += (double)j.partial[((int64_t)r * 2 + 1) * C + c];
     }
   }
-  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-  if ((tid & 63) < 16) { red[((tid >> 6) * 2 + 0) * 16 + cl] = s1; red[((tid >> 6) * 2 + 1) * 16 + cl] = s2; }
+#pragma unroll
+  for (int o = CW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if ((tid & 63) < CW) { red[((tid >> 6) * 2 + 0) * CW + cl] = s1; red[((tid >> 6) * 2 + 1) * CW + cl] = s2; }
   float p_mu = 0.f, p_is = 0.f, p_g = 1.f, p_db = 0.f, p_dg = 0.f;
   if (rg == 0 && c < C) {
     p_mu = j.mean[c]; p_is = j.invstd[c];
@@ -58,7 +59,7 @@ __device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinJob& j, int 
   if (rg == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < NW; ++q) { s1 += red[(q * 2 + 0) * 16 + cl]; s2 += red[(q * 2 + 1) * 16 + cl]; }
+    for (int q = 0; q < NW; ++q) { s1 += red[(q * 2 + 0) * CW + cl]; s2 += red[(q * 2 + 1) * CW + cl]; }
     const float invM = j.inv_count;
     const float mu = p_mu, is = p_is, k1 = p_g * is;
     const float a1 = (float)s1 * invM, a2 = (float)s2 * invM;
@@ -68,4 +69,15 @@ __device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinJob& j, int 
     if (j.dbeta) j.dbeta[c] = p_db + (float)s1;
     if (j.dgamma) j.dgamma[c] = p_dg + (float)s2;
   }
+}
+
+template <int NT>
+__device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinJob& j, int block, void* lds) {
+  if (j.cw == 4) bn_bwd_finalize_block_cw<NT, 4>(j, block, lds);     // uniform over the launch
+  else bn_bwd_finalize_block_cw<NT, 16>(j, block, lds);
+}
+
+static inline void bn_bwd_fin_shape(BnBwdFinJob& j) {       // host: channels per workgroup and workgroup count
+  j.cw = (j.C <= 256 && j.rows >= 512) ? 4 : 16;
+  j.nblocks = (j.C + j.cw - 1) / j.cw;
 }

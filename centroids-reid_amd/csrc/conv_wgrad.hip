@@ -844,7 +844,8 @@ int creid_conv2d_wgrad_partials_bnfin(const creid_conv_desc* d, const void* x, c
                                       float* bn_dgamma, float* bn_dbeta, void* stream) {
   CREID_CHECK_ARG(x && dy && bn_partial && bn_mean && bn_invstd && bn_sums && bn_rows > 0 && bn_C > 0 && bn_count > 0);
   BnBwdFinJob fin{bn_partial, (int)bn_rows, (int)bn_C, (float)(1.0 / (double)bn_count), bn_mean, bn_invstd, bn_gamma, bn_sums,
-                  bn_dgamma, bn_dbeta, (int)((bn_C + 15) / 16)};
+                  bn_dgamma, bn_dbeta, 0, 16};
+  bn_bwd_fin_shape(fin);
   return conv_wgrad_phases(d, x, dy, nullptr, 0, ws, ws_bytes, dtype, stream, 1, &fin);
 }
 

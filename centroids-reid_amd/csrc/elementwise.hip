@@ -36,6 +36,7 @@ template <> struct Vec16<unsigned short> {
 // ------------------------------------------------------------------ BN statistics finalize
 // partial: [rows][2][C] (sum, sumsq per 128-row conv tile).  training: mean/invstd from the batch and
 // running-stat update (momentum, unbiased variance); eval: mean = running_mean, invstd = rsqrt(rv+eps).
+template <int CW>
 __global__ __launch_bounds__(1024) void bn2d_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                             double count, float* __restrict__ rmean,
                                                             float* __restrict__ rvar, int training, float momentum,
@@ -46,9 +47,10 @@ __global__ __launch_bounds__(1024) void bn2d_finalize_kernel(const float* __rest
                                                             float* __restrict__ scale_shift) {
   // 16 channels x 64 row-groups per workgroup: 64-B coalesced reads, 4 independent loads in flight per
   // thread, fp64 accumulation, LDS tree (the kernel is pure latency: keep the dependent chain short)
-  __shared__ double red[64][2][16];
-  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  constexpr int RG = 1024 / CW;                      // row groups: CW = 16 for wide layers, 4 when C is small and rows many
+  __shared__ double red[16][2][CW];
+  const int cl = threadIdx.x % CW, rg = threadIdx.x / CW;
+  const int c = blockIdx.x * CW + cl;
   if (!training) {
     if (rg == 0 && c < C) {
       const float mu = rmean[c], is = 1.0f / sqrtf(rvar[c] + eps);
@@ -62,23 +64,23 @@ __global__ __launch_bounds__(1024) void bn2d_finalize_kernel(const float* __rest
   if (c < C)
   {
     int r = rg;
-    for (; r + 192 < rows; r += 256) {          // 8 independent loads per trip
+    for (; r + 3 * RG < rows; r += 4 * RG) {          // 8 independent loads per trip
       const float a0 = partial[((int64_t)r * 2) * C + c], b0 = partial[((int64_t)r * 2 + 1) * C + c];
-      const float a1 = partial[((int64_t)(r + 64) * 2) * C + c], b1 = partial[((int64_t)(r + 64) * 2 + 1) * C + c];
-      const float a2 = partial[((int64_t)(r + 128) * 2) * C + c], b2 = partial[((int64_t)(r + 128) * 2 + 1) * C + c];
-      const float a3 = partial[((int64_t)(r + 192) * 2) * C + c], b3 = partial[((int64_t)(r + 192) * 2 + 1) * C + c];
+      const float a1 = partial[((int64_t)(r + RG) * 2) * C + c], b1 = partial[((int64_t)(r + RG) * 2 + 1) * C + c];
+      const float a2 = partial[((int64_t)(r + 2 * RG) * 2) * C + c], b2 = partial[((int64_t)(r + 2 * RG) * 2 + 1) * C + c];
+      const float a3 = partial[((int64_t)(r + 3 * RG) * 2) * C + c], b3 = partial[((int64_t)(r + 3 * RG) * 2 + 1) * C + c];
       s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
       s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
     }
-    for (; r < rows; r += 64) {
+    for (; r < rows; r += RG) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
   }
   // a wave holds 4 row groups x 16 channels: fold them with two shuffles, then 16 per-wave partials meet in LDS
-  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-  if ((threadIdx.x & 63) < 16) { red[threadIdx.x >> 6][0][cl] = s1; red[threadIdx.x >> 6][1][cl] = s2; }
+#pragma unroll
+  for (int o = CW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if ((threadIdx.x & 63) < CW) { red[threadIdx.x >> 6][0][cl] = s1; red[threadIdx.x >> 6][1][cl] = s2; }
   // per-channel parameters are fetched before the barrier (off the dependent tail of this latency-bound kernel)
   float p_gamma = 1.f, p_beta = 0.f, p_rm = 0.f, p_rv = 0.f;
   if (rg == 0 && c < C) {
@@ -299,35 +301,37 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
 }
 
 // sums[2][C] = sum over row blocks; dgamma += sum dy*xhat ; dbeta += sum dy
+template <int CW>
 __global__ __launch_bounds__(1024) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                                 double count, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 float* __restrict__ sums, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta) {
-  __shared__ double red[64][2][16];
-  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  constexpr int RG = 1024 / CW;                      // row groups: CW = 16 for wide layers, 4 when C is small and rows many
+  __shared__ double red[16][2][CW];
+  const int cl = threadIdx.x % CW, rg = threadIdx.x / CW;
+  const int c = blockIdx.x * CW + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
   {
     int r = rg;
-    for (; r + 192 < rows; r += 256) {          // 8 independent loads per trip
+    for (; r + 3 * RG < rows; r += 4 * RG) {          // 8 independent loads per trip
       const float a0 = partial[((int64_t)r * 2) * C + c], b0 = partial[((int64_t)r * 2 + 1) * C + c];
-      const float a1 = partial[((int64_t)(r + 64) * 2) * C + c], b1 = partial[((int64_t)(r + 64) * 2 + 1) * C + c];
-      const float a2 = partial[((int64_t)(r + 128) * 2) * C + c], b2 = partial[((int64_t)(r + 128) * 2 + 1) * C + c];
-      const float a3 = partial[((int64_t)(r + 192) * 2) * C + c], b3 = partial[((int64_t)(r + 192) * 2 + 1) * C + c];
+      const float a1 = partial[((int64_t)(r + RG) * 2) * C + c], b1 = partial[((int64_t)(r + RG) * 2 + 1) * C + c];
+      const float a2 = partial[((int64_t)(r + 2 * RG) * 2) * C + c], b2 = partial[((int64_t)(r + 2 * RG) * 2 + 1) * C + c];
+      const float a3 = partial[((int64_t)(r + 3 * RG) * 2) * C + c], b3 = partial[((int64_t)(r + 3 * RG) * 2 + 1) * C + c];
       s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
       s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
     }
-    for (; r < rows; r += 64) {
+    for (; r < rows; r += RG) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
   }
-  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-  if ((threadIdx.x & 63) < 16) { red[threadIdx.x >> 6][0][cl] = s1; red[threadIdx.x >> 6][1][cl] = s2; }
+#pragma unroll
+  for (int o = CW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if ((threadIdx.x & 63) < CW) { red[threadIdx.x >> 6][0][cl] = s1; red[threadIdx.x >> 6][1][cl] = s2; }
   float p_mu = 0.f, p_is = 0.f, p_g = 1.f, p_db = 0.f, p_dg = 0.f;
   if (rg == 0 && c < C) {
     p_mu = mean[c]; p_is = invstd[c];
@@ -712,10 +716,17 @@ int creid_bn2d_finalize(const float* partial, int64_t rows, int64_t C, int64_t c
                         const float* beta, float* mean_out, float* invstd_out, float* scale_shift, void* stream) {
   CREID_CHECK_ARG(C > 0 && mean_out && invstd_out && scale_shift &&
                   (training ? (partial && rows > 0 && count > 0) : (running_mean && running_var)));
-  if (!fin_dry(1))
-  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, as_stream(stream), partial,
-                     (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, gamma, beta,
-                     mean_out, invstd_out, scale_shift);
+  // few channels, many partial rows (stem, layer1): 4 channels per workgroup -> 4x the workgroups, 1/4 of the dependent trips
+  if (!fin_dry(1)) {
+    if (C <= 256 && rows >= 512)
+      hipLaunchKernelGGL(bn2d_finalize_kernel<4>, dim3((unsigned)((C + 3) / 4)), dim3(1024), 0, as_stream(stream), partial,
+                         (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, gamma, beta,
+                         mean_out, invstd_out, scale_shift);
+    else
+      hipLaunchKernelGGL(bn2d_finalize_kernel<16>, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, as_stream(stream), partial,
+                         (int)rows, (int)C, (double)count, running_mean, running_var, training, momentum, eps, gamma, beta,
+                         mean_out, invstd_out, scale_shift);
+  }
   CREID_LAUNCH_RET();
 }
 
@@ -773,9 +784,14 @@ static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const ui
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
                                 invstd, M, (int)C, 128, partial, mask, pg));
-  if (partial_ready != 2 && !fin_dry(2))
-  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, rows, (int)C,
-                     (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
+  if (partial_ready != 2 && !fin_dry(2)) {
+    if (C <= 256 && rows >= 512)
+      hipLaunchKernelGGL(bn2d_bwd_finalize_kernel<4>, dim3((unsigned)((C + 3) / 4)), dim3(1024), 0, s, partial, rows, (int)C,
+                         (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
+    else
+      hipLaunchKernelGGL(bn2d_bwd_finalize_kernel<16>, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, rows, (int)C,
+                         (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
+  }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, sums, M, (int)C,
