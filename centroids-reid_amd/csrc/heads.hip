@@ -198,24 +198,39 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
     x += bo * D; dist_ap += bo; dist_an += bo; p_idx += bo; n_idx += bo; coef += bo; dx += bo * D;
   }
   const int r = blockIdx.x;
-  if (threadIdx.x == 0) {
-    int k = 0;
-    for (int a = 0; a < N; ++a) {
+  // one thread per anchor (all loads in flight at once; a single thread walking the N anchors spent ~10 us in dependent
+  // loads), then the terms are compacted in anchor order by an exclusive scan of the per-anchor counts
+  __shared__ int t_cnt[256];
+  for (int a0 = 0; a0 < N; a0 += 256) {                    // N <= 256 in every caller: one trip
+    const int a = a0 + (int)threadIdx.x;
+    int oth[4]; float wv[4]; int k = 0;
+    if (a < N) {
       const float c = coef[a];
-      if (c == 0.f) continue;
       const int p = p_idx[a], n = n_idx[a];
-      if (a != r && p != r && n != r) continue;
-      const float dap = dist_ap[a], dan = dist_an[a];
-      // cosine: d|1 - u.v| / du = -sign(1 - u.v) v (zero where the clamp is active); the sign is applied below
-      const float ip = KIND == 0 ? (dap > 1e-6f ? c / dap : 0.f) : (dap > 1e-12f ? -c : 0.f);
-      const float in_ = KIND == 0 ? (dan > 1e-6f ? c / dan : 0.f) : (dan > 1e-12f ? -c : 0.f);
-      if (a == r) { t_other[k] = p; t_w[k++] = ip; t_other[k] = n; t_w[k++] = -in_; }
-      if (p == r) { t_other[k] = a; t_w[k++] = ip; }
-      if (n == r) { t_other[k] = a; t_w[k++] = -in_; }
+      if (c != 0.f && (a == r || p == r || n == r)) {
+        const float dap = dist_ap[a], dan = dist_an[a];
+        // cosine: d|1 - u.v| / du = -sign(1 - u.v) v (zero where the clamp is active); the sign is applied below
+        const float ip = KIND == 0 ? (dap > 1e-6f ? c / dap : 0.f) : (dap > 1e-12f ? -c : 0.f);
+        const float in_ = KIND == 0 ? (dan > 1e-6f ? c / dan : 0.f) : (dan > 1e-12f ? -c : 0.f);
+        if (a == r) { oth[k] = p; wv[k++] = ip; oth[k] = n; wv[k++] = -in_; }
+        if (p == r) { oth[k] = a; wv[k++] = ip; }
+        if (n == r) { oth[k] = a; wv[k++] = -in_; }
+      }
     }
-    n_terms = k;
+    if (a0 == 0 && threadIdx.x == 0) n_terms = 0;
+    t_cnt[threadIdx.x] = k;
+    __syncthreads();
+    int off = n_terms;
+    for (int q = 0; q < (int)threadIdx.x; ++q) off += t_cnt[q];
+    for (int q = 0; q < k; ++q) { t_other[off + q] = oth[q]; t_w[off + q] = wv[q]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = n_terms;
+      for (int q = 0; q < 256; ++q) tot += t_cnt[q];
+      n_terms = tot;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int nt = n_terms;
   if (nt == 0) return;
   const float g = gscale * (gscale_ptr ? *gscale_ptr : 1.f);
