@@ -69,6 +69,7 @@ SIGNATURES = {
     "creid_conv2d_wgrad_partials": (C.c_int, [_p, _p, _p, _p, _sz, C.c_int, _p]),
     "creid_conv2d_wgrad_partials_bnfin": (C.c_int, [_p, _p, _p, _p, _sz, C.c_int, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "creid_conv2d_wgrad_reduce": (C.c_int, [_p, _p, C.c_int, _p, _sz, C.c_int, _p]),
+    "creid_bn2d_bwd_finalize_wred": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p, _sz, C.c_int, _p]),
     "creid_conv2d_wgrad_reduce_job": (C.c_int, [_p, _p, C.c_int, _p, _sz, C.c_int, _p]),
     "creid_stem_conv_fwd": (C.c_int, [_i64, _i64, _i64, _p, _p, _p, _p, C.c_int, _p]),
     "creid_stem_conv_wgrad_workspace_bytes": (_sz, [_i64, _i64, _i64, C.c_int]),

@@ -244,9 +244,15 @@ class BackboneEngine:
             and not self.reduce_stream
         # BatchNorm-backward finalizes ride in the first workgroups of a weight-gradient launch issued between the data
         # gradient that produced their column sums and the apply that needs them (CREID_BNFIN_PIGGYBACK=0: own launches)
-        self.bnfin_piggyback = self.wred_piggyback and dtype == torch.bfloat16 \
-            and os.environ.get("CREID_BNFIN_PIGGYBACK", "1") == "1"
+        # CREID_FIN_CARRIER: "wgrad" (above) | "wred" (finalize and the pending split reduction share one launch between the data
+        # gradient and the apply; launch order wgrad -> dgrad as before) | "none"
+        carrier = os.environ.get("CREID_FIN_CARRIER", "wgrad")
+        if os.environ.get("CREID_BNFIN_PIGGYBACK", "1") != "1" or not (self.wred_piggyback and dtype == torch.bfloat16):
+            carrier = "none"
+        self.bnfin_piggyback = carrier == "wgrad"
+        self.fin_with_wred = carrier == "wred"
         self._bn_sums = {}             # id(unit) -> coefficient tensor whose finalize has already been issued
+        self.wgrad_first = os.environ.get("CREID_WGRAD_FIRST", "0") == "1" or not self.bnfin_piggyback   # launch order
         self._wred_pending = []        # FIFO of (desc, grad tensor, workspace, nbytes)
         self._wred_ws = [None, None, None]
         self._wred_flip = 0
@@ -517,6 +523,13 @@ class BackboneEngine:
         bn = u.bn
         dgam = self._grad_of(bn.weight) if bn.weight.requires_grad else None
         dbet = self._grad_of(bn.bias) if bn.bias.requires_grad else None
+        if ready == 1 and self.fin_with_wred and self._wred_pending:
+            # the finalize and the oldest pending split reduction in ONE launch, then apply only
+            rd, rgw, rws, rbytes = self._wred_pending.pop(0)
+            L.check(lib.creid_bn2d_bwd_finalize_wred(L.ptr(part), rows, u.cout, M, L.ptr(mean), L.ptr(invstd), L.ptr(bn.weight),
+                                                     L.ptr(sums), L.ptr(dgam), L.ptr(dbet), C.byref(rd), L.ptr(rgw), 1, L.ptr(rws),
+                                                     rbytes, self.dt, st), "bn2d_bwd_finalize_wred")
+            ready = 2
         if mask is None and act is not None:
             mask = getattr(act, "_relu_mask", None)
         L.check(lib.creid_bn2d_bwd_mask(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mask), L.ptr(mean), L.ptr(invstd),
@@ -597,8 +610,9 @@ class BackboneEngine:
         M = B * H * W
         dx = self._empty(M, u.cin)
         fuse_bn = bnred is not None and self.fuse_bn_reduce
-        if self._wred_pending or fuse_bn or add_mask is not None:
-            rd, rgw, rws, rbytes = self._wred_pending.pop(0) if self._wred_pending else (None, None, None, 0)
+        carry = len(self._wred_pending) >= (2 if self.fin_with_wred else 1)     # "wred" mode keeps one job for the finalize launch
+        if carry or fuse_bn or add_mask is not None:
+            rd, rgw, rws, rbytes = self._wred_pending.pop(0) if carry else (None, None, None, 0)
             x, act, mean, invstd = bnred if fuse_bn else (None, None, None, None)
             mask = getattr(act, "_relu_mask", None) if act is not None else None
             part = self._empty(lib.creid_bn2d_bwd_rows(M) * 2, u.cin, dtype=torch.float32) if fuse_bn else None
@@ -642,23 +656,31 @@ class BackboneEngine:
             # then the weight gradient, which is off that chain and carries the finalize of the BatchNorm whose column sums
             # the data gradient just produced (and, via the pending queue, gets its own split reduction carried by the
             # NEXT data gradient)
+            wfirst = self.wgrad_first
+
+            def wg(u, a, dy, h_, w_, fin=None, early=False):   # the call site that matches the launch order issues it
+                if early == wfirst:
+                    self._wgrad(u, a, dy, B, h_, w_, fin=None if wfirst else fin)
+
+            wg(b["c3"], s["a2"], dx3, s["h2"], s["w2"], early=True)
             da2, p2 = self._dgrad(b["c3"], dx3, B, s["h2"], s["w2"], bnred=(s["x2"], s["a2"], s["m2"], s["i2"]))
-            self._wgrad(b["c3"], s["a2"], dx3, B, s["h2"], s["w2"], fin=(b["c2"], p2, M3, s["m2"], s["i2"]))
+            wg(b["c3"], s["a2"], dx3, s["h2"], s["w2"], fin=(b["c2"], p2, M3, s["m2"], s["i2"]))
             dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3, part=p2)
             ibn1 = b["c1"].ibn is not None
             hw1 = s["h1"] * s["w1"]
             ibn_fused = ibn1 and hw1 % 128 == 0          # per-image statistics: the 128-row tiles must not straddle images
+            wg(b["c2"], s["a1"], dx2, s["h1"], s["w1"], early=True)
             da1, p1 = self._dgrad(b["c2"], dx2, B, s["h1"], s["w1"],
                                   bnred=None if (ibn1 and not ibn_fused) else (s["x1"], s["a1"], s["m1"], s["i1"]),
                                   stat_image_rows=hw1 if ibn_fused else 0)
             M1 = B * s["h1"] * s["w1"]
-            self._wgrad(b["c2"], s["a1"], dx2, B, s["h1"], s["w1"],
-                        fin=None if ibn1 else (b["c1"], p1, M1, s["m1"], s["i1"]))
+            wg(b["c2"], s["a1"], dx2, s["h1"], s["w1"], fin=None if ibn1 else (b["c1"], p1, M1, s["m1"], s["i1"]))
             if ibn1:
                 dx1, _ = self._ibn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], B, hw1, part=p1)
             else:
                 dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1, part=p1)
             nxt = None if prev is None else (prev[1]["x3"], prev[1]["a3"], prev[1]["m3"], prev[1]["i3"])
+            wg(b["c1"], s["a_in"], dx1, s["hin"], s["win"], early=True)
             if b["ds"] is not None:
                 dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3, mask=m3)
                 dsu = b["ds"]
@@ -678,8 +700,8 @@ class BackboneEngine:
             else:
                 g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm, bnred=nxt, add_mask=m3)
             Min = B * s["hin"] * s["win"]
-            self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"],
-                        fin=None if (prev is None or part3 is None) else (prev[0]["c3"], part3, Min, prev[1]["m3"], prev[1]["i3"]))
+            wg(b["c1"], s["a_in"], dx1, s["hin"], s["win"],
+               fin=None if (prev is None or part3 is None) else (prev[0]["c3"], part3, Min, prev[1]["m3"], prev[1]["i3"]))
             if self.on_group_done is not None and bi in self._group_first:
                 self._flush_wred()                       # the layer's last split reduction: nothing left to carry it
                 self.on_group_done(self._group_first[bi])

@@ -855,6 +855,38 @@ int creid_conv2d_wgrad_reduce(const creid_conv_desc* d, float* dw_oihw, int accu
   return conv_wgrad_phases(d, nullptr, nullptr, dw_oihw, accumulate, const_cast<void*>(ws), ws_bytes, dtype, stream, 2);
 }
 
+// BatchNorm-backward finalize + split reduction in ONE launch: the first workgroups (a multiple of 8) finalize, the rest sum
+// the previous weight gradient's partial tiles.  Both are off each other's data; the reduction is bandwidth work that fills the
+// ~4 us during which the 4-128 finalize workgroups wait on their dependent loads, and the data gradient before it keeps its
+// full grid (no reduction tail).
+__global__ __launch_bounds__(512) void wred_bnfin_kernel(WRedJob j, BnBwdFinJob fin) {
+  extern __shared__ __attribute__((aligned(16))) float wredfin_lds[];
+  const int nf8 = fin.partial ? ((fin.nblocks + 7) & ~7) : 0;
+  if ((int)blockIdx.x < nf8) {
+    if ((int)blockIdx.x < fin.nblocks) bn_bwd_finalize_block<512>(fin, (int)blockIdx.x, wredfin_lds);
+    return;
+  }
+  wgrad_reduce_block<512>(j, (int)blockIdx.x - nf8, wredfin_lds);
+}
+
+int creid_bn2d_bwd_finalize_wred(const float* bn_partial, int64_t bn_rows, int64_t bn_C, int64_t bn_count, const float* bn_mean,
+                                 const float* bn_invstd, const float* bn_gamma, float* bn_sums, float* bn_dgamma,
+                                 float* bn_dbeta, const creid_conv_desc* wred_desc, float* wred_dw, int wred_accumulate,
+                                 const void* wred_ws, size_t wred_ws_bytes, int dtype, void* stream) {
+  CREID_CHECK_ARG(bn_partial && bn_mean && bn_invstd && bn_sums && bn_rows > 0 && bn_C > 0 && bn_count > 0 && wred_desc &&
+                  wred_dw && wred_ws);
+  BnBwdFinJob fin{bn_partial, (int)bn_rows, (int)bn_C, (float)(1.0 / (double)bn_count), bn_mean, bn_invstd, bn_gamma, bn_sums,
+                  bn_dgamma, bn_dbeta, 0, 16};
+  bn_bwd_fin_shape(fin);
+  WRedJob j{};
+  if (!wgrad_make_reduce_job(wred_desc, dtype, wred_ws, wred_ws_bytes, wred_dw, wred_accumulate, j)) return CREID_E_SHAPE;
+  const int nf8 = (fin.nblocks + 7) & ~7;
+  size_t lds = (size_t)(4 * 512 + j.K) * sizeof(float);
+  if (lds < 4096) lds = 4096;
+  hipLaunchKernelGGL(wred_bnfin_kernel, dim3((unsigned)(nf8 + j.nblocks)), dim3(512), lds, as_stream(stream), j, fin);
+  CREID_LAUNCH_RET();
+}
+
 /* The split reduction as the SAME job a data-gradient launch would have carried (wgrad_reduce_block, identical summation
  * order), as its own launch: for the reductions that find no carrier (end of a layer group / of the backward pass), so that
  * a schedule with and without carriers gives bit-identical gradients. */

@@ -322,6 +322,13 @@ int creid_conv2d_wgrad_nhwc(const creid_conv_desc* d, const void* x, const void*
  * reduce is a short, memory-light kernel that a caller may put on a second stream beside the next data gradient. */
 int creid_conv2d_wgrad_partials(const creid_conv_desc* d, const void* x, const void* dy, void* ws,
                                 size_t ws_bytes, int dtype, void* stream);
+/* A BatchNorm-backward finalize (arguments as in creid_conv2d_wgrad_partials_bnfin) and the split reduction of a weight
+ * gradient (arguments as in creid_conv2d_wgrad_reduce_job) in ONE launch: independent pieces of work, one latency-bound and
+ * one bandwidth-bound.  Afterwards creid_bn2d_bwd_mask(..., partial_ready = 2, ...). */
+int creid_bn2d_bwd_finalize_wred(const float* bn_partial, int64_t bn_rows, int64_t bn_C, int64_t bn_count,
+                                 const float* bn_mean, const float* bn_invstd, const float* bn_gamma, float* bn_sums,
+                                 float* bn_dgamma, float* bn_dbeta, const creid_conv_desc* wred_desc, float* wred_dw,
+                                 int wred_accumulate, const void* wred_ws, size_t wred_ws_bytes, int dtype, void* stream);
 /* creid_conv2d_wgrad_reduce with the summation order of the carried form (the job creid_conv2d_dgrad_fused_nhwc runs in its
  * last workgroups): a reduction that finds no carrier gives bit-identical gradients to one that did. */
 int creid_conv2d_wgrad_reduce_job(const creid_conv_desc* d, float* dw_oihw, int accumulate, const void* ws,

@@ -606,15 +606,17 @@ def test_bn_finalize_carried_by_wgrad_matches_own_launch(arch):
     x = bo.synthetic_images(4, 128, 64, seed=25).cuda()
     coef = torch.from_numpy(np.random.default_rng(8).standard_normal((4, 2048)).astype(np.float32)).cuda()
     grads = []
-    for carried in (True, False):
+    for mode in ("wgrad", "wred", "none"):
         net, eng, _ = _build(arch, torch.bfloat16)
-        assert eng.bnfin_piggyback
-        eng.bnfin_piggyback = carried
+        eng.bnfin_piggyback = mode == "wgrad"          # finalize in the first workgroups of a weight-gradient launch
+        eng.fin_with_wred = mode == "wred"             # finalize + pending split reduction as one launch
+        eng.wgrad_first = mode != "wgrad"
         for _ in range(2):
             _, feat = eng.forward(x, training=True)
             eng.backward(coef)
         assert not eng._wred_pending and not eng._bn_sums
         grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
-    for n in grads[0]:
-        a, b = grads[0][n].double(), grads[1][n].double()
-        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9, (n, float((a - b).norm()), float(b.norm()))
+    for other in grads[:2]:
+        for n in other:
+            a, b = other[n].double(), grads[2][n].double()
+            assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9, (n, float((a - b).norm()), float(b.norm()))
