@@ -253,6 +253,7 @@ class BackboneEngine:
         self.fin_with_wred = carrier == "wred"
         self._bn_sums = {}             # id(unit) -> coefficient tensor whose finalize has already been issued
         self.wgrad_first = os.environ.get("CREID_WGRAD_FIRST", "0") == "1" or not self.bnfin_piggyback   # launch order
+        self.carrier_max_bytes = int(float(os.environ.get("CREID_CARRIER_MAX_MB", "1e9")) * (1 << 20))
         self._wred_pending = []        # FIFO of (desc, grad tensor, workspace, nbytes)
         self._wred_ws = [None, None, None]
         self._wred_flip = 0
@@ -658,9 +659,10 @@ class BackboneEngine:
             # NEXT data gradient)
             wfirst = self.wgrad_first
 
-            def wg(u, a, dy, h_, w_, fin=None, early=False):   # the call site that matches the launch order issues it
-                if early == wfirst:
-                    self._wgrad(u, a, dy, B, h_, w_, fin=None if wfirst else fin)
+            def wg(u, a, dy, h_, w_, fin=None, early=False, first=None):   # the call site that matches the launch order issues it
+                f = wfirst if first is None else first
+                if early == f:
+                    self._wgrad(u, a, dy, B, h_, w_, fin=None if f else fin)
 
             wg(b["c3"], s["a2"], dx3, s["h2"], s["w2"], early=True)
             da2, p2 = self._dgrad(b["c3"], dx3, B, s["h2"], s["w2"], bnred=(s["x2"], s["a2"], s["m2"], s["i2"]))
@@ -680,7 +682,11 @@ class BackboneEngine:
             else:
                 dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1, part=p1)
             nxt = None if prev is None else (prev[1]["x3"], prev[1]["a3"], prev[1]["m3"], prev[1]["i3"])
-            wg(b["c1"], s["a_in"], dx1, s["hin"], s["win"], early=True)
+            # the c1 data gradient writes the block-input gradient (the widest tensor of the block) that the previous block's
+            # bn3 apply reads next; when it is larger than the carrier threshold the weight gradient goes first (its operand
+            # traffic would push that tensor out of the Infinity Cache) and bn3's finalize keeps its own launch
+            c1_first = wfirst or B * s["hin"] * s["win"] * b["c1"].cin * 2 > self.carrier_max_bytes
+            wg(b["c1"], s["a_in"], dx1, s["hin"], s["win"], early=True, first=c1_first)
             if b["ds"] is not None:
                 dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3, mask=m3)
                 dsu = b["ds"]
@@ -700,7 +706,7 @@ class BackboneEngine:
             else:
                 g, part3 = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=gm, bnred=nxt, add_mask=m3)
             Min = B * s["hin"] * s["win"]
-            wg(b["c1"], s["a_in"], dx1, s["hin"], s["win"],
+            wg(b["c1"], s["a_in"], dx1, s["hin"], s["win"], first=c1_first,
                fin=None if (prev is None or part3 is None) else (prev[0]["c3"], part3, Min, prev[1]["m3"], prev[1]["i3"]))
             if self.on_group_done is not None and bi in self._group_first:
                 self._flush_wred()                       # the layer's last split reduction: nothing left to carry it
