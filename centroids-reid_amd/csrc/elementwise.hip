@@ -378,6 +378,35 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict
     cb[k] = b.x; cb[k + 1] = b.y; cb[k + 2] = b.z; cb[k + 3] = b.w;
     cc[k] = c.x; cc[k + 1] = c.y; cc[k + 2] = c.z; cc[k + 3] = c.w;
   }
+  if (!pg.dy && !act) {
+    // common path (mask bits or no ReLU): two independent chunks per trip, every load issued before the first use
+    for (int64_t i = gtid; i < total; i += 2 * nthreads) {
+      const int64_t i2 = i + nthreads;
+      const bool two = i2 < total;
+      float xv[V], gv[V], xw[V], gw[V];
+      unsigned m1 = 0xffu, m2 = 0xffu;
+      Vec16<T>::load(x + i * V, xv);
+      Vec16<T>::load(g + i * V, gv);
+      if (mask) m1 = mask[i];
+      if (two) {
+        Vec16<T>::load(x + i2 * V, xw);
+        Vec16<T>::load(g + i2 * V, gw);
+        if (mask) m2 = mask[i2];
+      }
+      float o[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) { gv[k] = ((m1 >> k) & 1u) ? gv[k] : 0.f; o[k] = fmaf(ca[k], gv[k], fmaf(cb[k], xv[k], cc[k])); }
+      if (gm_out) Vec16<T>::store(gm_out + i * V, gv);
+      Vec16<T>::store(dx + i * V, o);
+      if (two) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) { gw[k] = ((m2 >> k) & 1u) ? gw[k] : 0.f; o[k] = fmaf(ca[k], gw[k], fmaf(cb[k], xw[k], cc[k])); }
+        if (gm_out) Vec16<T>::store(gm_out + i2 * V, gw);
+        Vec16<T>::store(dx + i2 * V, o);
+      }
+    }
+    return;
+  }
   for (int64_t i = gtid; i < total; i += nthreads) {
     float xv[V], gv[V];
     Vec16<T>::load(x + i * V, xv);
