@@ -95,6 +95,8 @@ SIGNATURES = {
                                 _p, C.c_int, _p, _p, _p, _p, _p]),
     "creid_ibn_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p,
                                 _p, _p, _p]),
+    "creid_ibn_fwd_mask": (C.c_int, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, C.c_int, _f32, _f32, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
+    "creid_ibn_bwd_mask": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_bn2d_apply_maxpool3x3s2": (C.c_int, [_p, _p, C.c_int, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),
     "creid_bn2d_bwd_pooled": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, C.c_int, _p, _p, _p, _p, _p, _p]),
     "creid_maxpool3x3s2_fwd": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),

@@ -391,10 +391,15 @@ class BackboneEngine:
         invstd = self._empty(B, u.cout, dtype=torch.float32)
         ss = self._empty(B * 2, u.cout, dtype=torch.float32)
         a = self._empty(B * HW, u.cout)
-        L.check(lib.creid_ibn_fwd(L.ptr(x), B, HW, u.cout, ibn.half, L.ptr(ibn.IN.weight), L.ptr(ibn.IN.bias),
-                                  L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean), L.ptr(bn.running_var),
-                                  1 if training else 0, bn.momentum, bn.eps, 1 if relu else 0, self.dt, L.ptr(part), ready,
-                                  L.ptr(mean), L.ptr(invstd), L.ptr(ss), L.ptr(a), st), "ibn_fwd")
+        mask = None
+        if training and relu and self.relu_bitmask:
+            mask = torch.empty(B * HW * u.cout // 8, dtype=torch.uint8, device=self.device)
+        L.check(lib.creid_ibn_fwd_mask(L.ptr(x), B, HW, u.cout, ibn.half, L.ptr(ibn.IN.weight), L.ptr(ibn.IN.bias),
+                                       L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                       1 if training else 0, bn.momentum, bn.eps, 1 if relu else 0, self.dt, L.ptr(part), ready,
+                                       L.ptr(mean), L.ptr(invstd), L.ptr(ss), L.ptr(a), L.ptr(mask), st), "ibn_fwd")
+        if mask is not None:
+            a._relu_mask = mask
         return a, mean, invstd
 
     def _ibn_bwd(self, u, x, g, act, mean, invstd, B, HW, part=None):
@@ -407,7 +412,8 @@ class BackboneEngine:
         coef = self._empty(B * 3, u.cout, dtype=torch.float32)
         per_img = self._empty(B * 2, ibn.half, dtype=torch.float32)
         dx = self._empty(B * HW, u.cout)
-        L.check(lib.creid_ibn_bwd(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mean), L.ptr(invstd), B, HW, u.cout, ibn.half,
+        mask = getattr(act, "_relu_mask", None) if act is not None else None
+        L.check(lib.creid_ibn_bwd_mask(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mask), L.ptr(mean), L.ptr(invstd), B, HW, u.cout, ibn.half,
                                   L.ptr(ibn.IN.weight), L.ptr(bn.weight), self.dt, L.ptr(part), ready, L.ptr(coef), L.ptr(per_img),
                                   L.ptr(self._grad_of(ibn.IN.weight)), L.ptr(self._grad_of(ibn.IN.bias)),
                                   L.ptr(self._grad_of(bn.weight)), L.ptr(self._grad_of(bn.bias)), L.ptr(dx), st), "ibn_bwd")

@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(1024) void ibn_finalize_kernel(const float* __restr
 // multiple of C/V), so its per-(image, channel) coefficients are loaded once and no index division remains
 template <typename T>
 __global__ __launch_bounds__(256) void ibn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift,
-                                                        int relu, int64_t M, int HW, int C, T* __restrict__ y) {
+                                                        int relu, int64_t M, int HW, int C, T* __restrict__ y,
+                                                        uint8_t* __restrict__ mask_out) {
   constexpr int V = Vec16<T>::N;
   const int cpr = C / V, n = blockIdx.y;
   const int total = HW * cpr, nthreads = gridDim.x * 256;       // 256 % cpr == 0 (host-checked)
@@ -1112,6 +1113,12 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(const T* __restrict__ x,
       if (relu) v[k] = fmaxf(v[k], 0.f);
     }
     Vec16<T>::store(y + (base + i) * V, v);
+    if (mask_out) {                                  // ReLU mask as bits, as bn2d_apply_kernel
+      unsigned m = 0;
+#pragma unroll
+      for (int k = 0; k < V; ++k) m |= (v[k] > 0.f ? 1u : 0u) << k;
+      mask_out[base + i] = (uint8_t)m;
+    }
   }
 }
 
@@ -1122,7 +1129,7 @@ __global__ __launch_bounds__(256) void ibn_bwd_reduce_kernel(const T* __restrict
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int HW, int C,
                                                              int rows_per_block, int rpi,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, const uint8_t* __restrict__ mask) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][256 * V];
   const int cpr = C / V, cw = cpr < 32 ? cpr : 32, nrl = 256 / cw;
@@ -1139,7 +1146,11 @@ __global__ __launch_bounds__(256) void ibn_bwd_reduce_kernel(const T* __restrict
       float xv[V], gv[V];
       Vec16<T>::load(x + base + (int64_t)r * C + c0, xv);
       Vec16<T>::load(g + base + (int64_t)r * C + c0, gv);
-      if (act) {
+      if (mask) {
+        const unsigned m = mask[(base + (int64_t)r * C + c0) / V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) gv[k] = ((m >> k) & 1u) ? gv[k] : 0.f;
+      } else if (act) {
         float av[V];
         Vec16<T>::load(act + base + (int64_t)r * C + c0, av);
 #pragma unroll
@@ -1231,7 +1242,8 @@ __global__ __launch_bounds__(256) void ibn_in_grad_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                             const T* __restrict__ act, const float* __restrict__ coef,
-                                                            int64_t M, int HW, int C, T* __restrict__ dx) {
+                                                            int64_t M, int HW, int C, T* __restrict__ dx,
+                                                            const uint8_t* __restrict__ mask) {
   constexpr int V = Vec16<T>::N;
   const int cpr = C / V, n = blockIdx.y;
   const int total = HW * cpr, nthreads = gridDim.x * 256;       // 256 % cpr == 0 (host-checked)
@@ -1249,7 +1261,11 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(const T* __restrict_
     float xv[V], gv[V], o[V];
     Vec16<T>::load(x + (base + i) * V, xv);
     Vec16<T>::load(g + (base + i) * V, gv);
-    if (act) {
+    if (mask) {
+      const unsigned m = mask[base + i];
+#pragma unroll
+      for (int k = 0; k < V; ++k) gv[k] = ((m >> k) & 1u) ? gv[k] : 0.f;
+    } else if (act) {
       float av[V];
       Vec16<T>::load(act + (base + i) * V, av);
 #pragma unroll
@@ -1271,13 +1287,14 @@ static unsigned ibn_img_blocks(int64_t vecs_per_image) {
 
 int64_t creid_ibn_rows_per_image(int64_t HW) { int64_t r = (HW + 127) / 128; return r < 1 ? 1 : r; }
 
-int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* in_b,
+int creid_ibn_fwd_mask(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* in_b,
                   const float* bn_w, const float* bn_b, float* running_mean, float* running_var, int training,
                   float momentum, float eps, int relu, int dtype, float* partial, int partial_ready, float* mean_out,
-                  float* invstd_out, float* scale_shift, void* y, void* stream) {
+                  float* invstd_out, float* scale_shift, void* y, uint8_t* mask_out, void* stream) {
   CREID_CHECK_ARG(x && y && in_w && in_b && bn_w && bn_b && running_mean && running_var && partial && mean_out &&
                   invstd_out && scale_shift && B > 0 && HW > 0 && C % 8 == 0 && c_in > 0 && c_in < C);
   if (256 % (C / 8) != 0 || 256 % (C / 4) != 0) return CREID_E_SHAPE;      // a thread keeps one channel vector
+  if (mask_out && dtype == CREID_F32) return CREID_E_DTYPE;
   if (partial_ready && HW % 128 != 0) return CREID_E_SHAPE;                 // conv tiles must not straddle images
   const int rpi = (int)creid_ibn_rows_per_image(HW);
   hipStream_t s = as_stream(stream);
@@ -1292,19 +1309,27 @@ int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in,
                      eps, mean_out, invstd_out, scale_shift);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(ibn_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4), (unsigned)B), dim3(256), 0, s, (const float*)x,
-                                scale_shift, relu, B * HW, (int)HW, (int)C, (float*)y),
+                                scale_shift, relu, B * HW, (int)HW, (int)C, (float*)y, (uint8_t*)nullptr),
              hipLaunchKernelGGL(ibn_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
-                                (const unsigned short*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (unsigned short*)y));
+                                (const unsigned short*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (unsigned short*)y, mask_out));
   CREID_LAUNCH_RET();
 }
 
-int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd, int64_t B,
+int creid_ibn_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* in_b,
+                  const float* bn_w, const float* bn_b, float* running_mean, float* running_var, int training,
+                  float momentum, float eps, int relu, int dtype, float* partial, int partial_ready, float* mean_out,
+                  float* invstd_out, float* scale_shift, void* y, void* stream) {
+  return creid_ibn_fwd_mask(x, B, HW, C, c_in, in_w, in_b, bn_w, bn_b, running_mean, running_var, training, momentum, eps, relu, dtype, partial, partial_ready, mean_out, invstd_out, scale_shift, y, nullptr, stream);
+}
+
+int creid_ibn_bwd_mask(const void* x, const void* g, const void* act, const uint8_t* mask, const float* mean, const float* invstd, int64_t B,
                   int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* bn_w, int dtype, float* partial,
                   int partial_ready, float* coef, float* per_img, float* d_in_w, float* d_in_b, float* d_bn_w,
                   float* d_bn_b, void* dx, void* stream) {
   CREID_CHECK_ARG(x && g && mean && invstd && in_w && bn_w && partial && coef && per_img && dx && B > 0 && HW > 0 &&
                   C % 8 == 0 && c_in > 0 && c_in < C);
   if (256 % (C / 8) != 0 || 256 % (C / 4) != 0) return CREID_E_SHAPE;
+  if (mask && dtype == CREID_F32) return CREID_E_DTYPE;
   if (partial_ready && HW % 128 != 0) return CREID_E_SHAPE;
   const int rpi = (int)creid_ibn_rows_per_image(HW);
   hipStream_t s = as_stream(stream);
@@ -1312,21 +1337,28 @@ int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* me
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(ibn_bwd_reduce_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rpi, (unsigned)B), dim3(256),
                                 0, s, (const float*)x, (const float*)g, (const float*)act, mean, invstd, (int)HW, (int)C, 128,
-                                rpi, partial),
+                                rpi, partial, (const uint8_t*)nullptr),
              hipLaunchKernelGGL(ibn_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
                                 dim3(256), 0, s, (const unsigned short*)x, (const unsigned short*)g,
-                                (const unsigned short*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial));
+                                (const unsigned short*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial, mask));
   hipLaunchKernelGGL(ibn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial,
                      (int)B, rpi, (int)HW, (int)C, (int)c_in, mean, invstd, in_w, bn_w, coef, per_img, d_bn_w, d_bn_b);
   hipLaunchKernelGGL(ibn_in_grad_kernel, dim3((unsigned)((c_in + 255) / 256)), dim3(256), 0, s, per_img, (int)B, (int)c_in,
                      d_in_w, d_in_b);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(ibn_bwd_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4), (unsigned)B), dim3(256), 0, s,
-                                (const float*)x, (const float*)g, (const float*)act, coef, B * HW, (int)HW, (int)C, (float*)dx),
+                                (const float*)x, (const float*)g, (const float*)act, coef, B * HW, (int)HW, (int)C, (float*)dx, (const uint8_t*)nullptr),
              hipLaunchKernelGGL(ibn_bwd_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
                                 (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, coef, B * HW,
-                                (int)HW, (int)C, (unsigned short*)dx));
+                                (int)HW, (int)C, (unsigned short*)dx, mask));
   CREID_LAUNCH_RET();
+}
+
+int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd, int64_t B,
+                  int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* bn_w, int dtype, float* partial,
+                  int partial_ready, float* coef, float* per_img, float* d_in_w, float* d_in_b, float* d_bn_w,
+                  float* d_bn_b, void* dx, void* stream) {
+  return creid_ibn_bwd_mask(x, g, act, nullptr, mean, invstd, B, HW, C, c_in, in_w, bn_w, dtype, partial, partial_ready, coef, per_img, d_in_w, d_in_b, d_bn_w, d_bn_b, dx, stream);
 }
 
 }  // extern "C"

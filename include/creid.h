@@ -418,6 +418,16 @@ int creid_ibn_bwd(const void* x, const void* g, const void* act, const float* me
                   int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w, const float* bn_w,
                   int dtype, float* partial, int partial_ready, float* coef, float* per_img, float* d_in_w,
                   float* d_in_b, float* d_bn_w, float* d_bn_b, void* dx, void* stream);
+/* the same with the ReLU mask as bits (see creid_bn2d_apply_mask): mask_out / mask = uint8[B*HW*C/8], bf16 / f16 only */
+int creid_ibn_fwd_mask(const void* x, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w,
+                       const float* in_b, const float* bn_w, const float* bn_b, float* running_mean,
+                       float* running_var, int training, float momentum, float eps, int relu, int dtype,
+                       float* partial, int partial_ready, float* mean_out, float* invstd_out, float* scale_shift,
+                       void* y, uint8_t* mask_out, void* stream);
+int creid_ibn_bwd_mask(const void* x, const void* g, const void* act, const uint8_t* mask, const float* mean,
+                       const float* invstd, int64_t B, int64_t HW, int64_t C, int64_t c_in, const float* in_w,
+                       const float* bn_w, int dtype, float* partial, int partial_ready, float* coef, float* per_img,
+                       float* d_in_w, float* d_in_b, float* d_bn_w, float* d_bn_b, void* dx, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:98) NHWC, with the argmax tap saved for the backward. */
 /* The stem's tail without its full-resolution intermediates (modelling/backbones/resnet.py:123-126, conv1 -> bn1 -> [relu] ->
