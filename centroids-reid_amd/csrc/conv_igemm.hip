@@ -1127,10 +1127,11 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   int bn = 128;
   static const int min_wgs = [] { const char* e = getenv("CREID_IGEMM_BN128_MIN_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
   if (g.N % 128 != 0 || (int64_t)tiles_m * (g.N / 128) < min_wgs) bn = 64;
-  // measured plan for this GEMM shape (tune.hpp): N tile and ring depth of the producer/consumer kernel
+  // measured plan for this GEMM shape (tune.hpp): N tile and ring depth of the producer/consumer kernel; the 4th key slot is
+  // transposed | stride << 1 (a stride-2 and a stride-1 3x3 layer can share M, N, K but not their gather pattern)
   TunePlan tp;
   int tuned_stages = 0, tuned_dma = 0, tuned_stream = 0;
-  if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, g.transposed, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
+  if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, g.transposed | (g.stride << 1), tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
     bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2;
   }

@@ -647,7 +647,7 @@ static int ilog2x(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return ((1
 
 struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split, xcd, stages, ws; };   // stages / ws: 0 = default
 
-static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
+static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype, int stride = 1) {
   // The fp32 partial tiles cost  workgroups x TM x TN x 8 bytes  of traffic per layer (write + re-read by the
   // reduce).  Measured (r01): shrinking the tile to cut that traffic LOSES (6147 vs 6370 img/s) -- the larger
   // tile's MFMA/LDS efficiency matters more and the partials mostly stay in the 256 MB Infinity Cache -- so the
@@ -661,7 +661,7 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype) {
   WgradPlan p;
   p.stages = 0; p.ws = 0;
   TunePlan tp;
-  if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_WGRAD, M, NCO, K, 0, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
+  if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_WGRAD, M, NCO, K, stride << 1, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       (tp.p1 == 64 || tp.p1 == 128) && NCO % tp.p0 == 0 && K % tp.p1 == 0 && tp.p2 >= 1) {
     // measured plan for this shape: tile tp.p0 x tp.p1, tp.p2 = pixel splits | ring depth << 16 | producer/consumer << 20
     p.tm = tp.p0; p.tn = tp.p1;
@@ -758,7 +758,7 @@ static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO,
                      int cin, int kh, int kw, int accumulate, void* ws, size_t ws_bytes, int dtype, hipStream_t s,
                      int phases = 3, const BnBwdFinJob* fin = nullptr) {
   if (dtype != CREID_BF16 && dtype != CREID_F32) return CREID_E_DTYPE;
-  const WgradPlan p = plan_wgrad(g.M, NCO, g.K, dtype);
+  const WgradPlan p = plan_wgrad(g.M, NCO, g.K, dtype, g.stride);
   const size_t need = (size_t)p.splits * NCO * g.K * sizeof(float);
   if (ws_bytes < need) return CREID_E_WS;
   if (phases & 1) {
@@ -805,7 +805,7 @@ bool wgrad_make_reduce_job(const creid_conv_desc* d, int dtype, const void* ws, 
                            WRedJob& j) {
   if (!d || !ws || !dw) return false;
   const int M = (int)(d->batch * d->out_h * d->out_w), K = (int)(d->kh * d->kw * d->in_c), NCO = (int)d->out_c;
-  const WgradPlan p = plan_wgrad(M, NCO, K, dtype);
+  const WgradPlan p = plan_wgrad(M, NCO, K, dtype, d->stride);
   if (ws_bytes < (size_t)p.splits * NCO * K * sizeof(float)) return false;
   const bool ok = wred_make_job(j, (const float*)ws, dw, p.splits, NCO, K, (int)d->in_c, d->kh, d->kw, accumulate);
   // timing experiments only: the carrier workgroups are launched but do nothing (gradients are then WRONG)
@@ -819,7 +819,7 @@ extern "C" {
 size_t creid_conv2d_wgrad_workspace_bytes(const creid_conv_desc* d, int dtype) {
   if (!d) return 0;
   const int M = (int)(d->batch * d->out_h * d->out_w), K = (int)(d->kh * d->kw * d->in_c);
-  const WgradPlan p = plan_wgrad(M, (int)d->out_c, K, dtype);
+  const WgradPlan p = plan_wgrad(M, (int)d->out_c, K, dtype, d->stride);
   return (size_t)p.splits * d->out_c * K * sizeof(float);
 }
 

@@ -88,3 +88,29 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_tuned_plan_file_is_well_formed_and_registers():
+    """centroids-reid_amd/tuned_plans.json: every entry has a known kind, a 4-slot key, a 3-slot plan with tile sizes the
+    kernels instantiate, and registers through creid_tune_set (host-side registry, no GPU needed)."""
+    import json
+    from centroids_reid_amd import _lib as L
+    path = os.path.join(os.path.dirname(L.__file__), "tuned_plans.json")
+    plans = json.load(open(path))["plans"]
+    assert len(plans) >= 20
+    seen = set()
+    for e in plans:
+        kind, key, plan = e["kind"], e["key"], e["plan"]
+        assert kind in (0, 1) and len(key) == 4 and len(plan) == 3 and all(isinstance(v, int) for v in key + plan)
+        assert (kind, tuple(key)) not in seen, "duplicate plan key"
+        seen.add((kind, tuple(key)))
+        if kind == 0:                                   # weight gradient: (tile rows, tile cols, splits | depth << 16 | ws << 20)
+            assert plan[0] in (64, 128) and plan[1] in (64, 128) and 1 <= (plan[2] & 0xffff) <= 4096
+            assert ((plan[2] >> 16) & 0xf) in (0, 2, 3, 4) and key[3] in (2, 4)   # stride << 1
+        else:                                           # forward / data gradient: (N tile, ring depth, kernel kind)
+            assert plan[0] in (64, 128) and plan[1] in (2, 3, 4) and plan[2] in (0, 1, 2)
+            assert key[1] % plan[0] == 0 and key[3] in (2, 3, 4, 5)          # transposed | stride << 1
+    lib = L.lib()
+    assert L.load_tuned_plans(path) == len(plans)
+    lib.creid_tune_clear()
+    assert L.load_tuned_plans() == len(plans)           # back to the shipped set

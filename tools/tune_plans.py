@@ -61,7 +61,7 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
         tr = t_us(lambda: L.check(lib.creid_conv2d_wgrad_reduce(C.byref(d), L.ptr(dw), 0, L.ptr(ws), nbytes, L.BF16, L.stream()), "r"))
         return tp + 0.4 * tr, tp, tr
     lib.creid_tune_clear()
-    tuned_keys.add((0, (M, cout, K, 0)))
+    tuned_keys.add((0, (M, cout, K, s << 1)))
     base, bp, br = wgrad_score()
     best = (base, None)
     cands = []
@@ -72,7 +72,7 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
         for sp in SPLITS:
             if not (160 <= tiles * sp <= 1600) or sp > M // 64:
                 continue
-            lib.creid_tune_set(0, M, cout, K, 0, tm, tn, sp)
+            lib.creid_tune_set(0, M, cout, K, s << 1, tm, tn, sp)
             sc, _, _ = wgrad_score()
             cands.append((sc, (tm, tn, sp)))
             if sc < best[0]:
@@ -82,18 +82,18 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
         for extra in ((3 << 16), (1 << 20)):
             if (extra >> 16) == 3 and 3 * (tm + tn) * 128 > 160 * 1024:
                 continue
-            lib.creid_tune_set(0, M, cout, K, 0, tm, tn, sp | extra)
+            lib.creid_tune_set(0, M, cout, K, s << 1, tm, tn, sp | extra)
             sc, _, _ = wgrad_score()
             if sc < best[0]:
                 best = (sc, (tm, tn, sp | extra))
     lib.creid_tune_clear()
     if best[1] is not None and best[0] < 0.97 * base:
-        plans.append({"kind": 0, "key": [M, cout, K, 0], "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2), "layer": name})
+        plans.append({"kind": 0, "key": [M, cout, K, s << 1], "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2), "layer": name})
     log.append(f"wgrad {name:28s} x{cnt} rule {base:6.1f} (partials {bp:5.1f} + reduce {br:5.1f})  best {best[0]:6.1f} {best[1]}")
 
     # ---------------- forward and data gradient
-    for tag, fn, key in (("fwd", lambda: ly.conv2d_fwd(x, krsc, s, pad, with_stats=True), (M, cout, K, 0)),
-                         ("dgrad", lambda: ly.conv2d_dgrad(y, crsk, (h, w), s, pad), (B * h * w, cin, k * k * cout, 1))):
+    for tag, fn, key in (("fwd", lambda: ly.conv2d_fwd(x, krsc, s, pad, with_stats=True), (M, cout, K, s << 1)),
+                         ("dgrad", lambda: ly.conv2d_dgrad(y, crsk, (h, w), s, pad), (B * h * w, cin, k * k * cout, 1 | (s << 1)))):
         lib.creid_tune_clear()
         tuned_keys.add((1, tuple(key)))
         base = t_us(fn)
