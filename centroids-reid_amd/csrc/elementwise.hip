@@ -717,7 +717,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
 // ------------------------------------------------------------------ host
 static inline unsigned ew_blocks(int64_t total_threads_needed, int64_t mult) {
   int64_t b = (total_threads_needed + 255) / 256;
-  if (b > 2048) b = 2048;
+  static const int64_t cap = [] { const char* e = getenv("CREID_EW_BLOCKS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 2048); }();
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   // make blocks*256 a multiple of `mult` (mult is a power of two <= 512)
   const int64_t q = mult > 256 ? mult / 256 : 1;
