@@ -92,8 +92,24 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
     log.append(f"wgrad {name:28s} x{cnt} rule {base:6.1f} (partials {bp:5.1f} + reduce {br:5.1f})  best {best[0]:6.1f} {best[1]}")
 
     # ---------------- forward and data gradient
+    # the data gradient as the training schedule runs it: with the next BatchNorm-backward's column sums in the epilogue
+    # (operand x, ReLU bits, statistics) and, for the block's first convolution (cin = 4 x cout), the masked residual add
+    Min = B * h * w
+    bn_x = torch.randn((Min, cin), device="cuda").to(torch.bfloat16)
+    bn_mask = torch.randint(0, 256, (Min * cin // 8,), dtype=torch.uint8, device="cuda")
+    bn_mean, bn_inv = torch.zeros(cin, device="cuda"), torch.ones(cin, device="cuda")
+    bn_part = torch.empty((lib.creid_bn2d_bwd_rows(Min) * 2, cin), device="cuda")
+    add = torch.randn((Min, cin), device="cuda").to(torch.bfloat16) if (cin == 4 * cout and s == 1) else None
+    dxbuf = torch.empty((Min, cin), device="cuda", dtype=torch.bfloat16)
+
+    def dgrad_fused():
+        L.check(lib.creid_conv2d_dgrad_fused_nhwc(C.byref(d), L.ptr(y), L.ptr(crsk), L.ptr(dxbuf), L.ptr(add), 1,
+                                                  L.ptr(bn_mask) if add is not None else None, L.ptr(bn_x), None, L.ptr(bn_mask),
+                                                  L.ptr(bn_mean), L.ptr(bn_inv), L.ptr(bn_part), 0, None, None, 0, None, 0, L.BF16,
+                                                  L.stream()), "dgrad_fused")
+
     for tag, fn, key in (("fwd", lambda: ly.conv2d_fwd(x, krsc, s, pad, with_stats=True), (M, cout, K, s << 1)),
-                         ("dgrad", lambda: ly.conv2d_dgrad(y, crsk, (h, w), s, pad), (B * h * w, cin, k * k * cout, 1 | (s << 1)))):
+                         ("dgrad", dgrad_fused, (B * h * w, cin, k * k * cout, 1 | (s << 1)))):
         lib.creid_tune_clear()
         tuned_keys.add((1, tuple(key)))
         base = t_us(fn)
