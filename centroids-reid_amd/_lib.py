@@ -63,6 +63,10 @@ SIGNATURES = {
     "creid_sgd_scaled_step": (C.c_int, [_p, _p, _i64, _f32, _f32, _p]),
     "creid_conv2d_bn_partial_rows": (_i64, [_p]),
     "creid_conv2d_fwd_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p]),
+    "creid_conv2d_fwd_affine_nhwc": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
+    "creid_bn2d_fold_entry_bytes": (_i64, []),
+    "creid_bn2d_fold_multi": (C.c_int, [_p, _i64, _p]),
+    "creid_stem_conv_fwd_affine": (C.c_int, [_i64, _i64, _i64, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "creid_conv2d_dgrad_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p]),
     "creid_conv2d_wgrad_workspace_bytes": (_sz, [_p, C.c_int]),
     "creid_conv2d_wgrad_nhwc": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _sz, C.c_int, _p]),

@@ -198,7 +198,7 @@ def _desc(B, H, W, cin, cout, k, stride, pad):
 
 class _ConvUnit:
     """conv + BN bookkeeping for one (holder conv, holder bn) pair."""
-    __slots__ = ("conv", "bn", "ibn", "w_krsc", "w_crsk", "k", "stride", "pad", "cin", "cout")
+    __slots__ = ("conv", "bn", "ibn", "w_krsc", "w_crsk", "k", "stride", "pad", "cin", "cout", "fold")
 
     def __init__(self, conv, bn):
         self.ibn = bn if isinstance(bn, IBN) else None
@@ -206,6 +206,7 @@ class _ConvUnit:
         self.k, self.stride, self.pad = conv.kernel_size, conv.stride, conv.padding
         self.cin, self.cout = conv.in_channels, conv.out_channels
         self.w_krsc = self.w_crsk = None
+        self.fold = None               # eval mode: BatchNorm as a per-channel affine, float [2][cout] (view of one flat buffer)
 
 
 class BackboneEngine:
@@ -274,6 +275,10 @@ class BackboneEngine:
         self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
         self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
+        # eval-mode forward: BatchNorm (running statistics = constants) folded into the producing convolution's epilogue --
+        # one launch per conv instead of conv -> finalize -> apply (CREID_EVAL_FOLD=0: the three-launch schedule)
+        self.eval_fold = os.environ.get("CREID_EVAL_FOLD", "1") == "1"
+        self._fold_key = None
 
     # ---- helpers
     @property
@@ -358,7 +363,79 @@ class BackboneEngine:
             u.bn.num_batches_tracked += self._pending_steps.to(u.bn.num_batches_tracked.device)
         self._pending_steps.zero_()
 
+    def fold_bn(self):
+        """Eval mode: (scale, shift) of every plain BatchNorm2d from its running statistics, ONE launch over a device
+        table (rebuilt only if a tensor moved); always re-evaluated, so statistics updated by a training step or a
+        load_state_dict are picked up without any dirty tracking."""
+        import numpy as np
+        lib, st = L.lib(), L.stream()
+        units = [u for u in self.all_units() if u.ibn is None]
+        key = tuple((u.bn.weight.data_ptr(), u.bn.bias.data_ptr(), u.bn.running_mean.data_ptr(),
+                     u.bn.running_var.data_ptr()) for u in units)
+        if self._fold_key != key:
+            total = sum(2 * u.cout for u in units)
+            self._fold_buf = torch.empty(total, dtype=torch.float32, device=self.device)
+            rec = np.zeros(len(units), dtype=np.dtype([("g", "<u8"), ("b", "<u8"), ("m", "<u8"), ("v", "<u8"), ("o", "<u8"),
+                                                       ("C", "<i4"), ("eps", "<f4")]))
+            assert lib.creid_bn2d_fold_entry_bytes() == rec.dtype.itemsize == 48
+            o = 0
+            for i, u in enumerate(units):
+                u.fold = self._fold_buf[o:o + 2 * u.cout].view(2, u.cout)
+                rec[i] = (u.bn.weight.data_ptr(), u.bn.bias.data_ptr(), u.bn.running_mean.data_ptr(),
+                          u.bn.running_var.data_ptr(), u.fold.data_ptr(), u.cout, u.bn.eps)
+                o += 2 * u.cout
+            self._fold_tab = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+            self._fold_n = len(units)
+            self._fold_key = key
+        L.check(lib.creid_bn2d_fold_multi(L.ptr(self._fold_tab), self._fold_n, st), "bn2d_fold_multi")
+
     # ---- layer steps
+    def _conv_fold(self, u, a_in, B, H, W, relu, residual=None):
+        """Eval mode: conv -> folded BatchNorm -> (+residual) -> (ReLU) in one launch.  Returns (a_out, oh, ow)."""
+        lib, st = L.lib(), L.stream()
+        d, oh, ow = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
+        a = self._empty(B * oh * ow, u.cout)
+        L.check(lib.creid_conv2d_fwd_affine_nhwc(C.byref(d), L.ptr(a_in), L.ptr(u.w_krsc), L.ptr(a), L.ptr(u.fold),
+                                                 L.ptr(residual), 1 if relu else 0, self.dt, st), "conv2d_fwd_affine")
+        return a, oh, ow
+
+    def _forward_eval_folded(self, x_nchw, want_base_out):
+        """validation_step / inference forward (modelling/bases.py:169-177, inference/inference_utils.py:104-113): 53
+        convolutions with their BatchNorm folded in + pad, max-pool, GAP -- no statistics, no separate normalisation
+        passes.  IBN blocks (resnet_ibn_a.py:27-32) keep their own pass: InstanceNorm needs per-image statistics."""
+        lib, st = L.lib(), L.stream()
+        B, _, H, W = x_nchw.shape
+        self.fold_bn()
+        xpad = self._empty(B, H + 8, W + 6, 4)
+        L.check(lib.creid_image_to_nhwc4_pad(L.ptr(x_nchw), B, H, W, self.dt, L.ptr(xpad), st), "image_pad")
+        H1, W1 = H // 2, W // 2
+        y0 = self._empty(B * H1 * W1, 64)
+        L.check(lib.creid_stem_conv_fwd_affine(B, H, W, L.ptr(xpad), L.ptr(self.stem.w_krsc), L.ptr(y0), L.ptr(self.stem.fold),
+                                               1 if self.net.stem_relu else 0, self.dt, st), "stem_conv_fwd_affine")
+        H2, W2 = H1 // 2, W1 // 2
+        a = self._empty(B * H2 * W2, 64)
+        idx0 = self._empty(B * H2 * W2, 64, dtype=torch.uint8)
+        L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, self.dt, L.ptr(a), L.ptr(idx0), st), "maxpool_fwd")
+        del xpad, y0
+        h, w = H2, W2
+        for b in self.blocks:
+            a_in, hin, win = a, h, w
+            if b["c1"].ibn is not None:
+                _, a1, _, _, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, False, True)
+            else:
+                a1, h1, w1 = self._conv_fold(b["c1"], a_in, B, hin, win, True)
+            a2, h2, w2 = self._conv_fold(b["c2"], a1, B, h1, w1, True)
+            r = a_in if b["ds"] is None else self._conv_fold(b["ds"], a_in, B, hin, win, False)[0]
+            a, h, w = self._conv_fold(b["c3"], a2, B, h2, w2, True, residual=r)
+        feat = self._empty(B, 2048, dtype=torch.float32)
+        L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), st), "gap_fwd")
+        self.saved = None
+        base_out = None
+        if want_base_out:
+            base_out = self._empty(B, 2048, h, w, dtype=torch.float32)
+            L.check(lib.creid_nhwc_to_nchw_f32(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(base_out), st), "nhwc_to_nchw")
+        return base_out, feat
+
     def _conv_bn(self, u, a_in, B, H, W, training, relu, residual=None):
         """conv -> BN(batch or running stats) -> (+residual) -> (ReLU).  Returns (x_raw, a_out, mean, invstd, oh, ow)."""
         lib, st = L.lib(), L.stream()
@@ -446,6 +523,8 @@ class BackboneEngine:
             self.prep_weights()
         lib, st = L.lib(), L.stream()
         B, _, H, W = x_nchw.shape
+        if not training and self.eval_fold:
+            return self._forward_eval_folded(x_nchw, want_base_out)
         sv = {"B": B, "H": H, "W": W, "training": training}
         if training:      # one counter kernel per step instead of 53 per-layer `num_batches_tracked += 1`
             if self._pending_steps is None:

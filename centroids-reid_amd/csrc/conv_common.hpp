@@ -31,6 +31,9 @@ struct IGemmGeom {
   const unsigned char* add_mask;   // nullable (full-resolution add_src only): bit mask applied to add_src before the add,
                                    // one byte per 8 channels -- the residual-branch gradient is then the UNMASKED incoming
                                    // gradient plus the ReLU bits, and no masked copy has to be written and re-read
+  const float* epi_scale;   // nullable: per-output-channel affine y = acc * scale + shift applied to the fp32 accumulators --
+  const float* epi_shift;   // eval-mode BatchNorm (running statistics are constants) folded into the convolution
+  int epi_relu;             // ReLU after the affine and after "+ add_src" (the block's residual) when that is given
 };
 
 static inline void igemm_finish_geom(IGemmGeom& g) {
@@ -39,6 +42,9 @@ static inline void igemm_finish_geom(IGemmGeom& g) {
   g.add_compact = 0;
   g.parity = 0;
   g.add_mask = nullptr;
+  g.epi_scale = nullptr;
+  g.epi_shift = nullptr;
+  g.epi_relu = 0;
 }
 
 // Source pixel of output row (oy, ox) under tap (r, s); returns false when it falls outside.

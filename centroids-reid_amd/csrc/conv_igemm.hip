@@ -462,6 +462,28 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     }
   }
   float s1v[TNW], s2v[TNW];
+  if (g.epi_scale) {
+    // eval-mode BatchNorm folded into the convolution: y = acc * scale[c] + shift[c] on the fp32 accumulators (a lane's
+    // column is fixed per j), ReLU here unless the block's residual is still to be added in the copy-out
+    const bool relu_now = g.epi_relu && !add_src;
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int cl = wn * (BN / 2) + j * 32 + l31;
+      const float sc = g.epi_scale[col0 + cl], sh = g.epi_shift[col0 + cl];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rl = wm * 64 + i * 32 + 8 * q + 4 * kh;
+          float v0 = fmaf(acc[i][j][4 * q], sc, sh), v1 = fmaf(acc[i][j][4 * q + 1], sc, sh);
+          float v2 = fmaf(acc[i][j][4 * q + 2], sc, sh), v3 = fmaf(acc[i][j][4 * q + 3], sc, sh);
+          if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+        }
+      }
+      s1v[j] = 0.f; s2v[j] = 0.f;
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < TNW; ++j) {
     const int cl = wn * (BN / 2) + j * 32 + l31;
@@ -481,6 +503,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     }
     s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
     s1v[j] = s1; s2v[j] = s2;
+  }
   }
   __syncthreads();
   constexpr int NIT = (128 * CPR) / 256;
@@ -541,8 +564,9 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
           for (int q = 0; q < 4; ++q) {
             const float alo = ((am >> (2 * q)) & 1u) ? __uint_as_float(aw[q] << 16) : 0.f;
             const float ahi = ((am >> (2 * q + 1)) & 1u) ? __uint_as_float(aw[q] & 0xffff0000u) : 0.f;
-            const float lo = __uint_as_float(vw[q] << 16) + alo;
-            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + ahi;
+            float lo = __uint_as_float(vw[q] << 16) + alo;
+            float hi = __uint_as_float(vw[q] & 0xffff0000u) + ahi;
+            if (g.epi_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }     // folded BatchNorm + residual: ReLU after the add
             vw[q] = f32x2_to_bf16x2_bits(lo, hi);
           }
         }
@@ -831,7 +855,27 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   // and the copy-out gets its row-major 16-byte chunks back through the transposing LDS read.  Column pitch 264 B:
   // 16 consecutive columns start 2 banks apart (conflict-free b64 stores), the 4 x 4 units of a transposing read too.
   float s1v[TNW], s2v[TNW];
-  if (!producer) {
+  if (!producer && g.epi_scale) {
+    // eval-mode BatchNorm folded into the convolution (see igemm_bf16_dma_kernel)
+    const bool relu_now = g.epi_relu && !add_src;
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int cl = wn * (BN / 2) + j * 32 + l31;
+      const float sc = g.epi_scale[col0 + cl], sh = g.epi_shift[col0 + cl];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rl = wm * 64 + i * 32 + 8 * q + 4 * kh;
+          float v0 = fmaf(acc[i][j][4 * q], sc, sh), v1 = fmaf(acc[i][j][4 * q + 1], sc, sh);
+          float v2 = fmaf(acc[i][j][4 * q + 2], sc, sh), v3 = fmaf(acc[i][j][4 * q + 3], sc, sh);
+          if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+        }
+      }
+      s1v[j] = 0.f; s2v[j] = 0.f;
+    }
+  } else if (!producer) {
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
       const int cl = wn * (BN / 2) + j * 32 + l31;
@@ -916,8 +960,9 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
           for (int q = 0; q < 4; ++q) {
             const float alo = ((am >> (2 * q)) & 1u) ? __uint_as_float(aw[q] << 16) : 0.f;
             const float ahi = ((am >> (2 * q + 1)) & 1u) ? __uint_as_float(aw[q] & 0xffff0000u) : 0.f;
-            const float lo = __uint_as_float(vw[q] << 16) + alo;
-            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + ahi;
+            float lo = __uint_as_float(vw[q] << 16) + alo;
+            float hi = __uint_as_float(vw[q] & 0xffff0000u) + ahi;
+            if (g.epi_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }     // folded BatchNorm + residual: ReLU after the add
             vw[q] = f32x2_to_bf16x2_bits(lo, hi);
           }
         }
@@ -1077,6 +1122,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IGemmGeom g, const float
     const int cl = wn * (BN / 2) + j * 32 + l31;
     const int c = col0 + cl;
     float s1 = 0.f, s2 = 0.f;
+    const float esc = g.epi_scale ? g.epi_scale[c] : 1.f, esh = g.epi_scale ? g.epi_shift[c] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -1084,7 +1130,9 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IGemmGeom g, const float
         const int rr = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (rr < g.M) {
           float v = acc[i][j][r];
+          if (g.epi_scale) v = fmaf(v, esc, esh);                   // folded eval-mode BatchNorm: bn2d_apply_kernel's arithmetic
           if (add_src) v += add_src[(int64_t)rr * g.N + c];
+          if (g.epi_relu) v = fmaxf(v, 0.f);
           s1 += v; s2 = fmaf(v, v, s2);
           out[(int64_t)rr * g.N + c] = v;
         }
@@ -1141,7 +1189,7 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
     const char* fe = getenv("CREID_STREAM1X1");                    // read per call: tests toggle it
     const int force_stream = fe ? atoi(fe) : 0;
     const bool plain_1x1 = dtype == CREID_BF16 && !g.transposed && g.K == (1 << g.log2span) && g.stride == 1 && g.pad == 0 &&
-                           g.kw == 1 && g.check_bounds && !add_src && !bnred.x && !wred.ws && g.pitch == g.K;
+                           g.kw == 1 && g.check_bounds && !add_src && !bnred.x && !wred.ws && g.pitch == g.K && !g.epi_scale;
     if (plain_1x1 && (force_stream || tuned_stream)) {
       const int rc = launch_stream1x1(g.M, g.K, g.N, src, wgt, out, bn_part, s);
       if (rc != CREID_E_SHAPE) return rc;
@@ -1202,8 +1250,8 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
                         default: CREID_DMA_LAUNCH(64, 2); break; }
     }
 #undef CREID_DMA_LAUNCH
-  } else if (bnred.x || g.add_mask) {
-    return CREID_E_DTYPE;          // the fused reduction / masked add exist only in the bf16 LDS-DMA kernels
+  } else if (bnred.x || g.add_mask || (g.epi_scale && dtype == CREID_BF16)) {
+    return CREID_E_DTYPE;          // the fused reduction / masked add / folded BatchNorm exist only in the bf16 LDS-DMA kernels
   } else if (wred.ws && wgrad_reduce_job_launch(wred, s) != 0) {
     return (int)hipGetLastError();
   } else if (dtype == CREID_BF16) {
@@ -1257,6 +1305,23 @@ int creid_conv2d_fwd_nhwc(const creid_conv_desc* d, const void* x, const void* w
   g.K = (int)(d->kh * d->kw * d->in_c); g.N = (int)d->out_c; g.check_bounds = 1;
   igemm_finish_geom(g);
   return launch_igemm(g, x, w_krsc, y, nullptr, bn_partial, dtype, as_stream(stream));
+}
+
+/* Forward convolution with an eval-mode BatchNorm folded into the epilogue: y = act(conv(x) * scale + shift (+ residual)),
+ * scale_shift = [2][out_c] fp32 (creid_bn2d_fold_multi), act = ReLU when relu != 0.  No statistics, no second pass. */
+int creid_conv2d_fwd_affine_nhwc(const creid_conv_desc* d, const void* x, const void* w_krsc, void* y, const float* scale_shift,
+                                 const void* residual, int relu, int dtype, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CREID_CHECK_ARG(x && w_krsc && y && scale_shift);
+  IGemmGeom g;
+  g.M = (int)(d->batch * d->out_h * d->out_w); g.OH = (int)d->out_h; g.OW = (int)d->out_w;
+  g.SH = (int)d->in_h; g.SW = (int)d->in_w; g.pitch = (int)d->in_c; g.log2span = ilog2_exact(d->in_c);
+  g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.transposed = 0;
+  g.K = (int)(d->kh * d->kw * d->in_c); g.N = (int)d->out_c; g.check_bounds = 1;
+  igemm_finish_geom(g);
+  g.epi_scale = scale_shift; g.epi_shift = scale_shift + d->out_c; g.epi_relu = relu ? 1 : 0;
+  return launch_igemm(g, x, w_krsc, y, residual, nullptr, dtype, as_stream(stream));
 }
 
 int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx, const void* add_src,
@@ -1353,6 +1418,20 @@ int creid_stem_conv_fwd(int64_t batch, int64_t H, int64_t W, const void* xpad, c
   g.kw = 1; g.stride = 2; g.pad = 0; g.transposed = 0; g.K = 256; g.N = 64; g.check_bounds = 0;
   igemm_finish_geom(g);
   return launch_igemm(g, xpad, w_stem, y, nullptr, bn_partial, dtype, as_stream(stream));
+}
+
+/* the stem with its eval-mode BatchNorm (and, for the IBN-a variant, ReLU) folded into the epilogue */
+int creid_stem_conv_fwd_affine(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* w_stem, void* y,
+                               const float* scale_shift, int relu, int dtype, void* stream) {
+  CREID_CHECK_ARG(xpad && w_stem && y && scale_shift && batch > 0 && H > 0 && W > 0);
+  if (H % 2 || W % 2) return CREID_E_SHAPE;
+  IGemmGeom g;
+  g.M = (int)(batch * (H / 2) * (W / 2)); g.OH = (int)(H / 2); g.OW = (int)(W / 2);
+  g.SH = (int)(H + 8); g.SW = (int)(W + 6); g.pitch = 4; g.log2span = 5;
+  g.kw = 1; g.stride = 2; g.pad = 0; g.transposed = 0; g.K = 256; g.N = 64; g.check_bounds = 0;
+  igemm_finish_geom(g);
+  g.epi_scale = scale_shift; g.epi_shift = scale_shift + 64; g.epi_relu = relu ? 1 : 0;
+  return launch_igemm(g, xpad, w_stem, y, nullptr, nullptr, dtype, as_stream(stream));
 }
 
 }  // extern "C"

@@ -654,6 +654,21 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
   }
 }
 
+// Eval-mode BatchNorm as a per-channel affine, every layer of the network in ONE launch: a device table of
+// {gamma, beta, running_mean, running_var, out[2][C], C, eps}; one workgroup per entry.  scale = gamma / sqrt(var + eps),
+// shift = beta - mean * scale -- the arithmetic of bn2d_finalize_kernel's eval branch (and of torch's CPU eval transform),
+// so that the folded convolution epilogue (conv_igemm.hip, g.epi_scale) equals finalize + apply.
+struct BnFoldEntry { const float* gamma; const float* beta; const float* mean; const float* var; float* out; int C; float eps; };
+__global__ __launch_bounds__(256) void bn_fold_multi_kernel(const BnFoldEntry* __restrict__ tab) {
+  const BnFoldEntry e = tab[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += 256) {
+    const float mu = e.mean[c], is = 1.0f / sqrtf(e.var[c] + e.eps);
+    const float sc = is * (e.gamma ? e.gamma[c] : 1.f);
+    e.out[c] = sc;
+    e.out[e.C + c] = (e.beta ? e.beta[c] : 0.f) - mu * sc;
+  }
+}
+
 // All convolutions in ONE launch: a device table of {src, krsc, crsk, O, I, kh, kw, first element}; each
 // thread finds its tensor by binary search over the cumulative element counts.
 struct WPrepEntry { const float* w; void* krsc; void* crsk; int O, I, kh, kw; int64_t start; };
@@ -951,6 +966,15 @@ int creid_weight_prep_multi(const void* table_dev, const int32_t* tile_start_dev
                                 (const WPrepEntry*)table_dev, (int)n_entries, tile_start_dev),
              hipLaunchKernelGGL(weight_prep_multi_kernel<unsigned short>, dim3((unsigned)total_tiles), dim3(256), 0, s,
                                 (const WPrepEntry*)table_dev, (int)n_entries, tile_start_dev));
+  CREID_LAUNCH_RET();
+}
+
+int64_t creid_bn2d_fold_entry_bytes(void) { return (int64_t)sizeof(BnFoldEntry); }
+
+int creid_bn2d_fold_multi(const void* table_dev, int64_t n_entries, void* stream) {
+  CREID_CHECK_ARG(table_dev && n_entries > 0 && n_entries < (1 << 20));
+  hipLaunchKernelGGL(bn_fold_multi_kernel, dim3((unsigned)n_entries), dim3(256), 0, as_stream(stream),
+                     (const BnFoldEntry*)table_dev);
   CREID_LAUNCH_RET();
 }
 

@@ -44,6 +44,33 @@ def conv2d_fwd(x, w_krsc, stride, pad, with_stats=False):
     return (y, part) if with_stats else y
 
 
+def bn_fold(gamma, beta, running_mean, running_var, eps=1e-5):
+    """Eval-mode BatchNorm as scale_shift float [2, C] (one-entry creid_bn2d_fold_multi table)."""
+    import numpy as np
+    Cc = running_mean.numel()
+    out = torch.empty((2, Cc), dtype=torch.float32, device=running_mean.device)
+    rec = np.zeros(1, dtype=np.dtype([("g", "<u8"), ("b", "<u8"), ("m", "<u8"), ("v", "<u8"), ("o", "<u8"), ("C", "<i4"),
+                                      ("eps", "<f4")]))
+    rec[0] = (gamma.data_ptr() if gamma is not None else 0, beta.data_ptr() if beta is not None else 0,
+              running_mean.data_ptr(), running_var.data_ptr(), out.data_ptr(), Cc, eps)
+    tab = torch.from_numpy(rec.view(np.uint8).copy()).to(out.device)
+    L.check(L.lib().creid_bn2d_fold_multi(L.ptr(tab), 1, L.stream()), "bn2d_fold_multi")
+    torch.cuda.current_stream().synchronize()      # `tab` must outlive the launch
+    return out
+
+
+def conv2d_fwd_affine(x, w_krsc, stride, pad, scale_shift, residual=None, relu=True):
+    """Eval-mode conv -> BatchNorm(scale_shift [2, Cout]) -> (+residual) -> (ReLU) in one launch."""
+    L.require_gpu(x, w_krsc, scale_shift, residual)
+    B, H, W, cin = x.shape
+    cout, k = w_krsc.shape[0], w_krsc.shape[1]
+    d, oh, ow = conv_desc(B, H, W, cin, cout, k, stride, pad)
+    y = torch.empty((B, oh, ow, cout), dtype=x.dtype, device=x.device)
+    L.check(L.lib().creid_conv2d_fwd_affine_nhwc(C.byref(d), L.ptr(x), L.ptr(w_krsc), L.ptr(y), L.ptr(scale_shift),
+                                                 L.ptr(residual), 1 if relu else 0, _dt(x), L.stream()), "conv2d_fwd_affine")
+    return y
+
+
 def conv2d_dgrad(dy, w_crsk, in_hw, stride, pad, add_src=None):
     L.require_gpu(dy, w_crsk)
     B, oh, ow, cout = dy.shape

@@ -281,6 +281,20 @@ typedef struct {
 int64_t creid_conv2d_bn_partial_rows(const creid_conv_desc* d);
 int creid_conv2d_fwd_nhwc(const creid_conv_desc* d, const void* x, const void* w_krsc, void* y,
                           float* bn_partial, int dtype, void* stream);
+/* Eval-mode forward of conv -> BatchNorm -> (+ residual) -> (ReLU) in ONE launch (modelling/backbones/resnet.py:67-87 under
+ * model.eval(), the path of validation_step, modelling/bases.py:169-177, and of inference/inference_utils.py:104-113): with
+ * running statistics BatchNorm is the per-channel affine scale_shift = float[2][out_c] {gamma / sqrt(var + eps),
+ * beta - mean * scale} (creid_bn2d_fold_multi), applied to the fp32 accumulators in the epilogue:
+ * y = act(conv(x) * scale + shift (+ residual)), act = ReLU when relu != 0; residual (nullable) has y's shape and dtype.
+ * Same arithmetic as creid_conv2d_fwd_nhwc + creid_bn2d_finalize(training = 0) + creid_bn2d_apply, without the two extra
+ * passes (fp32 mode: bit-identical; bf16 mode: the conv output is rounded once, after the affine, instead of twice). */
+int creid_conv2d_fwd_affine_nhwc(const creid_conv_desc* d, const void* x, const void* w_krsc, void* y,
+                                 const float* scale_shift, const void* residual, int relu, int dtype, void* stream);
+/* Folds MANY BatchNorm layers in one launch.  table_dev = device array of n_entries records { const float* gamma (nullable);
+ * const float* beta (nullable); const float* running_mean; const float* running_var; float* out (float[2][C]); int32 C;
+ * float eps } (48 bytes, creid_bn2d_fold_entry_bytes()). */
+int64_t creid_bn2d_fold_entry_bytes(void);
+int creid_bn2d_fold_multi(const void* table_dev, int64_t n_entries, void* stream);
 /* data gradient: dx = conv_transpose(dy, w) (+ add_src if non-NULL); w_crsk is [in_c][kh][kw][out_c]. */
 int creid_conv2d_dgrad_nhwc(const creid_conv_desc* d, const void* dy, const void* w_crsk, void* dx,
                             const void* add_src, int dtype, void* stream);
@@ -349,6 +363,9 @@ int creid_conv2d_wgrad_reduce(const creid_conv_desc* d, float* dw_oihw, int accu
  * xpad [B, H+8, W+6, 4] made by creid_image_to_nhwc4_pad; w_stem [64][8][32] from creid_stem_weight_prep. */
 int creid_stem_conv_fwd(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* w_stem, void* y,
                         float* bn_partial, int dtype, void* stream);
+/* the stem with its eval-mode BatchNorm (scale_shift float[2][64]) and optional ReLU (resnet_ibn_a.py:129) folded in */
+int creid_stem_conv_fwd_affine(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* w_stem, void* y,
+                               const float* scale_shift, int relu, int dtype, void* stream);
 size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype);
 int creid_stem_conv_wgrad(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* dy,
                           float* dw_oihw, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -1,0 +1,131 @@
+"""GPU parity: the eval-mode forward with BatchNorm folded into the convolution epilogue (creid_conv2d_fwd_affine_nhwc,
+creid_stem_conv_fwd_affine, creid_bn2d_fold_multi) -- the path of validation_step (modelling/bases.py:169-177) and of
+inference/inference_utils.py:104-113.  Layer level against a torch fp64 reference of conv -> eval BatchNorm -> (+residual)
+-> ReLU; network level against the three-launch schedule (conv, finalize, apply) it replaces: bit-identical in fp32 parity
+mode, and the reference goldens' `eval_feat` are checked by tests/test_backbone_gpu.py through the folded path (default)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, H, W, cin, cout, k, stride, residual, relu
+    (2, 16, 8, 64, 64, 1, 1, False, True),
+    (2, 16, 8, 64, 64, 3, 1, False, True),
+    (2, 16, 8, 64, 256, 1, 1, True, True),
+    (4, 16, 8, 128, 128, 3, 2, False, True),
+    (2, 16, 8, 256, 512, 1, 2, False, False),      # downsample branch: no ReLU
+    (1, 10, 10, 64, 256, 1, 1, True, True),        # M = 100: partial tile
+    (2, 8, 4, 512, 512, 3, 1, False, True),
+    (1, 6, 6, 1024, 2048, 1, 1, True, True),
+    (8, 16, 8, 512, 2048, 1, 1, True, True),       # N tile 128, several row tiles
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_affine_layer(case, dtype):
+    from centroids_reid_amd import layers as ly
+    B, H, W, cin, cout, k, stride, with_res, relu = case
+    pad = k // 2
+    rng = np.random.default_rng(sum(int(c) for c in case))
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    beta = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.3)
+    rm = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.2)
+    rv = torch.from_numpy(rng.uniform(0.5, 2.0, cout).astype(np.float32))
+    y = F.conv2d(x.to(dtype).double(), w.to(dtype).double(), stride=stride, padding=pad)
+    y = F.batch_norm(y, rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.0, 1e-5)
+    res = None
+    if with_res:
+        res = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(dtype)
+        y = y + res.double()
+    if relu:
+        y = y.clamp(min=0)
+    krsc, _ = ly.weight_prep(w.cuda(), dtype)
+    ss = ly.bn_fold(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda())
+    sc = gamma / torch.sqrt(rv + 1e-5)
+    np.testing.assert_allclose(ss[0].cpu().numpy(), sc.numpy(), rtol=2e-6)
+    np.testing.assert_allclose(ss[1].cpu().numpy(), (beta - rm * sc).numpy(), rtol=1e-5, atol=1e-6)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    rg = res.permute(0, 2, 3, 1).contiguous().cuda() if res is not None else None
+    yg = ly.conv2d_fwd_affine(xg, krsc, stride, pad, ss, rg, relu)
+    rt, at = (3e-2, 3e-2) if dtype == torch.bfloat16 else (1e-4, 1e-4)
+    np.testing.assert_allclose(yg.float().cpu().permute(0, 3, 1, 2).numpy(), y.float().numpy(), rtol=rt, atol=at)
+    if relu:
+        assert float(yg.float().min()) >= 0.0
+
+
+def _eval_feat(arch, dtype, fold, x, sd):
+    from centroids_reid_amd import backbone as bb
+    os.environ["CREID_EVAL_FOLD"] = "1" if fold else "0"
+    try:
+        net = (bb.ResNet(last_stride=1) if arch == "resnet50" else bb.resnet50_ibn_a(1)).cuda()
+        net.load_state_dict(sd, strict=False)
+        eng = bb.BackboneEngine(net, dtype)
+        with torch.no_grad():
+            base, feat = eng.forward(x, False, True)
+        return base, feat, eng
+    finally:
+        os.environ.pop("CREID_EVAL_FOLD", None)
+
+
+@pytest.mark.parametrize("arch,H,W", [("resnet50", 64, 32), ("resnet50", 256, 128), ("resnet50_ibn_a", 64, 64)])
+def test_folded_eval_forward_equals_three_launch_schedule_fp32(arch, H, W):
+    """fp32 parity mode: conv + finalize(eval) + apply and the folded epilogue run the same fmaf / add / max per element."""
+    from oracle import backbone_oracle as bo
+    sd = {k: v.cuda() for k, v in bo.make_state_dict(arch, 1, seed=11).items()}
+    x = bo.synthetic_images(3, H, W, seed=2).cuda()
+    b0, f0, _ = _eval_feat(arch, torch.float32, False, x, sd)
+    b1, f1, eng = _eval_feat(arch, torch.float32, True, x, sd)
+    assert torch.equal(f0, f1), float((f0 - f1).abs().max())
+    assert torch.equal(b0, b1)
+    # the folded constants follow the running statistics: perturb them and the result must follow, with no dirty flag
+    with torch.no_grad():
+        eng.net.layer2[0].bn2.running_var.mul_(1.7)
+        _, f2 = eng.forward(x, False, False)
+    assert not torch.equal(f1, f2)
+
+
+@pytest.mark.parametrize("arch,H,W", [("resnet50", 256, 128), ("resnet50_ibn_a", 64, 64)])
+def test_folded_eval_forward_bf16_close_to_fp32(arch, H, W):
+    from oracle import backbone_oracle as bo
+    sd = {k: v.cuda() for k, v in bo.make_state_dict(arch, 1, seed=12).items()}
+    x = bo.synthetic_images(4, H, W, seed=3).cuda()
+    _, f32, _ = _eval_feat(arch, torch.float32, True, x, sd)
+    _, fbf, _ = _eval_feat(arch, torch.bfloat16, True, x, sd)
+    _, fbu, _ = _eval_feat(arch, torch.bfloat16, False, x, sd)
+    cos = F.cosine_similarity(f32, fbf, dim=1)
+    cos_u = F.cosine_similarity(f32, fbu, dim=1)
+    assert float(cos.min()) > 0.995, cos
+    # one rounding per layer instead of two: the folded bf16 forward is no further from fp32 than the unfolded one (+ slack)
+    assert float((1 - cos).max()) <= 1.5 * float((1 - cos_u).max()) + 1e-4
+
+
+def test_eval_forward_after_training_step_uses_fresh_statistics():
+    """train -> eval -> train: the folded constants are rebuilt from the running statistics on every eval forward."""
+    from oracle import backbone_oracle as bo
+    from centroids_reid_amd import backbone as bb
+    sd = {k: v.cuda() for k, v in bo.make_state_dict("resnet50", 1, seed=13).items()}
+    net = bb.ResNet(last_stride=1).cuda()
+    net.load_state_dict(sd, strict=False)
+    eng = bb.BackboneEngine(net, torch.float32)
+    x = bo.synthetic_images(4, 64, 32, seed=4).cuda()
+    with torch.no_grad():
+        _, e0 = eng.forward(x, False)
+        eng.forward(x, True)                      # updates every running statistic
+        eng.saved = None
+        _, e1 = eng.forward(x, False)
+    os.environ["CREID_EVAL_FOLD"] = "0"
+    try:
+        eng2 = bb.BackboneEngine(net, torch.float32)
+        with torch.no_grad():
+            _, e2 = eng2.forward(x, False)
+    finally:
+        os.environ.pop("CREID_EVAL_FOLD", None)
+    assert not torch.equal(e0, e1)
+    assert torch.equal(e1, e2)
