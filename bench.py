@@ -35,8 +35,11 @@ def ddp_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force = os.environ.get("CREID_FORCE_DIST", "0") == "1"          # one-rank RCCL group: exercises the data-parallel path on one GPU
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force and world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("CREID_DIST_BACKEND", "nccl")      # "gloo" + CREID_SINGLE_DEVICE=1: control-flow
         if os.environ.get("CREID_SINGLE_DEVICE", "0") == "1":        # test of the N>1 path on a one-GPU box
@@ -123,7 +126,7 @@ def pmc_field(key, field):
         return None
 
 
-def run_eval(args, rank, world, steps=None, warmup=None):
+def run_eval(args, rank, world, steps=None, warmup=None, shape=None, extras=True):
     """BASELINE configs[4]: normalise + squared-L2 + rank + CMC/mAP over 2228 x 17661 x 2048 fp32.  Timed twice:
     the METRIC-ONLY path the validation hook uses (streamed: the m x n matrix is never written; `value`) and the
     materialised path (distance matrix + int64 ranked indices, what get_similar / the rank-index goldens need)."""
@@ -131,12 +134,13 @@ def run_eval(args, rank, world, steps=None, warmup=None):
     from centroids_reid_amd import parallel as par
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
-    nq, ng, D = 2228, 17661, 2048
+    nq, ng, D = shape or (2228, 17661, 2048)
     feats, pids, cams = eval_inputs(nq, ng, D, rank, world)
     # weak scaling: every rank ranks its own nq queries against the (all-gathered) gallery
     q_pids = torch.as_tensor(pids[:nq], device="cuda"); g_pids = torch.as_tensor(pids[nq:], device="cuda")
     q_cams = torch.as_tensor(cams[:nq], device="cuda"); g_cams = torch.as_tensor(cams[nq:], device="cuda")
-    plan = rm.StreamPlan(pids[:nq], pids[nq:], cams[:nq], cams[nq:], "cuda")     # index structures: resident inputs
+    plan = rm.StreamPlan.on_device(pids, cams, nq, "cuda").finish()               # for the per-kernel timings below
+    metric = rm.R1_mAP(num_query=nq, streamed=True)
     glo, ghi = par.shard_bounds(ng, rank, world)
     gal_shard = feats[nq + glo:nq + ghi].contiguous() if world > 1 else None
     gcounts = [par.shard_bounds(ng, r, world)[1] - par.shard_bounds(ng, r, world)[0] for r in range(world)]
@@ -147,9 +151,11 @@ def run_eval(args, rank, world, steps=None, warmup=None):
         return feats
 
     def step_streamed():
-        fn, sq = rm.l2_normalize(gathered(), return_sqnorm=True)
-        v, a, fr = rm.stream_eval(fn[:nq], fn[nq:], sq[:nq].contiguous(), sq[nq:].contiguous(), plan)
-        return rm.eval_reduce_device(v, a, fr, 50)
+        # END TO END: exactly what get_val_metrics calls (modelling/bases.py:264-297 -> utils/reid_metric.py:112-151): host label
+        # vectors in, (cmc, mAP, topk) on the host out -- label upload, device index build, normalise, positives, streamed
+        # contraction + count, finalize, means, read-back, every host synchronisation included
+        cmc, m_ap, topk = metric.compute(gathered(), pids, cams)
+        return cmc, torch.tensor([m_ap], dtype=torch.float64), topk
 
     def step_materialised():
         fn, sq = rm.l2_normalize(gathered(), return_sqnorm=True)
@@ -171,8 +177,14 @@ def run_eval(args, rank, world, steps=None, warmup=None):
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()), out
 
-    dt_m, out_m = timed(step_materialised)
-    dt, out = timed(step_streamed)
+    _quiet = open(os.devnull, "w")
+    _so, sys.stdout = sys.stdout, _quiet                   # R1_mAP.compute mirrors the reference's banner print per call
+    try:
+        dt_m, out_m = timed(step_materialised)
+        dt, out = timed(step_streamed)
+    finally:
+        sys.stdout = _so
+        _quiet.close()
     pairs = float(nq) * ng * world * steps
     mAP = float(out[1].item())
     assert abs(mAP - float(out_m[1].item())) < 1e-12, "streamed and materialised evaluation disagree"
@@ -199,6 +211,10 @@ def run_eval(args, rank, world, steps=None, warmup=None):
                                            L.ptr(plan.g_pids), cap, L.ptr(pos_key), L.ptr(pos_idx), L.ptr(npos), L.ptr(hist),
                                            L.stream()), "count")
         poslist()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            rm.StreamPlan.on_device(pids, cams, nq, "cuda").finish()
+        t_plan = (time.perf_counter() - t0) / 5 * 1e3           # host wall: upload + 5 launches + 8-byte read-back
         t_pos = time_kernel(poslist, 10)
         t_count = time_kernel(count, 10)
         t_dist = time_kernel(lambda: rm.get_euclidean(q, g, qq, gg), 10)
@@ -229,16 +245,31 @@ def run_eval(args, rank, world, steps=None, warmup=None):
         res["f16_vs_f32"] = {"sqdist_f16_ms": t_dist16, "sqdist_f16_TFLOPs": flops / (t_dist16 * 1e-3) / 1e12,
                              "sqdist_f32_ms": t_dist, "mAP_f16_minus_f32": float(map16.item()) - mAP,
                              "rank_index_agreement": float((idx16 == idx).float().mean().item())}
-        res["stages_ms"] = {"l2norm": t_norm, "poslist": t_pos, "sqdist_count": t_count}
+        res["stages_ms"] = {"l2norm": t_norm, "plan_device_build_wall": t_plan, "poslist": t_pos, "sqdist_count": t_count}
+        res["timed_region"] = ("R1_mAP(streamed=True).compute(device feats, host pids, host camids) -> host (cmc, mAP, topk): "
+                               "index build and every host sync inside the clock")
+        # BASELINE target line "HBM roofline on the distance matrix": the materialised fp32 matrix moves
+        # (m + n) * D * 4 + m * n * 4 algorithmic bytes; the contraction is MFMA-bound (2 D FLOP per 4 output bytes), so this
+        # fraction is capped at flops_floor / hbm_floor -- reported because the target is phrased in it
+        alg_bytes = (nq + ng) * D * 4 + nq * ng * 4
+        res["distance_matrix_hbm"] = {"kernel": "sqdist_f32_kernel (materialised matrix)", "bound": "hbm", "ms": t_dist,
+                                      "achieved": alg_bytes / (t_dist * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": alg_bytes / (t_dist * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "ceiling_frac": (alg_bytes / HBM_PEAK_GBS / 1e9) / (flops / MFMA_F32_TFLOPS / 1e12),
+                                      "note": "MFMA-bound kernel: f32-MFMA floor is 1/ceiling_frac x the HBM floor"}
         res["roofline_hbm_stages"] = {"l2norm_GBs": (nq + ng) * D * 8 / (t_norm * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS}
-        if not args.no_cpu_baseline and world == 1:             # the CPU leg is reported at N=1 only
+        if not args.no_cpu_baseline and world == 1 and extras:  # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline_eval(feats, pids, cams, nq, ng)
+        if not extras:
+            for k in ("f16_vs_f32", "roofline_hbm_stages"):
+                res.pop(k, None)
         res["mAP"] = mAP
     return {
         "metric": "eval_dist_pairs_per_sec", "value": pairs / dt, "unit": "pairs/s",
         "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32",
-        "config": {"workload": "DukeMTMC-shaped eval 2228x17661x2048: normalise + squared-L2 + rank + CMC/mAP, metric-only "
-                               "streamed path (BASELINE configs[4])",
+        "config": {"workload": f"{'DukeMTMC-shaped' if shape is None else 'north-star shape'} eval {nq}x{ng}x{D}: normalise + "
+                               "squared-L2 + rank + CMC/mAP end to end, metric-only streamed path"
+                               + (" (BASELINE configs[4])" if shape is None else " (BASELINE north_star 3000x15000)"),
                    "queries_per_rank": nq, "gallery": ng, "D": D,
                    "parallelism": f"query-shard x{world}, gallery all-gather" if world > 1 else "single"},
         **res}
@@ -262,7 +293,7 @@ def cpu_baseline_eval(feats, pids, cams, nq, ng):
 
 def cpu_baseline_train(P, K, H, W):
     """The CPU oracle (kind 'port': torch-CPU restatement of backbone + heads, autograd backward) on the host
-    cores, same synthetic shapes.  Bounded sample: ONE full 64-image step after a 8-image warm-up, on at most 32
+    cores, same synthetic shapes.  Bounded sample: five full 64-image steps after one warm-up step, on at most 32
     threads (torch-CPU convolutions get slower, not faster, when oversubscribed across hundreds of cores)."""
     from oracle import backbone_oracle as bo, reid_oracle as ro
     cores = min(32, os.cpu_count() or 1)
@@ -282,12 +313,14 @@ def cpu_baseline_train(P, K, H, W):
         _, feat = bo.backbone_forward(x, sd2, "resnet50", 1, training=True)
         o = ro.ctl_heads(feat, labels, is_real, bw, torch.zeros(2048), torch.zeros(2048), torch.ones(2048), fc, centers, p, K)
         o["total"].backward()
-    step(2)
-    t0 = time.perf_counter()
+    nsteps = int(os.environ.get("CREID_CPU_BASELINE_STEPS", "5"))     # >= 5 steps after 1 warm-up
     step(P)
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step(P)
     dt = time.perf_counter() - t0
-    return {"value": P * K / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 step of {P * K} images (fwd + bwd, no optimiser) after an 8-image warm-up, torch-CPU oracle",
+    return {"value": nsteps * P * K / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{nsteps} steps of {P * K} images (fwd + bwd, no optimiser) after 1 warm-up step, torch-CPU oracle",
             "seconds": dt}
 
 
@@ -307,8 +340,13 @@ def main():
     ap.add_argument("--workload", choices=["train", "eval"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU leg (profiling runs; the default run always reports it)")
+    ap.add_argument("--inner-trace", action="store_true", help=argparse.SUPPRESS)   # child of bench_train.insitu_trace
     args = ap.parse_args()
     rank, world = ddp_setup(args.gpus)
+    if args.inner_trace:
+        from centroids_reid_amd import bench_train
+        bench_train.inner_trace(args, barrier_sync)
+        return
     workload = args.workload
     if workload is None:
         try:
@@ -326,8 +364,11 @@ def main():
             # the other half of BASELINE.metric (eval query x gallery dist-pairs/s) rides in the same line, timed by
             # the same invocation: 5 steps after 2 warm-up of the configs[4] workload
             ev = run_eval(args, rank, world, steps=5, warmup=2)
+            ns = run_eval(args, rank, world, steps=5, warmup=2, shape=(3000, 15000, 2048), extras=False) if world == 1 else None
             if rank == 0:
                 ev["higher_is_better"] = True
+                if ns is not None:
+                    ev["north_star_3000x15000"] = ns
                 out["eval"] = ev
     else:
         args.steps = args.steps or 5

@@ -32,6 +32,7 @@ SIGNATURES = {
     "creid_cmc_ap_ranked_camsets": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_topk_rows": (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
     "creid_eval_reduce": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "creid_stream_plan": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "creid_stream_poslist": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "creid_stream_count": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "creid_stream_finalize": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p]),
@@ -138,8 +139,12 @@ def lib():
         if h.creid_abi_version() != 1:
             raise CreidError("libcreid_hip.so ABI version mismatch")
         _lib = h
-        load_tuned_plans()
+        global N_PLANS
+        N_PLANS = load_tuned_plans()
     return _lib
+
+
+N_PLANS = 0        # launch plans registered from tuned_plans.json (0: built-in tile / split / ring-depth rules only)
 
 
 PLANS_PATH = os.path.join(_HERE, "tuned_plans.json")

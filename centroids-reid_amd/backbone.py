@@ -795,6 +795,8 @@ class BackboneEngine:
                fin=None if (prev is None or part3 is None) else (prev[0]["c3"], part3, Min, prev[1]["m3"], prev[1]["i3"]))
             if self.on_group_done is not None and bi in self._group_first:
                 self._flush_wred()                       # the layer's last split reduction: nothing left to carry it
+                if self.wgrad_stream or self.reduce_stream:
+                    self._join_side()                    # side-stream weight gradients of this group must be ordered before the hook
                 self.on_group_done(self._group_first[bi])
         # stem
         xpad, x0, y0, mean0, invstd0, idx0 = sv["stem"]

@@ -75,6 +75,168 @@ def igemm_roofline(B, H, W, time_kernel, reps=5):
     return tot_flop / (tot_ms * 1e-3) / 1e12, tot_ms, worst[:3], worst[-3:]
 
 
+def igemm_step_flops(B, H, W):
+    """Algorithmic FLOPs of every launch of the igemm family in one training step: forward + data gradient of the 52
+    non-stem convolutions (2 * M * N * K each) and the stem's forward (7x7x3 taps)."""
+    fl = 0.0
+    for cin, cout, k, s, h, w in conv_shapes(B, H, W):
+        ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+        fl += 2 * (2.0 * B * ho * wo * cout * cin * k * k)
+    fl += 2.0 * B * (H // 2) * (W // 2) * 64 * 147
+    return fl
+
+
+def forward_flops(B, H, W, arch="resnet50"):
+    """Forward-only convolution FLOPs (8.11 GFLOP / image R50 256x128, 25.33 IBN-a 320x320 -- same formula)."""
+    fl = 2.0 * B * (H // 2) * (W // 2) * 64 * 147
+    for cin, cout, k, s, h, w in conv_shapes(B, H, W):
+        ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+        fl += 2.0 * B * ho * wo * cout * cin * k * k
+    return fl
+
+
+_GROUPS = [("igemm", r"igemm"), ("wgrad", r"wgrad_bf16|wgrad_f32|wgrad_reduce"), ("bn", r"bn2d_|ibn_|bn_apply|bn_bwd|bn_fold|col_stats"),
+           ("heads", r"triplet|center_|xent|bn1d|loo_|gemm_f32|ctl_step|scale_matrix"), ("optim", r"adam|sgd_scaled"),
+           ("pool_layout", r"maxpool|gap_|weight_prep|image_pad|nhwc")]
+
+
+def parse_step_trace(db_path):
+    """rocprofv3 kernel-trace .db of `bench.py --inner-trace` -> per-step kernel time by family, separately for the captured
+    training step (segments that contain the Adam kernel) and the eval-mode embedding forward (segments that do not).
+    A segment = the kernels from one image_pad launch to the next; the last segment of each kind is dropped (it runs
+    into whatever follows) and up to three of the remaining ones are averaged."""
+    import re
+    import sqlite3
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if "image_pad" in r[0]]
+    segs = {"train": [], "embed": []}
+    for a, b in zip(marks, marks[1:] + [len(rows)]):
+        seg = rows[a:b]
+        segs["train" if any("adam" in r[0] for r in seg) else "embed"].append(seg)
+    out = {}
+    for kind, ss in segs.items():
+        ss = ss[:-1][-3:]
+        if not ss:
+            continue
+        acc = {}
+        for seg in ss:
+            for n, st, en in seg:
+                g = next((gn for gn, pat in _GROUPS if re.search(pat, n)), "other")
+                v = acc.setdefault(g, [0, 0.0]); v[0] += 1; v[1] += (en - st) / 1e3
+            v = acc.setdefault("_span", [0, 0.0]); v[0] += 1; v[1] += (seg[-1][2] - seg[0][1]) / 1e3
+        out[kind] = {g: {"launches": c / len(ss), "us": t / len(ss)} for g, (c, t) in acc.items()}
+        out[kind]["_kernels"] = sum(v["launches"] for g, v in out[kind].items() if not g.startswith("_"))
+        out[kind]["_kernel_us"] = sum(v["us"] for g, v in out[kind].items() if isinstance(v, dict) and not g.startswith("_"))
+    return out
+
+
+def insitu_trace(timeout_s=420):
+    """IN-SITU kernel durations: re-runs this benchmark's captured training step and embedding forward for a few replays
+    under `rocprofv3 --kernel-trace` in a child process and reads the per-launch durations back (parse_step_trace).  The
+    per-family times are those of the launches inside the replayed step -- cold / warm operands, piggy-backed reductions
+    and fused epilogues included -- which is what the step pays, unlike the isolated per-shape timings.  Returns None
+    when rocprofv3 is unavailable or the child fails (the caller then reports the isolated figure only)."""
+    import glob
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or os.environ.get("CREID_BENCH_NO_INSITU", "0") == "1":
+        return None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = tempfile.mkdtemp(prefix="creid_insitu_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", CREID_BENCH_NO_EVAL="1", CREID_BENCH_NO_INSITU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [exe, "--kernel-trace", "--stats", "-d", tmp, "-o", "insitu", "--", sys.executable, os.path.join(root, "bench.py"),
+           "--inner-trace"]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            print(f"[bench] in-situ trace failed (rc {r.returncode}): {r.stderr[-400:]}", file=sys.stderr)
+            return None
+        res = parse_step_trace(dbs[0])
+        keep = os.path.join(root, "gpurun_out")
+        if os.path.isdir(keep):
+            import json
+            with open(os.path.join(keep, "insitu_step_trace.json"), "w") as f:
+                json.dump(res, f, indent=1)
+        return res
+    except Exception as e:  # noqa: BLE001  (a profiler problem must not cost the benchmark line)
+        print(f"[bench] in-situ trace unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+class EmbedBench:
+    """validation_step's device work (modelling/bases.py:169-177): eval-mode backbone -> GAP -> BNNeck on a resident batch,
+    captured once into a hipGraph."""
+
+    def __init__(self, arch="resnet50", B=128, H=256, W=128, dtype=torch.bfloat16):
+        self.arch, self.B, self.H, self.W, self.dtype = arch, B, H, W, dtype
+        self.model = make_model(arch=arch, dtype=dtype)
+        self.model.eval()
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        self.x = torch.randn((B, 3, H, W), generator=gen, device="cuda", dtype=torch.float32)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._fwd()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.emb = self._fwd()
+
+    def _fwd(self):
+        with torch.no_grad():
+            _, f = self.model.backbone(self.x)
+            return self.model.bn(f)
+
+    def run(self, steps, warmup):
+        for _ in range(warmup):
+            self.graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.graph.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+
+def run_embed(arch="resnet50", B=128, H=256, W=128, steps=20, warmup=3, insitu=None, label=None):
+    """The `embed` object of the bench line: images/s of the eval-mode embedding forward (BatchNorm folded into the
+    convolution epilogues), its roofline against the bf16 MFMA peak."""
+    eb = EmbedBench(arch, B, H, W)
+    dt = eb.run(steps, warmup)
+    assert bool(torch.isfinite(eb.emb).all()), "non-finite embeddings in the benchmark"
+    fl = forward_flops(B, H, W)                                # convolution FLOPs are the same for both backbones
+    res = {"metric": "embed_images_per_sec", "value": B / dt, "unit": "images/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "dtype": "bf16", "hip_graph": True,
+           "config": {"workload": label or f"{arch} {H}x{W} eval-mode embedding forward (validation_step: backbone + GAP + BNNeck), "
+                                           f"batch {B}, BatchNorm folded into the conv epilogues", "batch": B},
+           "roofline": {"kernel": "igemm_bf16_{ws,dma}_kernel (53 conv launches per forward, folded BN epilogue)", "bound": "mfma",
+                        "achieved": fl / dt / 1e12, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / dt / 1e12 / MFMA_BF16_TFLOPS,
+                        "source": "whole forward (wall time of the replayed graph, all kernels)", "traffic": None}}
+    if insitu and "embed" in insitu and "igemm" in insitu["embed"]:
+        e = insitu["embed"]
+        ig = e["igemm"]["us"] * 1e-6
+        res["roofline"].update({"achieved": fl / ig / 1e12, "frac": fl / ig / 1e12 / MFMA_BF16_TFLOPS,
+                                "frac_whole_forward": fl / dt / 1e12 / MFMA_BF16_TFLOPS,
+                                "source": "rocprofv3 kernel trace of this run's replayed forward (in situ)",
+                                "igemm_us": e["igemm"]["us"], "launches_per_forward": e["_kernels"]})
+    del eb
+    torch.cuda.empty_cache()
+    return res
+
+
 def hbm_stage_rates(time_kernel, B, H, W):
     """Achieved GB/s of the bandwidth-bound passes of the step on their largest instance (layer1 block output,
     [B*H/4*W/4, 256] bf16): BN apply (+residual, ReLU), BN backward (reduce + finalize + apply), and Adam over the
@@ -223,14 +385,28 @@ class DDPStepper:
                     segs.append(g)
                     g.capture_begin(pool=segs[0].pool())
             eng.on_group_done = cap_hook
-            segs[0].capture_begin()
-            self.out = model.forward_backward(self.static, 0)
-            segs[-1].capture_end()
-            eng.on_group_done = None
-            self.gopt = torch.cuda.CUDAGraph()
-            self.gopt.capture_begin(pool=segs[0].pool())
-            model.apply_optimizers()
-            self.gopt.capture_end()
+            open_graph = None
+            try:
+                segs[0].capture_begin()
+                open_graph = segs
+                self.out = model.forward_backward(self.static, 0)
+                segs[-1].capture_end()
+                open_graph = None
+                eng.on_group_done = None
+                self.gopt = torch.cuda.CUDAGraph()
+                self.gopt.capture_begin(pool=segs[0].pool())
+                open_graph = [self.gopt]
+                model.apply_optimizers()
+                self.gopt.capture_end()
+                open_graph = None
+            except BaseException:
+                eng.on_group_done = None
+                if open_graph is not None:               # never leave the stream in capture mode behind a failed capture
+                    try:
+                        open_graph[-1].capture_end()
+                    except Exception:  # noqa: BLE001
+                        pass
+                raise
         torch.cuda.current_stream().wait_stream(side)
         self.segs, self.split_at = segs, split_at
 
@@ -254,14 +430,57 @@ class DDPStepper:
         return self.out
 
 
-def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
+def inner_trace(args, barrier_sync):
+    """`bench.py --inner-trace` (the child of insitu_trace): a few replays of the captured training step, then of the
+    embedding forward, nothing else -- the parent reads the kernel durations from the profiler's trace."""
+    args.steps, args.warmup = 5, 2
+    run(args, 0, 1, barrier_sync, None, None, minimal=True)
+    torch.cuda.synchronize()
+    eb = EmbedBench()
+    eb.run(5, 2)
+    torch.cuda.synchronize()
+
+
+def fp32_mode_step(P, K, H, W, steps=6, warmup=2):
+    """The exact-f32 parity mode of the same training step (fp32 activations, v_mfma_f32_32x32x2_f32): the throughput that
+    goes with the <= 1e-4 embedding / mAP parity claims (bf16 is the throughput mode)."""
+    model = make_model(dtype=torch.float32)
+    b = synthetic_batch(P, K, H, W, 0)
+    static = (b[0].clone(), b[1].clone(), b[2], b[3])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for s in range(2):
+            model.training_step(static, s)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = model.training_step(static, 0)
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = float(out["loss"])
+    del model, graph
+    torch.cuda.empty_cache()
+    return {"value": P * K / dt, "unit": "images/s", "ms_per_step": dt * 1e3, "steps": steps, "dtype": "f32",
+            "final_loss": loss, "note": "same step, exact-f32 MFMA parity mode (the mode the <=1e-4 golden comparisons run in)"}
+
+
+def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, minimal=False):
     P, K, H, W = 16, 4, 256, 128
     arch = os.environ.get("CREID_BENCH_ARCH", "resnet50")      # resnet50_ibn_a: side measurement, not the headline config
     if os.environ.get("CREID_BENCH_CONFIG3", "0") == "1":      # side line: the training half of BASELINE configs[3]
         arch, P, H, W = "resnet50_ibn_a", 14, 320, 320         # (configs/320_resnet50_ibn_a.yml: 320 x 320, 14 x 4 images)
     f32 = os.environ.get("CREID_BENCH_DTYPE", "bf16") == "f32"   # side measurement: the exact-f32 parity mode
     model = make_model(arch=arch, dtype=torch.float32 if f32 else torch.bfloat16)
-    if world > 1:
+    ddp = world > 1 or (dist.is_available() and dist.is_initialized())      # CREID_FORCE_DIST=1: one-rank RCCL group
+    overlap = False
+    if ddp:
         # identical initial weights on every rank, then data-parallel gradient all-reduce over RCCL
         opt, _ = model.optimizers()
         dist.broadcast(opt.flat, 0)
@@ -274,16 +493,25 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
         overlap = os.environ.get("CREID_DDP_OVERLAP", "1") == "1"
     batches = [synthetic_batch(P, K, H, W, s, rank) for s in range(4)]
     use_graph = os.environ.get("CREID_NO_GRAPH", "0") != "1"
-    split_graph = world > 1 or os.environ.get("CREID_SPLIT_GRAPH", "0") == "1"
+    split_graph = ddp or os.environ.get("CREID_SPLIT_GRAPH", "0") == "1"
     stepper = None
-    if world > 1 and overlap:
+    if ddp and overlap:
         sx, sl = batches[0][0].clone(), batches[0][1].clone()
+        import sys
+        ok = 1
         try:
             stepper = DDPStepper(model, world, (sx, sl, batches[0][2], batches[0][3]), use_graph=use_graph)
         except Exception as e:  # noqa: BLE001  (capture problems must not cost the measurement: use the two-graph path)
-            import sys
-            print(f"[bench] overlapped data-parallel step unavailable ({type(e).__name__}: {e}); "
-                  "falling back to graph A -> all-reduce -> graph B", file=sys.stderr)
+            ok = 0
+            print(f"[bench] rank {rank}: overlapped data-parallel step unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+        # every rank must run the SAME collective schedule: agree on the outcome before choosing it (a rank that fell back
+        # alone would issue one flat all-reduce against the others' three bucketed ones and the job would hang).  The eager
+        # warm-up steps inside DDPStepper were data-parallel steps on every rank, so the replicas are still identical.
+        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if rank == 0:
+                print("[bench] falling back to graph A -> all-reduce -> graph B on every rank", file=sys.stderr)
             stepper = None
             model.backbone.engine.on_group_done = None
             model.grad_sync = parallel.make_grad_sync(world)
@@ -349,6 +577,8 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
     dt = float(tmax.item())
     imgs = P * K * world * args.steps
     res = {}
+    if minimal:
+        return {"ms_per_step": dt / args.steps * 1e3}
     if rank == 0:
         loss = float(out["loss"])
         assert np.isfinite(loss), "non-finite loss in the benchmark"
@@ -359,19 +589,46 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None):
         gflop_img = 76.0 if (H, W) == (320, 320) else R50_FWD_BWD_GFLOP_PER_IMG      # IBN-a 320x320 / R50 256x128
         tf_step = gflop_img * P * K / (ms * 1e-3) / 1e3
         res["step_mfma_frac"] = tf_step / MFMA_BF16_TFLOPS     # all conv FLOPs / whole-step time (incl. HBM-bound BN etc.)
+        from . import _lib as L
+        res["plans"] = "tuned" if (L.lib() and L.N_PLANS > 0) else "rules"   # tuned_plans.json covers the configs[1] / [3] shapes only
         tf, ig_ms, slow, fast = igemm_roofline(P * K, H, W, time_kernel)
-        res["roofline"] = {"kernel": "igemm_bf16_{dma,ws}_kernel (conv fwd + dgrad, 104 launches/step, real layer mix)",
-                           "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": tf / MFMA_BF16_TFLOPS, "traffic": pmc_traffic("igemm_family"),
-                           "mfma_busy_by_counter": pmc_field("igemm_family", "mfma_busy"),   # in-situ style: every launch, cold operands
-                           "ms_per_step": ig_ms, "slowest_TFs": slow, "fastest_TFs": fast}
+        headline = world == 1 and arch == "resnet50" and not f32 and (H, W) == (256, 128)
+        insitu = insitu_trace() if headline else None
+        roof = {"kernel": "igemm_bf16_{dma,ws}_kernel (conv fwd + dgrad + stem fwd, 105 launches/step, real layer mix)",
+                "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_TFLOPS,
+                "source": "HIP events, every shape launched alone back to back on warm operands (isolated)",
+                "frac_isolated": tf / MFMA_BF16_TFLOPS, "isolated_ms_per_step": ig_ms,
+                "traffic": pmc_traffic("igemm_family"),
+                "traffic_source": "profiles/r0x_pmc_traffic.json: committed rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE per "
+                                  "launch), NOT measured in this run",
+                "mfma_busy_by_counter": pmc_field("igemm_family", "mfma_busy"),
+                "slowest_TFs": slow, "fastest_TFs": fast}
+        if insitu and "train" in insitu and "igemm" in insitu["train"]:
+            t = insitu["train"]
+            fl = igemm_step_flops(P * K, H, W)
+            tf_in = fl / (t["igemm"]["us"] * 1e-6) / 1e12
+            roof.update({"achieved": tf_in, "frac": tf_in / MFMA_BF16_TFLOPS,
+                         "source": "rocprofv3 kernel trace of this run's replayed step: sum of 2*M*N*K over the family's launches / "
+                                   "sum of their durations IN SITU (fused epilogues and piggy-backed reductions included)",
+                         "algorithmic_TFLOP_per_step": fl / 1e12, "igemm_us_per_step": t["igemm"]["us"],
+                         "igemm_launches_per_step": t["igemm"]["launches"]})
+            res["step_anatomy_us"] = {g: round(v["us"], 1) for g, v in t.items() if isinstance(v, dict)}
+            res["launches_per_step"] = t["_kernels"]
+        res["roofline"] = roof
         res["roofline_hbm_stages"] = hbm_stage_rates(time_kernel, P * K, H, W)
         if cpu_baseline_fn is not None and world == 1:          # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline_fn(P, K, H, W)
-        if world == 1 and arch == "resnet50" and not f32 and os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
+        if headline and os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
             del model
             torch.cuda.empty_cache()
+            res["fp32_mode"] = fp32_mode_step(P, K, H, W)
             res["map_delta_bf16"] = map_delta_bf16()             # BASELINE metric (iii) on clustered synthetic identities
+            # embeddings/s: the eval-mode forward validation_step / inference run (north_star's multi-GPU target is in it)
+            res["embed"] = run_embed("resnet50", 128, 256, 128, steps=20, warmup=3, insitu=insitu)
+            res["embed"]["configs3_embedding_half"] = run_embed(
+                "resnet50_ibn_a", 256, 320, 320, steps=5, warmup=2,
+                label="ResNet50-IBN-a 320x320 eval-mode embedding forward, batch 256 (embedding half of BASELINE configs[3], "
+                      "TEST.IMS_PER_BATCH 256)")
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
             "ms_per_step": dt / args.steps * 1e3, "dtype": "f32" if f32 else "bf16",
             "config": {"workload": ("ResNet50" if arch == "resnet50" else arch) +

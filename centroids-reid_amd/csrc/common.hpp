@@ -11,6 +11,17 @@
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Timing-only ablation switches (CREID_*_DRY, CREID_STREAM_NOEPI, CREID_STREAM1X1_DBG: they SKIP work, results are wrong).
+// Reading one through this helper announces it on stderr, so a stray environment variable cannot silently corrupt a run.
+#include <stdio.h>
+#include <stdlib.h>
+static inline int creid_ablation_env(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  if (v) fprintf(stderr, "[libcreid_hip] WARNING: %s=%d is a timing-only ablation switch -- results of this process are WRONG\n", name, v);
+  return v;
+}
+
 typedef float  f32x4  __attribute__((ext_vector_type(4)));
 typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef short  s16x8  __attribute__((ext_vector_type(8)));

@@ -809,7 +809,7 @@ bool wgrad_make_reduce_job(const creid_conv_desc* d, int dtype, const void* ws, 
   if (ws_bytes < (size_t)p.splits * NCO * K * sizeof(float)) return false;
   const bool ok = wred_make_job(j, (const float*)ws, dw, p.splits, NCO, K, (int)d->in_c, d->kh, d->kw, accumulate);
   // timing experiments only: the carrier workgroups are launched but do nothing (gradients are then WRONG)
-  static const int dry = [] { const char* e = getenv("CREID_WRED_DRY"); return e ? atoi(e) : 0; }();
+  static const int dry = creid_ablation_env("CREID_WRED_DRY");
   if (ok && dry) { j.K = 0; j.splits = 0; }
   return ok;
 }

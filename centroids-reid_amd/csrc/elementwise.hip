@@ -751,7 +751,7 @@ static inline unsigned ew_blocks(int64_t total_threads_needed, int64_t mult) {
 // timing experiments only (results are then WRONG): CREID_BN_FIN_DRY bit 0 skips the forward finalize launches, bit 1 the
 // backward ones -- measures what the 106 tiny launches cost inside a captured step
 static bool fin_dry(int bit) {
-  static const int v = [] { const char* e = getenv("CREID_BN_FIN_DRY"); return e ? atoi(e) : 0; }();
+  static const int v = creid_ablation_env("CREID_BN_FIN_DRY");
   return (v & bit) != 0;
 }
 extern "C" {

@@ -317,7 +317,112 @@ __global__ __launch_bounds__(256) void stream_finalize_kernel(const int32_t* __r
   out_first[qi] = (int32_t)h[0];
 }
 
+// ----------------------------------------------------------------------------------------
+// 0. the index the three kernels above walk, built ON THE DEVICE (utils/eval_reid.py:36-65 does the equivalent per query
+//    on the host: `matches`, `remove`, `keep`): gallery grouped by pid as a CSR over the DENSE pid range [pmin, pmin + R),
+//    slot = pid - pmin.  Counting sort: histogram -> exclusive scan -> scatter.  The order inside a pid group is whatever the
+//    atomics give -- stream_poslist_kernel re-ranks its candidates by (distance, gallery index), so nothing downstream
+//    depends on it.  Then per query: #positives = group size - #(same pid AND same camera), their maximum (-> LDS list
+//    capacity) and the number of queries beyond PL_MAXC (-> general path).
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_count_kernel(const int64_t* __restrict__ g_pids, int n, int64_t pmin, int R,
+                                                         int32_t* __restrict__ count) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t s = g_pids[i] - pmin;
+    if (s >= 0 && s < R) atomicAdd(&count[s], 1);
+  }
+}
+
+// one workgroup: csr[0..R] = exclusive scan of count (int64, the layout stream_poslist_kernel reads); cursor[s] = 0
+__global__ __launch_bounds__(1024) void plan_scan_kernel(const int32_t* __restrict__ count, int R, int64_t* __restrict__ csr,
+                                                         int32_t* __restrict__ cursor, int32_t* __restrict__ stats) {
+  __shared__ long long wsum[16];
+  __shared__ long long carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { carry_s = 0; stats[0] = 0; stats[1] = 0; }
+  __syncthreads();
+  for (int base = 0; base < R; base += 1024) {
+    const int i = base + tid;
+    const long long v = i < R ? (long long)count[i] : 0;
+    long long x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    long long off = carry_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (i < R) { csr[i] = off + x - v; cursor[i] = 0; }
+    __syncthreads();
+    if (tid == 1023) carry_s = off + x;
+    __syncthreads();
+  }
+  if (tid == 0) csr[R] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void plan_scatter_kernel(const int64_t* __restrict__ g_pids, int n, int64_t pmin, int R,
+                                                           const int64_t* __restrict__ csr, int32_t* __restrict__ cursor,
+                                                           int32_t* __restrict__ g_order) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t s = g_pids[i] - pmin;
+    if (s >= 0 && s < R) g_order[csr[s] + atomicAdd(&cursor[s], 1)] = i;
+  }
+}
+
+// one wave per query
+__global__ __launch_bounds__(256) void plan_query_kernel(const int64_t* __restrict__ q_pids, const int64_t* __restrict__ q_cams,
+                                                         const int64_t* __restrict__ g_cams, const int64_t* __restrict__ csr,
+                                                         const int32_t* __restrict__ g_order, int64_t pmin, int R, int m,
+                                                         int32_t* __restrict__ q_slot, int32_t* __restrict__ n_pos,
+                                                         int32_t* __restrict__ stats) {
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (qi >= m) return;
+  const int64_t s = q_pids[qi] - pmin;
+  int slot = -1, np = 0;
+  if (s >= 0 && s < R) {
+    const int64_t c0 = csr[s], c1 = csr[s + 1];
+    if (c1 > c0) {
+      slot = (int)s;
+      const int64_t qc = q_cams[qi];
+      int same = 0;
+      for (int64_t e = c0 + lane; e < c1; e += 64) same += g_cams[g_order[e]] == qc ? 1 : 0;
+      same = wave_sum_i(same);
+      np = (int)(c1 - c0) - same;
+    }
+  }
+  if (lane == 0) {
+    q_slot[qi] = slot; n_pos[qi] = np;
+    if (np > PL_MAXC) atomicAdd(&stats[1], 1);
+    else atomicMax(&stats[0], np);
+  }
+}
+
 extern "C" {
+
+/* Device-side index for the streamed evaluation.  g_pids / g_cams int64[n], q_pids / q_cams int64[m] on the device; the pid
+ * range [pmin, pmin + R) must cover every gallery pid (the caller knows min / max from the host arrays it uploaded).
+ * Outputs: csr_off int64[R + 1], g_order int32[n], q_slot int32[m] (pid - pmin, or -1 when the pid has no gallery entry),
+ * n_pos int32[m] (same pid, other camera), stats int32[2] = {max n_pos among queries with n_pos <= 128, #queries beyond}.
+ * scratch: int32[2 * R].  Five launches, no host synchronisation. */
+int creid_stream_plan(const int64_t* q_pids, const int64_t* g_pids, const int64_t* q_cams, const int64_t* g_cams, int64_t m,
+                      int64_t n, int64_t pmin, int64_t R, int64_t* csr_off, int32_t* g_order, int32_t* q_slot, int32_t* n_pos,
+                      int32_t* stats, int32_t* scratch, void* stream) {
+  CREID_CHECK_ARG(m >= 0 && n > 0 && R > 0);
+  CREID_CHECK_ARG(q_pids && g_pids && q_cams && g_cams && csr_off && g_order && q_slot && n_pos && stats && scratch);
+  if (n > 0x7ffffff0LL || m > 0x7ffffff0LL || R > (1LL << 26)) return CREID_E_SHAPE;
+  hipStream_t s = as_stream(stream);
+  int32_t* count = scratch;
+  int32_t* cursor = scratch + R;
+  hipError_t e = hipMemsetAsync(count, 0, (size_t)R * sizeof(int32_t), s);
+  if (e != hipSuccess) return (int)e;
+  const unsigned gb = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(plan_count_kernel, dim3(gb), dim3(256), 0, s, g_pids, (int)n, pmin, (int)R, count);
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, count, (int)R, csr_off, cursor, stats);
+  hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb), dim3(256), 0, s, g_pids, (int)n, pmin, (int)R, csr_off, cursor, g_order);
+  if (m > 0)
+    hipLaunchKernelGGL(plan_query_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, q_pids, q_cams, g_cams, csr_off, g_order,
+                       pmin, (int)R, (int)m, q_slot, n_pos, stats);
+  CREID_LAUNCH_RET();
+}
 
 int creid_stream_poslist(const float* q, const float* g, const float* qq, const float* gg, int64_t m, int64_t n,
                          int64_t D, const int32_t* q_slot, const int64_t* csr_off, const int32_t* g_order,
@@ -347,7 +452,7 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
   // enough workgroups for two per CU, but never fewer than ~4 gallery tiles per workgroup (per-tile restart cost)
   static const int target = [] { const char* e = getenv("CREID_STREAM_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   // timing ablation only (CREID_STREAM_NOEPI=1: contraction without the count epilogue -- results are then wrong)
-  static const int skip_count = [] { const char* e = getenv("CREID_STREAM_NOEPI"); return e ? atoi(e) : 0; }();
+  static const int skip_count = creid_ablation_env("CREID_STREAM_NOEPI");
   int nsplit = (target + tiles_m - 1) / tiles_m;
   if (nsplit > tiles_n) nsplit = tiles_n;
   if (nsplit < 1) nsplit = 1;

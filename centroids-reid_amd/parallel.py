@@ -90,6 +90,15 @@ class GradBuckets:
             dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
 
 
+def _layer_number(group_name: str) -> int:
+    """"layer4." -> 4 (the backbone engine's group hook is called with the layer number)."""
+    import re
+    m = re.fullmatch(r"layer(\d+)\.?", group_name)
+    if m is None:
+        raise ValueError(f"gradient bucket groups are named 'layer<k>.': got {group_name!r}")
+    return int(m.group(1))
+
+
 def make_overlapped_grad_sync(model, world, groups=("layer4.", "layer3.")):
     """Returns (buckets, on_group_done, finish): `on_group_done(k)` is the backbone engine's backward hook (k = 4, 3,
     2, 1 after layer k's last kernel has been enqueued): it all-reduces the bucket that just became final on a side
@@ -104,7 +113,7 @@ def make_overlapped_grad_sync(model, world, groups=("layer4.", "layer3.")):
     layer_to_bucket = {}
     for i, g in enumerate(groups):
         if i < len(buckets) - 1:
-            layer_to_bucket[int(g.strip("layer."))] = i
+            layer_to_bucket[_layer_number(g)] = i
     state = {"next": 0}
 
     def _launch(i):
@@ -140,11 +149,12 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(local: torch.Tensor, counts=None) -> torch.Tensor:
+def all_gather_rows(local: torch.Tensor, counts=None, force_collective=False) -> torch.Tensor:
     """Concatenate row-shards [n_r, D] from all ranks (ragged allowed) with ONE all_gather_into_tensor: equal shards
-    land directly in the output; ragged shards are padded to the longest and the padding rows are dropped after."""
+    land directly in the output; ragged shards are padded to the longest and the padding rows are dropped after.
+    force_collective: issue the collective even in a one-rank group (first-contact test of the RCCL path)."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         return local
     if counts is None:
         cnt = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)

@@ -168,12 +168,68 @@ def eval_func(indices, q_pids, g_pids, q_camids, g_camids, max_rank=50, respect_
 
 # --------------------------------------------------------------------------- streamed (metric-only) evaluation
 class StreamPlan:
-    """Host-side index for the streamed evaluation (csrc/stream_eval.hip): the gallery grouped by pid (CSR), every
-    query's slot in it, and the per-query number of positives (same pid, different camera) which fixes the LDS list
-    capacity `cap`.  Queries with more than 128 positives are listed in `overflow` and must take the general
-    (materialised) path.  Built once per (pids, camids) set; holds device tensors only."""
+    """Index for the streamed evaluation (csrc/stream_eval.hip): the gallery grouped by pid (CSR), every query's slot in
+    it, and the per-query number of positives (same pid, different camera) which fixes the LDS list capacity `cap`.
+    Queries with more than 128 positives are listed in `overflow` and must take the general (materialised) path.  Holds
+    device tensors only.
+
+    `StreamPlan.on_device(...)` (what R1_mAP uses) builds it with creid_stream_plan: one upload of the label vectors, a
+    counting sort on the GPU, and an 8-byte read-back for `cap`.  The constructor is the host (numpy) construction of the
+    same index -- kept for label sets whose pid range is too sparse for a dense counting sort, and as the checker of the
+    device build in tests/test_stream_eval_gpu.py."""
 
     MAX_CAP = 128
+    MAX_DENSE_RANGE = 1 << 24          # pid range the device counting sort accepts (2 x int32 scratch + int64 CSR per slot)
+
+    @classmethod
+    def on_device(cls, pids, camids, num_query, device):
+        """pids / camids: host vectors [nq + ng] as R1_mAP.compute receives them (utils/reid_metric.py:112)."""
+        p = np.ascontiguousarray(np.asarray(pids), dtype=np.int64)
+        c = np.ascontiguousarray(np.asarray(camids), dtype=np.int64)
+        nq = int(num_query)
+        m, n = nq, len(p) - nq
+        if n <= 0:
+            return cls(p[:nq], p[nq:], c[:nq], c[nq:], device)
+        pmin, pmax = int(p[nq:].min()), int(p[nq:].max())
+        R = pmax - pmin + 1
+        if R > cls.MAX_DENSE_RANGE:
+            return cls(p[:nq], p[nq:], c[:nq], c[nq:], device)
+        self = cls.__new__(cls)
+        self.m, self.n = m, n
+        lab = torch.from_numpy(np.stack([p, c])).to(device)                       # ONE upload: [2, nq + ng] int64
+        self.q_pids, self.g_pids, self.q_cams, self.g_cams = lab[0, :nq], lab[0, nq:], lab[1, :nq], lab[1, nq:]
+        i32 = dict(dtype=torch.int32, device=device)
+        self.csr_off = torch.empty(R + 1, dtype=torch.int64, device=device)
+        self.g_order = torch.empty(n, **i32)
+        self.q_slot = torch.empty(max(m, 1), **i32)
+        self._n_pos_dev = torch.empty(max(m, 1), **i32)
+        self._stats = torch.empty(2, **i32)
+        scratch = torch.empty(2 * R, **i32)
+        L.check(L.lib().creid_stream_plan(L.ptr(self.q_pids), L.ptr(self.g_pids), L.ptr(self.q_cams), L.ptr(self.g_cams), m, n,
+                                          pmin, R, L.ptr(self.csr_off), L.ptr(self.g_order), L.ptr(self.q_slot),
+                                          L.ptr(self._n_pos_dev), L.ptr(self._stats), L.ptr(scratch), L.stream()),
+                "creid_stream_plan")
+        self._n_pos = None
+        self.cap = None                      # resolved by finish(): the only host read, 8 bytes
+        return self
+
+    def finish(self):
+        """Read back {max positives, #overflow queries} (the one synchronisation of the device build) and fix `cap`."""
+        if self.cap is not None:
+            return self
+        mx, nover = (int(v) for v in self._stats.cpu().tolist())
+        cap = 2
+        while cap < max(mx, 1):
+            cap *= 2
+        self.cap = cap
+        self.overflow = np.nonzero(self.n_pos > self.MAX_CAP)[0] if nover else np.zeros(0, np.int64)
+        return self
+
+    @property
+    def n_pos(self):
+        if self._n_pos is None:
+            self._n_pos = self._n_pos_dev[:self.m].cpu().numpy().astype(np.int64)
+        return self._n_pos
 
     def __init__(self, q_pids, g_pids, q_camids, g_camids, device):
         qp = np.ascontiguousarray(np.asarray(q_pids), dtype=np.int64)
@@ -198,9 +254,9 @@ class StreamPlan:
         ks = np.searchsorted(uk, qk)
         ks_c = np.minimum(ks, max(len(uk) - 1, 0))
         same_cam = np.where((ks < len(uk)) & (uk[ks_c] == qk), cnt[ks_c], 0) if len(uk) else np.zeros(self.m, np.int64)
-        self.n_pos = (same_pid - same_cam).astype(np.int64)
-        self.overflow = np.nonzero(self.n_pos > self.MAX_CAP)[0]
-        mx = int(self.n_pos[self.n_pos <= self.MAX_CAP].max(initial=1))
+        self._n_pos = (same_pid - same_cam).astype(np.int64)
+        self.overflow = np.nonzero(self._n_pos > self.MAX_CAP)[0]
+        mx = int(self._n_pos[self._n_pos <= self.MAX_CAP].max(initial=1))
         cap = 2
         while cap < mx:
             cap *= 2
@@ -212,6 +268,12 @@ class StreamPlan:
 
 
 def stream_eval(fq, fg, qq, gg, plan: StreamPlan):
+    if plan.cap is None:
+        plan.finish()
+    return _stream_eval(fq, fg, qq, gg, plan)
+
+
+def _stream_eval(fq, fg, qq, gg, plan: StreamPlan):
     """Per-query (valid u8[m], AP f64[m], first-match rank i32[m]) with no m x n matrix: positives' distances ->
     streamed MFMA contraction with an in-register count epilogue -> histogram prefix.  valid == 2 marks a query
     whose positive list overflowed the plan's capacity (see StreamPlan.overflow)."""
@@ -282,7 +344,8 @@ class R1_mAP:
         feats = feats.float().contiguous()
         nq = self.num_query
         if (self.streamed and self.dist_name == "euclidean" and not respect_camids
-                and self.compute_dtype == torch.float32):
+                and self.compute_dtype == torch.float32 and feats.shape[1] % 4 == 0):
+            # (the streamed contraction loads 16-byte k-chunks: D % 4 != 0 takes the materialised kernels below)
             return self._compute_streamed(feats, pids, camids)
         if self.dist_name == "euclidean":
             if self.feat_norm:
@@ -313,7 +376,11 @@ class R1_mAP:
             f, sq = feats, row_sqnorm(feats)
         pids = np.asarray(pids); camids = np.asarray(camids)
         if plan is None:
-            plan = StreamPlan(pids[:nq], pids[nq:], camids[:nq], camids[nq:], feats.device)
+            # index built on the device BEHIND the normalisation launch; its 8-byte read-back (finish) is the only
+            # synchronisation before the contraction is enqueued
+            plan = StreamPlan.on_device(pids, camids, nq, feats.device)
+        if plan.cap is None:
+            plan.finish()
         fq, fg = f[:nq], f[nq:]
         qq, gg = sq[:nq].contiguous(), sq[nq:].contiguous()
         valid, ap, first = stream_eval(fq, fg, qq, gg, plan)
@@ -341,26 +408,29 @@ class R1_mAP:
         if not isinstance(feats, torch.Tensor) or not feats.is_cuda:
             raise L.CreidError("R1_mAP.compute_chunked needs device features (no CPU fallback)")
         from .parallel import merge_eval_results
-        if self.dist_name != "euclidean":
-            raise L.CreidError("compute_chunked streams the squared-L2 kernel only; use compute() for "
-                               f"SOLVER.DISTANCE_FUNC={self.dist_name!r}")
-        if self.compute_dtype == torch.float32:
+        euclid = self.dist_name == "euclidean"
+        if euclid and self.compute_dtype == torch.float32 and feats.shape[1] % 4 == 0:
             return self._compute_streamed(feats.float().contiguous(), pids, camids)
         feats = feats.float().contiguous()
         nq = self.num_query
-        if self.feat_norm:
+        if not euclid:
+            # SOLVER.DISTANCE_FUNC = cosine (utils/reid_metric.py:51-59,93-110 works with either function): the same
+            # query-chunk loop on the cosine matrix
+            f = l2_normalize(feats) if self.feat_norm else feats
+            sq = None
+        elif self.feat_norm:
             f, sq = l2_normalize(feats, out_dtype=self.compute_dtype, return_sqnorm=True)
         else:
             f = feats if self.compute_dtype == torch.float32 else feats.to(self.compute_dtype)
             sq = row_sqnorm(f)
-        g, gg = f[nq:], sq[nq:].contiguous()
+        g, gg = f[nq:].contiguous(), (sq[nq:].contiguous() if sq is not None else None)
         pids = np.asarray(pids); camids = np.asarray(camids)
         dev = feats.device
         gp, gc = _dev_i64(pids[nq:], dev), _dev_i64(camids[nq:], dev)
         vs, aps, firsts = [], [], []
         for lo in range(0, nq, query_chunk):
             hi = min(nq, lo + query_chunk)
-            d = get_euclidean(f[lo:hi], g, sq[lo:hi].contiguous(), gg)
+            d = get_euclidean(f[lo:hi], g, sq[lo:hi].contiguous(), gg) if euclid else self.dist_func(f[lo:hi].contiguous(), g)
             idx = rank_rows(d)
             del d
             _, _, _, _, v, a, fr = eval_func_device(idx, pids[lo:hi], gp, camids[lo:hi], gc, self.max_rank)

@@ -90,7 +90,8 @@ class CTLModel(ModelBase):
             is_real = (isReal if isinstance(isReal, torch.Tensor) else torch.as_tensor(ir_host)).to(dev)
         class_labels = class_labels.to(dev, non_blocking=True)
 
-        if (self.fused_heads and all_real and P >= 2 and K >= 2 and x.is_cuda and hasattr(self.backbone, "engine")
+        # (K <= 16: creid_loo_emb_bwd keeps one register slot per instance of a pid)
+        if (self.fused_heads and all_real and P >= 2 and 2 <= K <= 16 and x.is_cuda and hasattr(self.backbone, "engine")
                 and self.backbone.training and self.contrastive_loss.margin is not None
                 and self.contrastive_loss.dist_name == "euclidean"):
             return self._forward_backward_fused(x, class_labels, P, K)

@@ -100,8 +100,9 @@ int creid_eval_reduce(const uint8_t* valid, const double* ap, const int32_t* fir
  * utils/eval_reid.py:25-92 compute, for plain camera ids and the squared-L2 distance.  Three launches:
  *  poslist : per query, distances to its positives (gallery rows of the same pid, other camera) in the arithmetic
  *            of creid_sqdist_matrix, sorted by (distance, gallery index).  The gallery is given grouped by pid:
- *            g_order int32 [n] (gallery indices sorted by pid, ascending index inside a pid), csr_off int64
- *            [n_pid + 1], q_slot int32 [m] (the query pid's group, -1 if absent).  cap = list capacity per query
+ *            g_order int32 [n] (gallery indices grouped by pid; any order inside a group -- the kernel re-ranks its
+ *            candidates by (distance, gallery index)), csr_off int64 [n_groups + 1], q_slot int32 [m] (the query
+ *            pid's group, -1 if absent) -- built on the device by creid_stream_plan.  cap = list capacity per query
  *            (power of two, 2..128); pos_key uint32 [m][cap] (order-preserving image of the fp32 distance, padded
  *            with 0xffffffff), pos_idx int32 [m][cap], npos int32 [m] (-1: more than cap positives -- such queries
  *            must take creid_sqdist_matrix + creid_rank_rows + creid_cmc_ap_ranked instead).
@@ -109,6 +110,15 @@ int creid_eval_reduce(const uint8_t* valid, const double* ap, const int32_t* fir
  *            hist[q][#positives ranked before it] -- hist uint32 [m][cap] must be ZERO on entry.
  *  finalize: valid uint8 [m] (0: no positive, 1: ok, 2: overflow), ap float64 [m], first int32 [m] with the
  *            meaning of creid_cmc_ap_ranked; feed creid_eval_reduce. */
+/* The index of the three launches above, built on the device from the raw label vectors (the per-query `matches` /
+ * `remove` bookkeeping of utils/eval_reid.py:36-65 done once for all queries): counting sort of the gallery by pid over the
+ * dense range [pmin, pmin + R) (R = max pid - min pid + 1 of the gallery; group = pid - pmin), then per query its group,
+ * its number of positives n_pos (same pid, other camera) and stats int32[2] = {max n_pos over queries with n_pos <= 128,
+ * number of queries with more}.  csr_off int64[R + 1], g_order int32[n], q_slot / n_pos int32[m], scratch int32[2 R].
+ * No host synchronisation; the caller reads `stats` (8 bytes) to choose cap. */
+int creid_stream_plan(const int64_t* q_pids, const int64_t* g_pids, const int64_t* q_cams, const int64_t* g_cams,
+                      int64_t m, int64_t n, int64_t pmin, int64_t R, int64_t* csr_off, int32_t* g_order,
+                      int32_t* q_slot, int32_t* n_pos, int32_t* stats, int32_t* scratch, void* stream);
 int creid_stream_poslist(const float* q, const float* g, const float* qq, const float* gg, int64_t m, int64_t n,
                          int64_t D, const int32_t* q_slot, const int64_t* csr_off, const int32_t* g_order,
                          const int64_t* q_cams, const int64_t* g_cams, int32_t cap, uint32_t* pos_key,

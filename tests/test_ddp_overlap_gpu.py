@@ -20,3 +20,17 @@ def test_overlapped_ddp_step_equals_flat_allreduce_two_ranks_one_gpu():
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert out.count("DDP_OVERLAP_OK") == 2 and "DDP_OVERLAP_MISMATCH" not in out, out[-3000:]
+
+
+def test_rccl_one_rank_group_matches_step_without_group():
+    """First RCCL contact (backend nccl, world size 1): communicator init, flat and bucketed side-stream all-reduces between
+    hipGraph segments, all_gather_into_tensor and the sharded evaluation -- all equal to the step / evaluation with no
+    process group at all, bit for bit (tools/debug/rccl_world1_check.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "rccl_world1_check.py")], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert "RCCL_WORLD1_OK" in out and "RCCL_WORLD1_MISMATCH" not in out, out[-3000:]

@@ -133,3 +133,13 @@ def test_bucketed_allreduce_equals_flat_and_ragged_allgather_gloo():
         assert same and nb == 3
         np.testing.assert_array_equal(allr, expect)
         np.testing.assert_array_equal(eq, np.repeat([[0.0], [1.0]], 2, axis=0).repeat(3, axis=1))
+
+
+def test_bucket_group_names_parse_to_layer_numbers():
+    """parallel._layer_number: "layer4." -> 4 by a real parse (str.strip("layer.") is a character-set strip)."""
+    from centroids_reid_amd import parallel
+    assert parallel._layer_number("layer4.") == 4 and parallel._layer_number("layer3") == 3
+    assert parallel._layer_number("layer12.") == 12
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        parallel._layer_number("stem.")

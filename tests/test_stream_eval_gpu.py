@@ -137,3 +137,46 @@ def test_streamed_configs3_shard_6250x200000():
     np.testing.assert_array_equal(valid[sl] == 1, per_q["valid"])
     np.testing.assert_array_equal(first[sl], per_q["first"])
     np.testing.assert_allclose(ap[sl], per_q["ap"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("nq,ng,npid,ncam,offset", [(50, 700, 40, 4, 0), (2228, 17661, 702, 8, 0), (300, 5000, 2000, 3, -977),
+                                                    (64, 3000, 5, 2, 10_000_000)])
+def test_device_stream_plan_equals_host_plan(nq, ng, npid, ncam, offset):
+    """creid_stream_plan (counting sort on the device) against the numpy construction: same capacity, overflow set and
+    per-query positive counts, and for every query the same GROUP of gallery indices (the order inside a group is free)."""
+    from centroids_reid_amd import reid_metric as rm
+    rng = np.random.default_rng(nq + ng)
+    pids = rng.integers(0, npid, nq + ng) + offset
+    cams = rng.integers(0, ncam, nq + ng)
+    pids[0] = offset + npid + 3                                  # above the gallery's range
+    pids[1] = offset - 2                                         # below it
+    if npid > 10:
+        pids[nq:][pids[nq:] == offset + 7] = offset + 8          # a hole inside the range
+        pids[2] = offset + 7
+    dev = rm.StreamPlan.on_device(pids, cams, nq, "cuda").finish()
+    host = rm.StreamPlan(pids[:nq], pids[nq:], cams[:nq], cams[nq:], "cuda")
+    assert dev.cap == host.cap
+    np.testing.assert_array_equal(dev.overflow, host.overflow)
+    np.testing.assert_array_equal(dev.n_pos, host.n_pos)
+    ds, hs = dev.q_slot[:nq].cpu().numpy(), host.q_slot.cpu().numpy()
+    np.testing.assert_array_equal(ds < 0, hs < 0)
+    dc, hc = dev.csr_off.cpu().numpy(), host.csr_off.cpu().numpy()
+    do, ho = dev.g_order.cpu().numpy(), host.g_order.cpu().numpy()
+    assert sorted(do.tolist()) == list(range(ng))                # a permutation of the gallery
+    for qi in range(0, nq, max(1, nq // 97)):
+        if hs[qi] < 0:
+            continue
+        a = np.sort(do[dc[ds[qi]]:dc[ds[qi] + 1]]); b = np.sort(ho[hc[hs[qi]]:hc[hs[qi] + 1]])
+        np.testing.assert_array_equal(a, b)
+        assert (pids[nq:][a] == pids[qi]).all()
+
+
+def test_device_plan_sparse_pid_range_falls_back_to_host_index():
+    from centroids_reid_amd import reid_metric as rm
+    rng = np.random.default_rng(3)
+    nq, ng = 20, 400
+    pids = rng.integers(0, 30, nq + ng) * (1 << 40)              # range far beyond the dense counting sort
+    cams = rng.integers(0, 3, nq + ng)
+    f = torch.from_numpy(rng.standard_normal((nq + ng, 64)).astype(np.float32))
+    a, ra, b, rb = _both(f, pids, cams, nq)
+    _assert_same(a, ra, b, rb, pids, cams, nq)
