@@ -441,6 +441,46 @@ def inner_trace(args, barrier_sync):
     torch.cuda.synchronize()
 
 
+def fake_mix_step(model, batches, P, K, steps=30, warmup=5):
+    """SURVEY 8d cfg2 variant: 10 % of the steps carry 1-2 padded (isReal = False) samples.  ONE captured graph serves every
+    pattern: the step takes the mask from a device tensor (train_ctl_model._forward_backward_fused, masked schedule) and
+    contains no host synchronisation; per step only the mask / image / label buffers are refreshed."""
+    B = P * K
+    dev = batches[0][0].device
+    mask = torch.ones(B, dtype=torch.uint8, device=dev)
+    sx, sl = batches[0][0].clone(), batches[0][1].clone()
+    static = (sx, sl, batches[0][2], mask)
+    pats = [torch.ones(B, dtype=torch.uint8, device=dev) for _ in range(10)]
+    pats[3][5] = 0                                             # one fake in identity 1
+    pats[3][K * 7 + 1] = 0; pats[3][K * 7 + 2] = 0             # two fakes in identity 7 (two real instances left)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for s in range(2):
+            mask.copy_(pats[3 if s else 0])
+            model.training_step(static, s)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = model.training_step(static, 0)
+
+    def one(s):
+        mask.copy_(pats[s % 10]); sx.copy_(batches[s % 4][0]); sl.copy_(batches[s % 4][1])
+        graph.replay()
+    for s in range(warmup):
+        one(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        one(s)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = float(out["loss"])
+    assert np.isfinite(loss), "non-finite loss in the fake-mix benchmark"
+    return {"value": B / dt, "unit": "images/s", "ms_per_step": dt * 1e3, "steps": steps, "final_loss": loss,
+            "note": "same step captured with a DEVICE isReal mask; every 10th step has 3 padded samples (1 + 2 in two identities)"}
+
+
 def fp32_mode_step(P, K, H, W, steps=6, warmup=2):
     """The exact-f32 parity mode of the same training step (fp32 activations, v_mfma_f32_32x32x2_f32): the throughput that
     goes with the <= 1e-4 embedding / mAP parity claims (bf16 is the throughput mode)."""
@@ -619,6 +659,8 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
         if cpu_baseline_fn is not None and world == 1:          # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline_fn(P, K, H, W)
         if headline and os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
+            res["fake_mix"] = fake_mix_step(model, batches, P, K)
+            res["fake_mix"]["vs_all_real"] = res["fake_mix"]["value"] / (imgs / dt)
             del model
             torch.cuda.empty_cache()
             res["fp32_mode"] = fp32_mode_step(P, K, H, W)

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restr
                                                            const int64_t* __restrict__ labels, int N, int D,
                                                            float* __restrict__ dist_ap, float* __restrict__ dist_an,
                                                            int32_t* __restrict__ p_idx, int32_t* __restrict__ n_idx,
-                                                           float* __restrict__ dist_row_out /* nullable [N,N] */) {
+                                                           float* __restrict__ dist_row_out /* nullable [N,N] */,
+                                                           const uint8_t* __restrict__ exists /* nullable [N]: rows that are
+                                                           part of the problem at all (neither anchors nor candidates otherwise) */) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [D] anchor row, then [N] distances
   float* xa = sm;
   float* drow = sm + D;
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restr
     const int64_t bo = (int64_t)blockIdx.y * N;
     x += bo * D; labels += bo; dist_ap += bo; dist_an += bo; p_idx += bo; n_idx += bo;
     if (dist_row_out) dist_row_out += bo * N;
+    if (exists) exists += bo;
   }
   const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xap = x + (int64_t)a * D;
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restr
     float bp = -INFINITY, bn = INFINITY;
     int ip = 0x7fffffff, in_ = 0x7fffffff;
     for (int j = lane; j < N; j += 64) {
+      if (exists && !exists[j]) continue;
       const float d = drow[j];
       if (labels[j] == la) { if (d > bp) { bp = d; ip = j; } }
       else { if (d < bn) { bn = d; in_ = j; } }
@@ -131,7 +135,9 @@ __global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restr
 __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restrict__ dist_ap,
                                                            const float* __restrict__ dist_an,
                                                            const uint8_t* __restrict__ mask, int N, float margin,
-                                                           float* __restrict__ out, float* __restrict__ coef) {
+                                                           float* __restrict__ out, float* __restrict__ coef,
+                                                           int min_anchors /* fewer anchors: the problem is skipped (a centroid
+                                                           round with <= 1 valid identity, train_ctl_model.py:113) */) {
   __shared__ float s[4][4];
   {
     const int64_t bo = (int64_t)blockIdx.y * N;
@@ -147,6 +153,11 @@ __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restri
   __syncthreads();
   const float nm = s[0][3] + s[1][3] + s[2][3] + s[3][3];
   __syncthreads();
+  if (nm < (float)min_anchors || nm == 0.f) {          // (nm == 0 only with a mask: nothing to average)
+    if (coef) for (int a = tid; a < N; a += 256) coef[a] = 0.f;
+    if (tid == 0) { out[0] = 0.f; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f; }
+    return;
+  }
   float l = 0.f, sap = 0.f, san = 0.f;
   for (int a = tid; a < N; a += 256) {
     const bool on = !mask || mask[a];
@@ -297,16 +308,31 @@ __global__ __launch_bounds__(256) void center_row_kernel(const float* __restrict
   }
 }
 
+// number of rows with mask != 0 (all B when mask is NULL), by every thread of a 256-thread workgroup; `sc` = 4 ints of LDS
+__device__ __forceinline__ int masked_row_count(const uint8_t* __restrict__ mask, int B, int* sc) {
+  if (!mask) return B;
+  int c = 0;
+  for (int b = threadIdx.x; b < B; b += 256) c += mask[b] ? 1 : 0;
+  c = wave_sum_i(c);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
+  __syncthreads();
+  return (sc[0] + sc[1]) + (sc[2] + sc[3]);
+}
+
+// mask (nullable, uint8 [B]): the rows the loss is taken over -- train_ctl_model.py:69-73 feeds features[isReal] only
 __global__ __launch_bounds__(256) void center_reduce_kernel(const float* __restrict__ row_loss, int B, int C,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, const uint8_t* __restrict__ mask) {
   __shared__ float s[4];
+  __shared__ int sc[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = masked_row_count(mask, B, sc);
   float l = 0.f;
-  for (int b = tid; b < B; b += 256) l += fminf(fmaxf(row_loss[b], 1e-12f), 1e12f);
+  for (int b = tid; b < B; b += 256) l += (!mask || mask[b]) ? fminf(fmaxf(row_loss[b], 1e-12f), 1e12f) : 0.f;
   l = wave_sum(l);
   if (lane == 0) s[wave] = l;
   __syncthreads();
-  if (tid == 0) out[0] = (((s[0] + s[1]) + (s[2] + s[3])) + (float)B * (float)(C - 1) * 1e-12f) / (float)B;
+  if (tid == 0) out[0] = nb > 0 ? (((s[0] + s[1]) + (s[2] + s[3])) + (float)nb * (float)(C - 1) * 1e-12f) / (float)nb : 0.f;
 }
 
 // dx[b] += g*(2/B)(x_b - c_y) ; dcenters[y] (+)= g*(2/B) sum_{b:y_b=y}(c_y - x_b), written once per
@@ -316,10 +342,14 @@ __global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ centers,
                                                          const float* __restrict__ row_loss, int B, int D,
                                                          const float* __restrict__ gscale_ptr, float gscale,
-                                                         float* __restrict__ dx, float* __restrict__ dcenters) {
+                                                         float* __restrict__ dx, float* __restrict__ dcenters,
+                                                         const uint8_t* __restrict__ mask) {
   const int b = blockIdx.x;
   const int64_t y = labels[b];
-  const float g = gscale * (gscale_ptr ? *gscale_ptr : 1.f) * 2.0f / (float)B;
+  __shared__ int sc[4];
+  const int nb = masked_row_count(mask, B, sc);
+  if (mask && !mask[b]) return;                        // a padded (isReal = False) row: no loss term, owns no class
+  const float g = gscale * (gscale_ptr ? *gscale_ptr : 1.f) * 2.0f / (float)nb;
   const bool on = row_loss[b] >= 1e-12f && row_loss[b] <= 1e12f;
   const float* c = centers + y * D;
   const float* xb = x + (int64_t)b * D;
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict
   const bool listed = B <= 1024;
   if (listed) {
     for (int t = threadIdx.x; t < B; t += 256)
-      s_flag[t] = (labels[t] == y) ? ((row_loss[t] >= 1e-12f && row_loss[t] <= 1e12f) ? 2 : 1) : 0;
+      s_flag[t] = (labels[t] == y && (!mask || mask[t])) ? ((row_loss[t] >= 1e-12f && row_loss[t] <= 1e12f) ? 2 : 1) : 0;
     __syncthreads();
     if (threadIdx.x == 0) {
       int n = 0, first = -1;
@@ -345,7 +375,7 @@ __global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict
   }
   bool first = true;
   if (listed) first = s_first == b;
-  else for (int t = 0; t < b; ++t) first = first && (labels[t] != y);
+  else for (int t = 0; t < b; ++t) first = first && (labels[t] != y || (mask && !mask[t]));
   for (int d = threadIdx.x; d < D; d += 256) {
     const float cv = c[d];
     if (dx) dx[(int64_t)b * D + d] += on ? g * (xb[d] - cv) : 0.f;
@@ -355,7 +385,7 @@ __global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict
         for (int k = 0; k < s_nmem; ++k) acc += cv - x[(int64_t)s_members[k] * D + d];
       } else {
         for (int t = b; t < B; ++t)
-          if (labels[t] == y && row_loss[t] >= 1e-12f && row_loss[t] <= 1e12f) acc += cv - x[(int64_t)t * D + d];
+          if (labels[t] == y && (!mask || mask[t]) && row_loss[t] >= 1e-12f && row_loss[t] <= 1e12f) acc += cv - x[(int64_t)t * D + d];
       }
       dcenters[y * D + d] += g * acc;
     }
@@ -369,10 +399,17 @@ __global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void xent_ls_kernel(const float* __restrict__ logits,
                                                       const int64_t* __restrict__ targets, int B, int C, float eps,
                                                       float* __restrict__ row_loss, float* __restrict__ dlogits,
-                                                      float gscale) {
+                                                      float gscale, const uint8_t* __restrict__ mask) {
   __shared__ float s[4];
   __shared__ float bc;
+  __shared__ int sc[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nrows = masked_row_count(mask, B, sc);     // the mean is over the real rows (train_ctl_model.py:74-77)
+  if (mask && !mask[b]) {
+    if (tid == 0) row_loss[b] = 0.f;
+    if (dlogits) for (int c = tid; c < C; c += 256) dlogits[(int64_t)b * C + c] = 0.f;
+    return;
+  }
   const float* z = logits + (int64_t)b * C;
   float mx = -INFINITY;
   for (int c = tid; c < C; c += 256) mx = fmaxf(mx, z[c]);
@@ -403,7 +440,7 @@ __global__ __launch_bounds__(256) void xent_ls_kernel(const float* __restrict__ 
     row_loss[b] = -((1.f - eps) * logp_y + (eps / (float)C) * sum_logp);
   }
   if (dlogits) {
-    const float gb = gscale / (float)B;
+    const float gb = gscale / (float)nrows;
     for (int c = tid; c < C; c += 256) {
       const float p = expf(z[c] - mx) / se;
       const float t = (c == y ? (1.f - eps) : 0.f) + eps / (float)C;
@@ -413,9 +450,11 @@ __global__ __launch_bounds__(256) void xent_ls_kernel(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ v, int n, float scale,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const uint8_t* __restrict__ mask) {
   __shared__ float s[4];
+  __shared__ int sc[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (mask) { const int c = masked_row_count(mask, n, sc); scale = c > 0 ? 1.0f / (float)c : 0.f; }   // v is 0 on masked rows
   float l = 0.f;
   for (int i = tid; i < n; i += 256) l += v[i];
   l = wave_sum(l);
@@ -434,34 +473,38 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ rmean, float* __restrict__ rvar,
                                                        int training, float momentum, float eps,
                                                        float* __restrict__ y, float* __restrict__ save_mean,
-                                                       float* __restrict__ save_invstd) {
+                                                       float* __restrict__ save_invstd, const uint8_t* __restrict__ mask) {
+  // mask (nullable, uint8 [B]): the batch the statistics are taken over -- the BNNeck sees features[isReal] only
+  // (train_ctl_model.py:69-75); masked rows of y are written as 0
   __shared__ float red[8][32];
   __shared__ float s_mean[32], s_inv[32];
+  __shared__ int sc[4];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int d = blockIdx.x * 32 + cl;
   const bool live = d < D;
+  const int nb = masked_row_count(mask, B, sc);
   if (training) {
     float s = 0.f;
-    if (live) for (int b = rl; b < B; b += 8) s += x[(int64_t)b * D + d];
+    if (live) for (int b = rl; b < B; b += 8) s += (!mask || mask[b]) ? x[(int64_t)b * D + d] : 0.f;
     red[rl][cl] = s;
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) mean += red[q][cl];
-    mean /= (float)B;
+    mean /= (float)nb;
     __syncthreads();
     float m2 = 0.f;
-    if (live) for (int b = rl; b < B; b += 8) { const float t = x[(int64_t)b * D + d] - mean; m2 = fmaf(t, t, m2); }
+    if (live) for (int b = rl; b < B; b += 8) { const float t = (!mask || mask[b]) ? x[(int64_t)b * D + d] - mean : 0.f; m2 = fmaf(t, t, m2); }
     red[rl][cl] = m2;
     __syncthreads();
     if (rl == 0 && live) {
       m2 = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) m2 += red[q][cl];
-      const float var = m2 / (float)B;
+      const float var = m2 / (float)nb;
       const float invstd = 1.0f / sqrtf(var + eps);
       if (rmean) rmean[d] = (1.f - momentum) * rmean[d] + momentum * mean;
-      if (rvar) rvar[d] = (1.f - momentum) * rvar[d] + momentum * (B > 1 ? m2 / (float)(B - 1) : var);
+      if (rvar) rvar[d] = (1.f - momentum) * rvar[d] + momentum * (nb > 1 ? m2 / (float)(nb - 1) : var);
       if (save_mean) { save_mean[d] = mean; save_invstd[d] = invstd; }
       s_mean[cl] = mean; s_inv[cl] = invstd;
     }
@@ -473,7 +516,8 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
   if (!live) return;
   const float mean = s_mean[cl], invstd = s_inv[cl];
   const float g = w ? w[d] : 1.f, be = bias ? bias[d] : 0.f;
-  for (int b = rl; b < B; b += 8) y[(int64_t)b * D + d] = (x[(int64_t)b * D + d] - mean) * invstd * g + be;
+  for (int b = rl; b < B; b += 8)
+    y[(int64_t)b * D + d] = (!mask || mask[b]) ? (x[(int64_t)b * D + d] - mean) * invstd * g + be : 0.f;
 }
 
 __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -481,15 +525,18 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ save_mean,
                                                        const float* __restrict__ save_invstd,
                                                        float* __restrict__ dx, float* __restrict__ dw,
-                                                       float* __restrict__ dbias) {
+                                                       float* __restrict__ dbias, const uint8_t* __restrict__ mask) {
   __shared__ float red[8][2][32];
+  __shared__ int sc[4];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int d = blockIdx.x * 32 + cl;
   const bool live = d < D;
+  const int nb = masked_row_count(mask, B, sc);
   const float mean = live ? save_mean[d] : 0.f, invstd = live ? save_invstd[d] : 0.f, g = (live && w) ? w[d] : 1.f;
   float sdy = 0.f, sdyx = 0.f;
   if (live)
     for (int b = rl; b < B; b += 8) {
+      if (mask && !mask[b]) continue;
       const float t = dy[(int64_t)b * D + d];
       sdy += t; sdyx = fmaf(t, (x[(int64_t)b * D + d] - mean) * invstd, sdyx);
     }
@@ -503,10 +550,11 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
     if (dw) dw[d] += sdyx;
     if (dbias) dbias[d] += sdy;
   }
-  const float k = g * invstd / (float)B;
+  const float k = g * invstd / (float)nb;
   for (int b = rl; b < B; b += 8) {
+    if (mask && !mask[b]) continue;
     const float xh = (x[(int64_t)b * D + d] - mean) * invstd;
-    dx[(int64_t)b * D + d] += k * ((float)B * dy[(int64_t)b * D + d] - sdy - xh * sdyx);
+    dx[(int64_t)b * D + d] += k * ((float)nb * dy[(int64_t)b * D + d] - sdy - xh * sdyx);
   }
 }
 
@@ -690,7 +738,7 @@ __global__ __launch_bounds__(256) void loo_emb_fwd_kernel(const float* __restric
                                                           const int64_t* __restrict__ labels, int P, int K, int D,
                                                           float* __restrict__ cent, int32_t* __restrict__ valid,
                                                           float* __restrict__ emb, int64_t* __restrict__ lab,
-                                                          float* __restrict__ cnorm) {
+                                                          float* __restrict__ cnorm, uint8_t* __restrict__ exists) {
   __shared__ float wsum[4];
   const int p = blockIdx.x, i = blockIdx.y;
   const bool qreal = is_real[p * K + i] != 0;
@@ -698,6 +746,9 @@ __global__ __launch_bounds__(256) void loo_emb_fwd_kernel(const float* __restric
   if (qreal)
     for (int s = 0; s < K; ++s) cnt += (s != i && is_real[p * K + s]) ? 1 : 0;
   if (threadIdx.x == 0) {
+    // exists (nullable, uint8 [K][2P]): identity p takes part in round i -- its i-th instance is real (the query) AND it has
+    // another real instance (a non-zero centroid); train_ctl_model.py:112-122 keeps exactly these rows
+    if (exists) { const uint8_t e = (qreal && cnt > 0) ? 1 : 0; exists[i * 2 * P + p] = e; exists[i * 2 * P + P + p] = e; }
     valid[i * P + p] = cnt;
     const int64_t l = labels[p * K + i];
     lab[(int64_t)i * 2 * P + p] = l;
@@ -786,6 +837,49 @@ __global__ __launch_bounds__(64) void ctl_step_stats_kernel(const float* __restr
   }
 }
 
+// Batches with padded (isReal = False) samples: a centroid round counts only if it kept >= 2 identities (out4 slot 3 = its
+// number of anchors = 2 x identities; triplet_loss_kernel zeroed the round otherwise).  inv_rounds[0] = 1 / #valid rounds
+// (0 if none) -- the device-side factor of the rounds' backward (train_ctl_model.py:143-146: mean over the valid rounds).
+__global__ void ctl_round_scale_kernel(const float* __restrict__ out4_rounds, int K, float* __restrict__ inv_rounds) {
+  int nv = 0;
+  for (int k = 0; k < K; ++k) nv += out4_rounds[4 * k + 3] >= 4.f ? 1 : 0;
+  inv_rounds[0] = nv > 0 ? 1.0f / (float)nv : 0.f;
+}
+
+// ctl_step_stats_kernel for such batches: w[4k] (round losses) must hold the FULL centroid weight (not weight / K); the round
+// means divide by the number of valid rounds; l2 = mean over valid rounds of the mean centroid norm of the round's kept rows.
+__global__ __launch_bounds__(64) void ctl_step_stats_rows_kernel(const float* __restrict__ scal, const float* __restrict__ w, int n,
+                                                                 int K, int P, const float* __restrict__ cnorm,
+                                                                 const uint8_t* __restrict__ exists, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  int nv = 0;
+  for (int k = 1; k <= K; ++k) nv += scal[4 * k + 3] >= 4.f ? 1 : 0;
+  const float inv = nv > 0 ? 1.0f / (float)nv : 0.f;
+  float total = 0.f, step = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const bool round_loss = i >= 4 && i < 4 * (K + 1) && (i & 3) == 0;
+    const float t = scal[i] * w[i] * (round_loss ? inv : 1.f);
+    out[i] = t;
+    total += t;
+    if (round_loss) step += t;
+  }
+  out[n] = total; out[n + 1] = step;
+  for (int c = 0; c < 4; ++c) {
+    float a = 0.f;
+    for (int k = 1; k <= K; ++k) a += scal[4 * k + 3] >= 4.f ? scal[4 * k + c] : 0.f;
+    out[n + 2 + c] = a * inv;
+  }
+  float l2 = 0.f;
+  for (int k = 0; k < K; ++k) {
+    if (scal[4 * (k + 1) + 3] < 4.f) continue;
+    float a = 0.f; int c = 0;
+    for (int p = 0; p < P; ++p)
+      if (exists[k * 2 * P + P + p]) { a += cnorm[k * P + p]; ++c; }
+    l2 += a / (float)c;
+  }
+  out[n + 6] = l2 * inv;
+}
+
 // ======================================================================================
 extern "C" {
 
@@ -809,7 +903,30 @@ int creid_loo_emb_fwd(const float* feat, const uint8_t* is_real, const int64_t* 
                       float* centroids, int32_t* valid, float* emb, int64_t* lab, float* cnorm, void* stream) {
   CREID_CHECK_ARG(feat && is_real && labels && centroids && valid && emb && lab && cnorm && P > 0 && K > 0 && D > 0);
   hipLaunchKernelGGL(loo_emb_fwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream), feat, is_real, labels,
-                     (int)P, (int)K, (int)D, centroids, valid, emb, lab, cnorm);
+                     (int)P, (int)K, (int)D, centroids, valid, emb, lab, cnorm, (uint8_t*)nullptr);
+  CREID_LAUNCH_RET();
+}
+
+int creid_loo_emb_fwd_rows(const float* feat, const uint8_t* is_real, const int64_t* labels, int64_t P, int64_t K, int64_t D,
+                           float* centroids, int32_t* valid, float* emb, int64_t* lab, float* cnorm, uint8_t* row_exists,
+                           void* stream) {
+  CREID_CHECK_ARG(feat && is_real && labels && centroids && valid && emb && lab && cnorm && row_exists && P > 0 && K > 0 && D > 0);
+  hipLaunchKernelGGL(loo_emb_fwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream), feat, is_real, labels,
+                     (int)P, (int)K, (int)D, centroids, valid, emb, lab, cnorm, row_exists);
+  CREID_LAUNCH_RET();
+}
+
+int creid_ctl_round_scale(const float* out4_rounds, int64_t K, float* inv_rounds, void* stream) {
+  CREID_CHECK_ARG(out4_rounds && inv_rounds && K > 0);
+  hipLaunchKernelGGL(ctl_round_scale_kernel, dim3(1), dim3(1), 0, as_stream(stream), out4_rounds, (int)K, inv_rounds);
+  CREID_LAUNCH_RET();
+}
+
+int creid_ctl_step_stats_rows(const float* scal, const float* weights, int64_t n, int64_t K, int64_t P, const float* cnorm,
+                              const uint8_t* row_exists, float* out, void* stream) {
+  CREID_CHECK_ARG(scal && weights && cnorm && row_exists && out && n >= 4 * (K + 1) && K > 0 && P > 0);
+  hipLaunchKernelGGL(ctl_step_stats_rows_kernel, dim3(1), dim3(64), 0, as_stream(stream), scal, weights, (int)n, (int)K, (int)P,
+                     cnorm, row_exists, out);
   CREID_LAUNCH_RET();
 }
 
@@ -832,7 +949,8 @@ int creid_ctl_step_stats(const float* scal, const float* weights, int64_t n, int
 
 static int triplet_fwd_impl(int kind, const float* x, const int64_t* labels, const uint8_t* anchor_mask, int64_t nb, int64_t N,
                             int64_t D, float margin, float* dist_ap, float* dist_an, int32_t* p_idx, int32_t* n_idx,
-                            float* coef, float* out4, float* dist_mat, void* stream) {
+                            float* coef, float* out4, float* dist_mat, void* stream, const uint8_t* row_exists = nullptr,
+                            int min_anchors = 0) {
   CREID_CHECK_ARG(x && labels && dist_ap && dist_an && p_idx && n_idx && out4 && N > 0 && D > 0 && nb > 0);
   if (D % 4 != 0 || nb > 65535) return CREID_E_SHAPE;
   const size_t smem = (size_t)(D + N) * sizeof(float);
@@ -840,12 +958,12 @@ static int triplet_fwd_impl(int kind, const float* x, const int64_t* labels, con
   hipStream_t s = as_stream(stream);
   if (kind == 0)
     hipLaunchKernelGGL(triplet_mine_kernel<0>, dim3((unsigned)N, (unsigned)nb), dim3(TM_T), smem, s, x, labels, (int)N,
-                       (int)D, dist_ap, dist_an, p_idx, n_idx, dist_mat);
+                       (int)D, dist_ap, dist_an, p_idx, n_idx, dist_mat, row_exists);
   else
     hipLaunchKernelGGL(triplet_mine_kernel<1>, dim3((unsigned)N, (unsigned)nb), dim3(TM_T), smem, s, x, labels, (int)N,
-                       (int)D, dist_ap, dist_an, p_idx, n_idx, dist_mat);
-  hipLaunchKernelGGL(triplet_loss_kernel, dim3(1, (unsigned)nb), dim3(256), 0, s, dist_ap, dist_an, anchor_mask, (int)N,
-                     margin, out4, coef);
+                       (int)D, dist_ap, dist_an, p_idx, n_idx, dist_mat, row_exists);
+  hipLaunchKernelGGL(triplet_loss_kernel, dim3(1, (unsigned)nb), dim3(256), 0, s, dist_ap, dist_an,
+                     row_exists ? row_exists : anchor_mask, (int)N, margin, out4, coef, min_anchors);
   CREID_LAUNCH_RET();
 }
 
@@ -854,6 +972,14 @@ int creid_triplet_fwd_batched(const float* x, const int64_t* labels, const uint8
                               float* coef, float* out4, float* dist_mat, void* stream) {
   return triplet_fwd_impl(0, x, labels, anchor_mask, nb, N, D, margin, dist_ap, dist_an, p_idx, n_idx, coef, out4, dist_mat,
                           stream);
+}
+
+int creid_triplet_fwd_batched_rows(const float* x, const int64_t* labels, const uint8_t* row_exists, int64_t nb, int64_t N,
+                                   int64_t D, float margin, int32_t min_rows, float* dist_ap, float* dist_an, int32_t* p_idx,
+                                   int32_t* n_idx, float* coef, float* out4, void* stream) {
+  CREID_CHECK_ARG(row_exists && coef && min_rows >= 0);
+  return triplet_fwd_impl(0, x, labels, nullptr, nb, N, D, margin, dist_ap, dist_an, p_idx, n_idx, coef, out4, nullptr, stream,
+                          row_exists, (int)min_rows);
 }
 
 int creid_triplet_cosine_fwd(const float* x_unit, const int64_t* labels, const uint8_t* anchor_mask, int64_t N, int64_t D,
@@ -938,7 +1064,16 @@ int creid_center_loss_fwd(const float* x, const int64_t* labels, const float* ce
   CREID_CHECK_ARG(x && labels && centers && row_sq && loss && B > 0 && C > 0 && D > 0);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(center_row_kernel, dim3((unsigned)B), dim3(256), 0, s, x, labels, centers, (int)D, row_sq);
-  hipLaunchKernelGGL(center_reduce_kernel, dim3(1), dim3(256), 0, s, row_sq, (int)B, (int)C, loss);
+  hipLaunchKernelGGL(center_reduce_kernel, dim3(1), dim3(256), 0, s, row_sq, (int)B, (int)C, loss, (const uint8_t*)nullptr);
+  CREID_LAUNCH_RET();
+}
+
+int creid_center_loss_fwd_masked(const float* x, const int64_t* labels, const float* centers, const uint8_t* row_mask, int64_t B,
+                                 int64_t C, int64_t D, float* row_sq, float* loss, void* stream) {
+  CREID_CHECK_ARG(x && labels && centers && row_mask && row_sq && loss && B > 0 && C > 0 && D > 0);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(center_row_kernel, dim3((unsigned)B), dim3(256), 0, s, x, labels, centers, (int)D, row_sq);
+  hipLaunchKernelGGL(center_reduce_kernel, dim3(1), dim3(256), 0, s, row_sq, (int)B, (int)C, loss, row_mask);
   CREID_LAUNCH_RET();
 }
 
@@ -947,7 +1082,16 @@ int creid_center_loss_bwd(const float* x, const int64_t* labels, const float* ce
                           float* dcenters_accum, void* stream) {
   CREID_CHECK_ARG(x && labels && centers && row_sq && B > 0 && D > 0 && (dx_accum || dcenters_accum));
   hipLaunchKernelGGL(center_bwd_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), x, labels, centers,
-                     row_sq, (int)B, (int)D, gscale_dev, gscale, dx_accum, dcenters_accum);
+                     row_sq, (int)B, (int)D, gscale_dev, gscale, dx_accum, dcenters_accum, (const uint8_t*)nullptr);
+  CREID_LAUNCH_RET();
+}
+
+int creid_center_loss_bwd_masked(const float* x, const int64_t* labels, const float* centers, const float* row_sq,
+                                 const uint8_t* row_mask, int64_t B, int64_t D, const float* gscale_dev, float gscale,
+                                 float* dx_accum, float* dcenters_accum, void* stream) {
+  CREID_CHECK_ARG(x && labels && centers && row_sq && row_mask && B > 0 && D > 0 && (dx_accum || dcenters_accum));
+  hipLaunchKernelGGL(center_bwd_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), x, labels, centers,
+                     row_sq, (int)B, (int)D, gscale_dev, gscale, dx_accum, dcenters_accum, row_mask);
   CREID_LAUNCH_RET();
 }
 
@@ -956,8 +1100,18 @@ int creid_xent_ls(const float* logits, const int64_t* targets, int64_t B, int64_
   CREID_CHECK_ARG(logits && targets && row_loss && loss && B > 0 && C > 0);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(xent_ls_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, targets, (int)B, (int)C, eps,
-                     row_loss, dlogits, gscale);
-  hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, s, row_loss, (int)B, 1.0f / (float)B, loss);
+                     row_loss, dlogits, gscale, (const uint8_t*)nullptr);
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, s, row_loss, (int)B, 1.0f / (float)B, loss, (const uint8_t*)nullptr);
+  CREID_LAUNCH_RET();
+}
+
+int creid_xent_ls_masked(const float* logits, const int64_t* targets, const uint8_t* row_mask, int64_t B, int64_t C, float eps,
+                         float gscale, float* row_loss, float* loss, float* dlogits, void* stream) {
+  CREID_CHECK_ARG(logits && targets && row_mask && row_loss && loss && B > 0 && C > 0);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(xent_ls_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, targets, (int)B, (int)C, eps,
+                     row_loss, dlogits, gscale, row_mask);
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, s, row_loss, (int)B, 0.f, loss, row_mask);
   CREID_LAUNCH_RET();
 }
 
@@ -968,7 +1122,16 @@ int creid_bn1d_fwd(const float* x, int64_t B, int64_t D, const float* weight, co
   CREID_CHECK_ARG(training || (running_mean && running_var));
   hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)((D + 31) / 32)), dim3(256), 0, as_stream(stream), x, (int)B,
                      (int)D, weight, bias, running_mean, running_var, training, momentum, eps, y, save_mean,
-                     save_invstd);
+                     save_invstd, (const uint8_t*)nullptr);
+  CREID_LAUNCH_RET();
+}
+
+int creid_bn1d_fwd_masked(const float* x, const uint8_t* row_mask, int64_t B, int64_t D, const float* weight, const float* bias,
+                          float* running_mean, float* running_var, float momentum, float eps, float* y, float* save_mean,
+                          float* save_invstd, void* stream) {
+  CREID_CHECK_ARG(x && y && row_mask && B > 0 && D > 0);
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((unsigned)((D + 31) / 32)), dim3(256), 0, as_stream(stream), x, (int)B,
+                     (int)D, weight, bias, running_mean, running_var, 1, momentum, eps, y, save_mean, save_invstd, row_mask);
   CREID_LAUNCH_RET();
 }
 
@@ -977,7 +1140,16 @@ int creid_bn1d_bwd(const float* x, const float* dy, int64_t B, int64_t D, const 
                    void* stream) {
   CREID_CHECK_ARG(x && dy && save_mean && save_invstd && dx_accum && B > 0 && D > 0);
   hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((D + 31) / 32)), dim3(256), 0, as_stream(stream), x, dy,
-                     (int)B, (int)D, weight, save_mean, save_invstd, dx_accum, dweight_accum, dbias_accum);
+                     (int)B, (int)D, weight, save_mean, save_invstd, dx_accum, dweight_accum, dbias_accum, (const uint8_t*)nullptr);
+  CREID_LAUNCH_RET();
+}
+
+int creid_bn1d_bwd_masked(const float* x, const float* dy, const uint8_t* row_mask, int64_t B, int64_t D, const float* weight,
+                          const float* save_mean, const float* save_invstd, float* dx_accum, float* dweight_accum,
+                          float* dbias_accum, void* stream) {
+  CREID_CHECK_ARG(x && dy && row_mask && save_mean && save_invstd && dx_accum && B > 0 && D > 0);
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((unsigned)((D + 31) / 32)), dim3(256), 0, as_stream(stream), x, dy,
+                     (int)B, (int)D, weight, save_mean, save_invstd, dx_accum, dweight_accum, dbias_accum, row_mask);
   CREID_LAUNCH_RET();
 }
 

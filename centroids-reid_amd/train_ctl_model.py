@@ -79,8 +79,26 @@ class CTLModel(ModelBase):
         assert B % K == 0, "batch must be PID-contiguous [P, K] (datasets/bases.py:447-455 collate)"
         P = B // K
         dev = x.device
+        # hand-scheduled heads (same kernels, no autograd tape).  K <= 16: creid_loo_emb_bwd keeps one register slot per
+        # instance of a pid.  All-real batches take the unmasked schedule; batches with padded samples (isReal = False,
+        # datasets/bases.py:346-406) the masked one, driven by a DEVICE mask: given isReal on the device the step contains
+        # no host synchronisation for any pattern of fakes (hipGraph-capturable, bench.py's "fake_mix" line)
+        fused_ok = (self.fused_heads and P >= 2 and 2 <= K <= 16 and x.is_cuda and hasattr(self.backbone, "engine")
+                    and self.backbone.training and self.contrastive_loss.margin is not None
+                    and self.contrastive_loss.dist_name == "euclidean")
+        if fused_ok and isinstance(isReal, torch.Tensor) and isReal.is_cuda:
+            real = isReal if isReal.dtype == torch.uint8 else isReal.to(torch.uint8)
+            return self._forward_backward_fused(x, class_labels.to(dev, non_blocking=True), P, K, real=real.contiguous())
         ir_host = np.asarray(isReal.cpu() if isinstance(isReal, torch.Tensor) else isReal, dtype=bool)
         all_real = bool(ir_host.all())
+        if fused_ok and not all_real:
+            ir2 = ir_host.reshape(P, K)
+            lonely = ir2 & (ir2.sum(1, keepdims=True) == 1)                  # a real instance without a real partner
+            if lonely.any():
+                raise RuntimeError("query/centroid count mismatch in a centroid round (the reference fails in "
+                                   "labels.expand at losses/triplet_loss.py:88)")
+            real = torch.as_tensor(ir_host.astype(np.uint8)).to(dev)
+            return self._forward_backward_fused(x, class_labels.to(dev, non_blocking=True), P, K, real=real)
         if all_real:       # cached device mask: no H2D copy inside the step (keeps it hipGraph-capturable)
             cache = getattr(self, "_all_real_dev", None)
             if cache is None or cache.numel() != B or cache.device != dev:
@@ -90,10 +108,7 @@ class CTLModel(ModelBase):
             is_real = (isReal if isinstance(isReal, torch.Tensor) else torch.as_tensor(ir_host)).to(dev)
         class_labels = class_labels.to(dev, non_blocking=True)
 
-        # (K <= 16: creid_loo_emb_bwd keeps one register slot per instance of a pid)
-        if (self.fused_heads and all_real and P >= 2 and 2 <= K <= 16 and x.is_cuda and hasattr(self.backbone, "engine")
-                and self.backbone.training and self.contrastive_loss.margin is not None
-                and self.contrastive_loss.dist_name == "euclidean"):
+        if fused_ok and all_real:
             return self._forward_backward_fused(x, class_labels, P, K)
 
         _, features = self.backbone(x)                                        # :59
@@ -156,12 +171,15 @@ class CTLModel(ModelBase):
         return {"loss": total_loss.detach(), "other": log_data}
 
     # ------------------------------------------------------------------ hand-scheduled heads (all-real batch)
-    def _forward_backward_fused(self, x, class_labels, P, K):
+    def _forward_backward_fused(self, x, class_labels, P, K, real=None):
         """The same arithmetic as the autograd path of forward_backward (train_ctl_model.py:59-152), issued as
         one explicit forward/backward schedule over the C ABI: every backward kernel accumulates into a single
         dfeat buffer / the parameters' .grad, loss weights ride in the kernels' gscale argument, and the K centroid
-        rounds share one [K, 2P, D] embedding buffer."""
+        rounds share one [K, 2P, D] embedding buffer.  real (uint8 [B] on the device, optional): the isReal mask -- the
+        masked schedule of train_ctl_model.py:62-148 (anchors of the query triplet, rows of center / BNNeck / xent, rows and
+        validity of the centroid rounds), every count taken on the device."""
         hp = self.hparams
+        masked = real is not None
         lib, st = L.lib(), L.stream()
         eng = self.backbone.engine
         _, feat = eng.forward(x.contiguous().float(), True, False)            # :59  [B, D] fp32
@@ -184,70 +202,114 @@ class CTLModel(ModelBase):
                 p.grad = torch.zeros_like(p)
             return p.grad
 
-        def triplet(emb, lab, nb, N, o4, gscale, demb):
-            """nb stacked problems [nb, N, D] in one launch per kernel (mining, loss, backward)."""
+        def triplet(emb, lab, nb, N, o4, gscale, demb, anchor_mask=None, rows=None, gscale_dev=None):
+            """nb stacked problems [nb, N, D] in one launch per kernel (mining, loss, backward).  anchor_mask: the reference's
+            `mask` argument (anchors dropped after mining); rows: uint8 [nb, N] of rows that exist at all (centroid rounds of
+            a batch with fakes; problems with < 2 identities are skipped by the kernel)."""
             dap, dan, coef = torch.empty(nb * N, **f32), torch.empty(nb * N, **f32), torch.empty(nb * N, **f32)
             pi, ni = torch.empty(nb * N, **i32), torch.empty(nb * N, **i32)
-            L.check(lib.creid_triplet_fwd_batched(L.ptr(emb), L.ptr(lab), None, nb, N, D, margin, L.ptr(dap), L.ptr(dan),
-                                                  L.ptr(pi), L.ptr(ni), L.ptr(coef), L.ptr(o4), None, st),
-                    "creid_triplet_fwd_batched")
+            if rows is None:
+                L.check(lib.creid_triplet_fwd_batched(L.ptr(emb), L.ptr(lab), L.ptr(anchor_mask), nb, N, D, margin, L.ptr(dap),
+                                                      L.ptr(dan), L.ptr(pi), L.ptr(ni), L.ptr(coef), L.ptr(o4), None, st),
+                        "creid_triplet_fwd_batched")
+            else:
+                L.check(lib.creid_triplet_fwd_batched_rows(L.ptr(emb), L.ptr(lab), L.ptr(rows), nb, N, D, margin, 4, L.ptr(dap),
+                                                           L.ptr(dan), L.ptr(pi), L.ptr(ni), L.ptr(coef), L.ptr(o4), st),
+                        "creid_triplet_fwd_batched_rows")
+                L.check(lib.creid_ctl_round_scale(L.ptr(o4), nb, L.ptr(gscale_dev), st), "creid_ctl_round_scale")
             L.check(lib.creid_triplet_bwd_batched(L.ptr(emb), nb, N, D, L.ptr(dap), L.ptr(dan), L.ptr(pi), L.ptr(ni),
-                                                  L.ptr(coef), None, float(gscale), L.ptr(demb), st),
+                                                  L.ptr(coef), L.ptr(gscale_dev), float(gscale), L.ptr(demb), st),
                     "creid_triplet_bwd_batched")
             return dap, dan, pi, ni, coef                                       # keep alive until the caller returns
 
-        keep = [triplet(feat, labels, 1, B, out4[0], hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT, dfeat)]       # :62-67
+        keep = [triplet(feat, labels, 1, B, out4[0], hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT, dfeat, anchor_mask=real)]   # :62-67
 
         centers = self.center_loss.centers                                     # :71-73
         C_cent = centers.shape[0]
         row_c = torch.empty(B, **f32)
-        L.check(lib.creid_center_loss_fwd(L.ptr(feat), L.ptr(labels), L.ptr(centers), B, C_cent, D, L.ptr(row_c),
-                                          L.ptr(lc), st), "creid_center_loss_fwd")
-        L.check(lib.creid_center_loss_bwd(L.ptr(feat), L.ptr(labels), L.ptr(centers), L.ptr(row_c), B, D, None,
-                                          float(hp.SOLVER.CENTER_LOSS_WEIGHT), L.ptr(dfeat), L.ptr(grad_of(centers)), st),
-                "creid_center_loss_bwd")
+        if masked:
+            L.check(lib.creid_center_loss_fwd_masked(L.ptr(feat), L.ptr(labels), L.ptr(centers), L.ptr(real), B, C_cent, D,
+                                                     L.ptr(row_c), L.ptr(lc), st), "creid_center_loss_fwd_masked")
+            L.check(lib.creid_center_loss_bwd_masked(L.ptr(feat), L.ptr(labels), L.ptr(centers), L.ptr(row_c), L.ptr(real), B, D,
+                                                     None, float(hp.SOLVER.CENTER_LOSS_WEIGHT), L.ptr(dfeat),
+                                                     L.ptr(grad_of(centers)), st), "creid_center_loss_bwd_masked")
+        else:
+            L.check(lib.creid_center_loss_fwd(L.ptr(feat), L.ptr(labels), L.ptr(centers), B, C_cent, D, L.ptr(row_c),
+                                              L.ptr(lc), st), "creid_center_loss_fwd")
+            L.check(lib.creid_center_loss_bwd(L.ptr(feat), L.ptr(labels), L.ptr(centers), L.ptr(row_c), B, D, None,
+                                              float(hp.SOLVER.CENTER_LOSS_WEIGHT), L.ptr(dfeat), L.ptr(grad_of(centers)), st),
+                    "creid_center_loss_bwd")
 
         bn, W = self.bn, self.fc_query.weight                                  # :74-77 BNNeck -> classifier -> xent
         bn.num_batches_tracked += 1
         bnf, sm, si = torch.empty((B, D), **f32), torch.empty(D, **f32), torch.empty(D, **f32)
-        L.check(lib.creid_bn1d_fwd(L.ptr(feat), B, D, L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
-                                   L.ptr(bn.running_var), 1, float(bn.momentum), float(bn.eps), L.ptr(bnf), L.ptr(sm),
-                                   L.ptr(si), st), "creid_bn1d_fwd")
+        if masked:
+            L.check(lib.creid_bn1d_fwd_masked(L.ptr(feat), L.ptr(real), B, D, L.ptr(bn.weight), L.ptr(bn.bias),
+                                              L.ptr(bn.running_mean), L.ptr(bn.running_var), float(bn.momentum), float(bn.eps),
+                                              L.ptr(bnf), L.ptr(sm), L.ptr(si), st), "creid_bn1d_fwd_masked")
+        else:
+            L.check(lib.creid_bn1d_fwd(L.ptr(feat), B, D, L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
+                                       L.ptr(bn.running_var), 1, float(bn.momentum), float(bn.eps), L.ptr(bnf), L.ptr(sm),
+                                       L.ptr(si), st), "creid_bn1d_fwd")
         C_cls = W.shape[0]
         det = ops._DETERMINISTIC
         logits = ops.gemm_f32(bnf, D, 1, W, 1, D, B, C_cls, D, split_k=1 if det else 32)          # 64-deep K slices
         row_x, dlogits = torch.empty(B, **f32), torch.empty((B, C_cls), **f32)
-        L.check(lib.creid_xent_ls(L.ptr(logits), L.ptr(labels), B, C_cls, float(self.xent.epsilon),
-                                  float(hp.SOLVER.QUERY_XENT_WEIGHT), L.ptr(row_x), L.ptr(lx), L.ptr(dlogits), st),
-                "creid_xent_ls")
+        if masked:             # padded rows: bnf = 0 -> logits 0, row loss 0, dlogits 0 (no contribution to dW / dbnf)
+            L.check(lib.creid_xent_ls_masked(L.ptr(logits), L.ptr(labels), L.ptr(real), B, C_cls, float(self.xent.epsilon),
+                                             float(hp.SOLVER.QUERY_XENT_WEIGHT), L.ptr(row_x), L.ptr(lx), L.ptr(dlogits), st),
+                    "creid_xent_ls_masked")
+        else:
+            L.check(lib.creid_xent_ls(L.ptr(logits), L.ptr(labels), B, C_cls, float(self.xent.epsilon),
+                                      float(hp.SOLVER.QUERY_XENT_WEIGHT), L.ptr(row_x), L.ptr(lx), L.ptr(dlogits), st),
+                    "creid_xent_ls")
         dbnf = ops.gemm_f32(dlogits, C_cls, 1, W, D, 1, B, D, C_cls, split_k=1 if det else 12)      # dlogits @ W
         if W.requires_grad:
             ops.gemm_f32(dlogits, 1, C_cls, bnf, D, 1, C_cls, D, B, out=grad_of(W), beta=1.0)     # += dlogits^T @ bnf
-        L.check(lib.creid_bn1d_bwd(L.ptr(feat), L.ptr(dbnf), B, D, L.ptr(bn.weight), L.ptr(sm), L.ptr(si), L.ptr(dfeat),
-                                   L.ptr(grad_of(bn.weight)), L.ptr(grad_of(bn.bias)), st), "creid_bn1d_bwd")
+        if masked:
+            L.check(lib.creid_bn1d_bwd_masked(L.ptr(feat), L.ptr(dbnf), L.ptr(real), B, D, L.ptr(bn.weight), L.ptr(sm), L.ptr(si),
+                                              L.ptr(dfeat), L.ptr(grad_of(bn.weight)), L.ptr(grad_of(bn.bias)), st),
+                    "creid_bn1d_bwd_masked")
+        else:
+            L.check(lib.creid_bn1d_bwd(L.ptr(feat), L.ptr(dbnf), B, D, L.ptr(bn.weight), L.ptr(sm), L.ptr(si), L.ptr(dfeat),
+                                       L.ptr(grad_of(bn.weight)), L.ptr(grad_of(bn.bias)), st), "creid_bn1d_bwd")
 
         # ---- leave-one-out centroids and the K centroid rounds (:79-148)
         cent = torch.empty((K, P, D), **f32)
         valid = torch.empty((K, P), **i32)
         emb = torch.empty((K, 2 * P, D), **f32)                                # round i: P queries, then P centroids
         lab = torch.empty((K, 2 * P), dtype=torch.int64, device=dev)
-        real = self._all_real_u8(B, dev)
         cnorm = torch.empty(K * P, **f32)
-        L.check(lib.creid_loo_emb_fwd(L.ptr(feat), L.ptr(real), L.ptr(labels), P, K, D, L.ptr(cent), L.ptr(valid), L.ptr(emb),
-                                      L.ptr(lab), L.ptr(cnorm), st), "creid_loo_emb_fwd")
         demb = zbuf[B * D:].view(K, 2 * P, D)
-        g_round = hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT / K
-        keep.append(triplet(emb, lab, K, 2 * P, out4[1:], g_round, demb))      # the K rounds: one launch per kernel
+        if masked:
+            rows = torch.empty((K, 2 * P), dtype=torch.uint8, device=dev)
+            inv_rounds = torch.empty(1, **f32)
+            L.check(lib.creid_loo_emb_fwd_rows(L.ptr(feat), L.ptr(real), L.ptr(labels), P, K, D, L.ptr(cent), L.ptr(valid),
+                                               L.ptr(emb), L.ptr(lab), L.ptr(cnorm), L.ptr(rows), st), "creid_loo_emb_fwd_rows")
+            # the K rounds, valid ones only (>= 2 identities kept, :113); their mean is taken on the device (inv_rounds)
+            keep.append(triplet(emb, lab, K, 2 * P, out4[1:], hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT, demb, rows=rows,
+                                gscale_dev=inv_rounds))
+        else:
+            real = self._all_real_u8(B, dev)
+            L.check(lib.creid_loo_emb_fwd(L.ptr(feat), L.ptr(real), L.ptr(labels), P, K, D, L.ptr(cent), L.ptr(valid), L.ptr(emb),
+                                          L.ptr(lab), L.ptr(cnorm), st), "creid_loo_emb_fwd")
+            g_round = hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT / K
+            keep.append(triplet(emb, lab, K, 2 * P, out4[1:], g_round, demb))      # the K rounds: one launch per kernel
         L.check(lib.creid_loo_emb_bwd(L.ptr(demb), L.ptr(real), P, K, D, L.ptr(dfeat), st), "creid_loo_emb_bwd")
 
         eng.backward(dfeat)                                                    # manual_backward (:152)
 
         # weighted terms with ONE multiply: w is a cached constant vector aligned with `scal`
         # (query triplet loss, round losses / K, center loss, xent) -- the logged values are views of the product
-        wv = self._loss_weight_vector(K, dev)
+        wv = self._loss_weight_vector(K, dev, full_round_weight=masked)
         n = scal.numel()
         stats = torch.empty(n + 7, **f32)                                      # terms[n], total, step, rounds[4], l2
-        L.check(lib.creid_ctl_step_stats(L.ptr(scal), L.ptr(wv), n, K, L.ptr(cnorm), K * P, L.ptr(stats), st), "creid_ctl_step_stats")
+        if masked:
+            L.check(lib.creid_ctl_step_stats_rows(L.ptr(scal), L.ptr(wv), n, K, P, L.ptr(cnorm), L.ptr(rows), L.ptr(stats), st),
+                    "creid_ctl_step_stats_rows")
+        else:
+            L.check(lib.creid_ctl_step_stats(L.ptr(scal), L.ptr(wv), n, K, L.ptr(cnorm), K * P, L.ptr(stats), st),
+                    "creid_ctl_step_stats")
         terms = stats[:n]
         contrastive_loss_query = terms[0]
         center_loss, xent_query = terms[4 * (K + 1)], terms[4 * (K + 1) + 1]
@@ -259,19 +321,21 @@ class CTLModel(ModelBase):
         log_data = {"step_dist_ap": rounds[1], "step_dist_an": rounds[2], "l2_mean_centroid": l2_mean}
         return {"loss": total_loss, "other": log_data}
 
-    def _loss_weight_vector(self, K, dev):
+    def _loss_weight_vector(self, K, dev, full_round_weight=False):
+        """full_round_weight: the round slots carry the whole centroid weight (the masked schedule divides by the number of
+        VALID rounds on the device) instead of weight / K."""
         hp = self.hparams
         key = (K, str(dev), hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT, hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT,
-               hp.SOLVER.CENTER_LOSS_WEIGHT, hp.SOLVER.QUERY_XENT_WEIGHT)
-        c = getattr(self, "_loss_wv", None)
-        if c is None or c[0] != key:
+               hp.SOLVER.CENTER_LOSS_WEIGHT, hp.SOLVER.QUERY_XENT_WEIGHT, bool(full_round_weight))
+        cache = self.__dict__.setdefault("_loss_wv", {})
+        if key not in cache:
             w = torch.zeros(4 * (K + 1) + 2)
             w[0] = hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT
-            w[4:4 * (K + 1):4] = hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT / K
+            w[4:4 * (K + 1):4] = hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT / (1 if full_round_weight else K)
             w[4 * (K + 1)] = hp.SOLVER.CENTER_LOSS_WEIGHT
             w[4 * (K + 1) + 1] = hp.SOLVER.QUERY_XENT_WEIGHT
-            c = self._loss_wv = (key, w.to(dev))
-        return c[1]
+            cache[key] = w.to(dev)
+        return cache[key]
 
     def _all_real_u8(self, B, dev):
         c = getattr(self, "_all_real_u8_dev", None)

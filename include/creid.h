@@ -161,6 +161,42 @@ int creid_loo_emb_bwd(const float* demb, const uint8_t* is_real, int64_t P, int6
 int creid_ctl_step_stats(const float* scal, const float* weights, int64_t n, int64_t K, const float* cnorm,
                          int64_t rows, float* out, void* stream);
 
+/* ---- the same training step for batches with padded samples (isReal = False, datasets/bases.py:346-406), driven by a DEVICE
+ * mask so that the step stays free of host synchronisation (hipGraph-capturable for any pattern of fakes):
+ *  creid_loo_emb_fwd_rows    = creid_loo_emb_fwd + row_exists uint8 [K][2P]: identity p takes part in round i iff its i-th
+ *                              instance is real and it has another real instance (train_ctl_model.py:112-122 keeps these rows);
+ *  creid_triplet_fwd_batched_rows: rows with row_exists = 0 are neither anchors nor candidates; a problem with fewer than
+ *                              min_rows rows is skipped (out4 = 0, coef = 0: the round with <= 1 valid identity, :113);
+ *  creid_ctl_round_scale     : inv_rounds[0] = 1 / #rounds with out4[k][3] >= 4 (the mean over valid rounds, :143-146), the
+ *                              gscale_dev of the rounds' creid_triplet_bwd_batched;
+ *  creid_ctl_step_stats_rows : creid_ctl_step_stats with the round terms / means over the VALID rounds only and the centroid
+ *                              norm averaged per round over its kept rows; weights[4k] must hold the full centroid weight;
+ *  *_masked                  : center loss, label-smoothed cross entropy and the BNNeck over the rows with row_mask != 0 only
+ *                              (means / statistics over their count), zero gradient and zero output on the others
+ *                              (train_ctl_model.py:69-77 feeds features[isReal] to these three). */
+int creid_loo_emb_fwd_rows(const float* feat, const uint8_t* is_real, const int64_t* labels, int64_t P, int64_t K, int64_t D,
+                           float* centroids, int32_t* valid, float* emb, int64_t* lab, float* cnorm, uint8_t* row_exists,
+                           void* stream);
+int creid_triplet_fwd_batched_rows(const float* x, const int64_t* labels, const uint8_t* row_exists, int64_t nb, int64_t N,
+                                   int64_t D, float margin, int32_t min_rows, float* dist_ap, float* dist_an,
+                                   int32_t* p_idx, int32_t* n_idx, float* coef, float* out4, void* stream);
+int creid_ctl_round_scale(const float* out4_rounds, int64_t K, float* inv_rounds, void* stream);
+int creid_ctl_step_stats_rows(const float* scal, const float* weights, int64_t n, int64_t K, int64_t P, const float* cnorm,
+                              const uint8_t* row_exists, float* out, void* stream);
+int creid_center_loss_fwd_masked(const float* x, const int64_t* labels, const float* centers, const uint8_t* row_mask,
+                                 int64_t B, int64_t C, int64_t D, float* row_sq, float* loss, void* stream);
+int creid_center_loss_bwd_masked(const float* x, const int64_t* labels, const float* centers, const float* row_sq,
+                                 const uint8_t* row_mask, int64_t B, int64_t D, const float* gscale_dev, float gscale,
+                                 float* dx_accum, float* dcenters_accum, void* stream);
+int creid_xent_ls_masked(const float* logits, const int64_t* targets, const uint8_t* row_mask, int64_t B, int64_t C,
+                         float eps, float gscale, float* row_loss, float* loss, float* dlogits, void* stream);
+int creid_bn1d_fwd_masked(const float* x, const uint8_t* row_mask, int64_t B, int64_t D, const float* weight,
+                          const float* bias, float* running_mean, float* running_var, float momentum, float eps, float* y,
+                          float* save_mean, float* save_invstd, void* stream);
+int creid_bn1d_bwd_masked(const float* x, const float* dy, const uint8_t* row_mask, int64_t B, int64_t D,
+                          const float* weight, const float* save_mean, const float* save_invstd, float* dx_accum,
+                          float* dweight_accum, float* dbias_accum, void* stream);
+
 /* ------------------------------------------------------------------ stage C: losses */
 
 /* losses/triplet_loss.py:27-41 (euclidean_dist), :68-119 (hard_example_mining), :139-173

@@ -16,6 +16,31 @@ class FeatStub(torch.nn.Module):
         return None, self.feats * 1.0
 
 
+class EngineStub:
+    """Stands in for backbone.BackboneEngine in the hand-scheduled step: forward returns the stored features, backward
+    accumulates the head gradient into the feature parameter's .grad (a view of the optimiser's flat gradient buffer)."""
+
+    def __init__(self, owner):
+        self.owner = owner
+        self.weights_dirty = False
+
+    def forward(self, x, training, want_base_out=False):
+        return None, self.owner.feats.detach() * 1.0
+
+    def backward(self, dfeat):
+        self.owner.feats.grad.add_(dfeat)
+
+
+class FeatStubEngine(torch.nn.Module):
+    def __init__(self, feats):
+        super().__init__()
+        self.feats = torch.nn.Parameter(feats.clone())
+        self.engine = EngineStub(self)
+
+    def forward(self, x):
+        return None, self.feats * 1.0
+
+
 def _cfg(D, K, margin):
     from centroids_reid_amd.config import get_cfg_defaults
     cfg = get_cfg_defaults()
@@ -27,25 +52,39 @@ def _cfg(D, K, margin):
     return cfg
 
 
+@pytest.mark.parametrize("path", ["autograd", "fused_host_mask", "fused_device_mask"])
 @pytest.mark.parametrize("name", ["heads_p16k4_d128", "heads_p16k4_d128_fake1", "heads_p16k4_d128_fake2", "heads_p8k4_d2048"])
-def test_training_step_heads_golden(golden, name):
+def test_training_step_heads_golden(golden, name, path):
+    """The reference's own training_step recordings (incl. batches with isReal = False samples) through the autograd path,
+    the hand-scheduled step with the mask known on the host, and the same step driven by a DEVICE mask (no host
+    synchronisation: what a captured hipGraph replays for any pattern of fakes)."""
     from centroids_reid_amd.train_ctl_model import CTLModel
     g = golden(name)
     P, K, C = int(g["P"]), int(g["K"]), int(g["C"])
     D = g["feats"].shape[1]
     model = CTLModel(_cfg(D, K, float(g["margin"])), num_classes=C, num_query=0)
-    model.backbone = FeatStub(torch.from_numpy(g["feats"]))
+    model.backbone = (FeatStub if path == "autograd" else FeatStubEngine)(torch.from_numpy(g["feats"]))
     with torch.no_grad():
         model.center_loss.centers.copy_(torch.from_numpy(g["centers0"]))
         model.fc_query.weight.copy_(torch.from_numpy(g["fc0"]))
         model.bn.weight.copy_(torch.from_numpy(g["bn_w0"]))
     model = model.cuda().train()
     model.configure_optimizers()
+    is_real = torch.from_numpy(g["is_real"])
+    if path == "fused_device_mask":
+        is_real = is_real.cuda()
     batch = (torch.zeros(P * K, 3, 8, 4, device="cuda"), torch.from_numpy(g["labels"]).cuda(),
-             torch.zeros(P * K, dtype=torch.int64), torch.from_numpy(g["is_real"]))
+             torch.zeros(P * K, dtype=torch.int64), is_real)
     nsteps = 2 if "s1_loss_total" in g else 1
+    calls = []
+    if path != "autograd":
+        orig = model._forward_backward_fused
+        model._forward_backward_fused = lambda *a, **k: (calls.append(k.get("real") is not None), orig(*a, **k))[1]
     for s in range(nsteps):
         out = model.training_step(batch, s)
+        if path != "autograd":            # the hand-scheduled step ran, masked iff the mask is on the device or has fakes
+            assert len(calls) == s + 1
+            assert calls[-1] == (path == "fused_device_mask" or not bool(g["is_real"].all()))
         assert abs(float(out["loss"]) - float(g[f"s{s}_loss_total"])) < 3e-5
         for n in model.losses_names:
             assert abs(float(model.losses_dict[n][-1]) - float(g[f"s{s}_{n}"])) < 3e-5, n
