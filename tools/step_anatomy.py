@@ -36,6 +36,21 @@ def main(path):
     print("| group | launches | us | % |\n|---|---:|---:|---:|")
     for g, (c, t) in sorted(grp.items(), key=lambda kv: -kv[1][1]):
         print(f"| {g} | {c} | {t/1e3:.0f} | {100*t/tot:.1f} |")
+    # BatchNorm apply launches by role (ResNet50: per block c1, c2, [ds on the first block of a layer], c3 in forward order;
+    # c3, c2, c1, [ds] per block in reverse block order in backward): what consumer-side fusion of bn1 / bn2 could remove at most
+    has_ds = {0, 3, 7, 13}
+    fwd_roles = [r for b in range(16) for r in (["c1", "c2"] + (["ds"] if b in has_ds else []) + ["c3"])]
+    bwd_roles = [r for b in reversed(range(16)) for r in (["c3", "c2", "c1"] + (["ds"] if b in has_ds else []))]
+    for label, pat, roles in (("BN apply (forward)", r"bn2d_apply_kernel", fwd_roles), ("BN backward apply", r"bn2d_bwd_apply_kernel", bwd_roles)):
+        ls = [(e - st) / 1e3 for n, st, e in step if re.search(pat, n)]
+        if len(ls) not in (len(roles), len(roles) + 1):
+            continue
+        if len(ls) == len(roles) + 1:                 # backward: the stem's BatchNorm comes last
+            roles = roles + ["stem"]
+        tot = {}
+        for r, t in zip(roles, ls):
+            v = tot.setdefault(r, [0, 0.0]); v[0] += 1; v[1] += t
+        print(f"\n{label} by role: " + ", ".join(f"{r}: {c} launches {t:.0f} us" for r, (c, t) in sorted(tot.items())))
     print("\n| kernel | launches | us | avg us |\n|---|---:|---:|---:|")
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
         print(f"| {n} | {c} | {t/1e3:.0f} | {t/c/1e3:.1f} |")
