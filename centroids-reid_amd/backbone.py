@@ -279,6 +279,15 @@ class BackboneEngine:
         # one launch per conv instead of conv -> finalize -> apply (CREID_EVAL_FOLD=0: the three-launch schedule)
         self.eval_fold = os.environ.get("CREID_EVAL_FOLD", "1") == "1"
         self._fold_key = None
+        # TIMING-ONLY ablation (results are WRONG): bit 0 skips the forward BatchNorm apply launches of bn1 / bn2 (no residual),
+        # bit 1 their backward apply launches -- the upper bound of what fusing those passes into the consuming / producing
+        # convolutions could save (profiles/r03_bn_fusion_bound.md)
+        self.dual_apply = os.environ.get("CREID_DUAL_APPLY", "1") == "1"     # A/B knob: 0 = separate downsample-BN apply launch
+        self._apply_dry = int(os.environ.get("CREID_BN_APPLY_DRY", "0"))
+        if self._apply_dry:
+            import sys
+            print(f"[creid] WARNING: CREID_BN_APPLY_DRY={self._apply_dry} is a timing-only ablation switch -- results are WRONG",
+                  file=sys.stderr)
 
     # ---- helpers
     @property
@@ -436,8 +445,10 @@ class BackboneEngine:
             L.check(lib.creid_nhwc_to_nchw_f32(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(base_out), st), "nhwc_to_nchw")
         return base_out, feat
 
-    def _conv_bn(self, u, a_in, B, H, W, training, relu, residual=None):
-        """conv -> BN(batch or running stats) -> (+residual) -> (ReLU).  Returns (x_raw, a_out, mean, invstd, oh, ow)."""
+    def _conv_bn(self, u, a_in, B, H, W, training, relu, residual=None, residual_ss=None, apply=True):
+        """conv -> BN(batch or running stats) -> (+residual) -> (ReLU).  Returns (x_raw, a_out, mean, invstd, oh, ow).
+        apply=False: statistics only, a_out is the (scale, shift) pair instead (the downsample branch: its normalisation
+        happens inside the block's bn3 pass, which takes the raw tensor as `residual` and that pair as `residual_ss`)."""
         lib, st = L.lib(), L.stream()
         d, oh, ow = _desc(B, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
         M = B * oh * ow
@@ -455,7 +466,7 @@ class BackboneEngine:
         part = self._empty(rows * 2, u.cout, dtype=torch.float32) if training else None
         L.check(lib.creid_conv2d_fwd_nhwc(C.byref(d), L.ptr(a_in), L.ptr(u.w_krsc), L.ptr(x), L.ptr(part), self.dt, st),
                 "conv2d_fwd")
-        return (x,) + self._bn_tail(u, x, part, rows, M, training, relu, residual) + (oh, ow)
+        return (x,) + self._bn_tail(u, x, part, rows, M, training, relu, residual, residual_ss, apply) + (oh, ow)
 
     def _ibn_tail(self, u, x, B, HW, training, relu, part=None):
         lib, st = L.lib(), L.stream()
@@ -496,7 +507,7 @@ class BackboneEngine:
                                   L.ptr(self._grad_of(bn.weight)), L.ptr(self._grad_of(bn.bias)), L.ptr(dx), st), "ibn_bwd")
         return dx, None
 
-    def _bn_tail(self, u, x, part, rows, M, training, relu, residual):
+    def _bn_tail(self, u, x, part, rows, M, training, relu, residual, residual_ss=None, apply=True):
         lib, st = L.lib(), L.stream()
         bn = u.bn
         mean = self._empty(u.cout, dtype=torch.float32)
@@ -505,12 +516,18 @@ class BackboneEngine:
         L.check(lib.creid_bn2d_finalize(L.ptr(part), rows, u.cout, M, L.ptr(bn.running_mean), L.ptr(bn.running_var),
                                         1 if training else 0, bn.momentum, bn.eps, L.ptr(bn.weight), L.ptr(bn.bias),
                                         L.ptr(mean), L.ptr(invstd), L.ptr(ss), st), "bn2d_finalize")
+        if not apply:
+            return ss, mean, invstd
         a = self._empty(M, u.cout)
         mask = None
         if training and relu and self.relu_bitmask:
             mask = torch.empty(M * u.cout // 8, dtype=torch.uint8, device=self.device)
-        L.check(lib.creid_bn2d_apply_mask(L.ptr(x), L.ptr(ss), L.ptr(residual), 1 if relu else 0, M, u.cout, self.dt,
-                                          L.ptr(a), L.ptr(mask), st), "bn2d_apply")
+        if residual_ss is not None:
+            L.check(lib.creid_bn2d_apply_dual_mask(L.ptr(x), L.ptr(ss), L.ptr(residual), L.ptr(residual_ss), 1 if relu else 0, M,
+                                                   u.cout, self.dt, L.ptr(a), L.ptr(mask), st), "bn2d_apply_dual")
+        elif not (self._apply_dry & 1 and training and relu and residual is None):
+            L.check(lib.creid_bn2d_apply_mask(L.ptr(x), L.ptr(ss), L.ptr(residual), 1 if relu else 0, M, u.cout, self.dt,
+                                              L.ptr(a), L.ptr(mask), st), "bn2d_apply")
         if mask is not None:
             a._relu_mask = mask            # travels with the saved activation to _bn_bwd / _dgrad
         return a, mean, invstd
@@ -565,11 +582,17 @@ class BackboneEngine:
             a_in, hin, win = a, h, w
             x1, a1, m1, i1, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, training, True)
             x2, a2, m2, i2, h2, w2 = self._conv_bn(b["c2"], a1, B, h1, w1, training, True)
-            if b["ds"] is not None:
+            rss = None
+            if b["ds"] is not None and self.dual_apply:
+                # downsample branch: conv + statistics only; its normalisation rides in bn3's apply pass (one launch and
+                # the write + read of the normalised branch tensor less per downsample block)
+                xd, rss, md, idd, _, _ = self._conv_bn(b["ds"], a_in, B, hin, win, training, False, apply=False)
+                r = xd
+            elif b["ds"] is not None:
                 xd, r, md, idd, _, _ = self._conv_bn(b["ds"], a_in, B, hin, win, training, False)
             else:
                 xd, r, md, idd = None, a_in, None, None
-            x3, a3, m3, i3, h3, w3 = self._conv_bn(b["c3"], a2, B, h2, w2, training, True, residual=r)
+            x3, a3, m3, i3, h3, w3 = self._conv_bn(b["c3"], a2, B, h2, w2, training, True, residual=r, residual_ss=rss)
             if training:
                 sv["blocks"].append(dict(a_in=a_in, hin=hin, win=win, x1=x1, a1=a1, m1=m1, i1=i1, h1=h1, w1=w1,
                                          x2=x2, a2=a2, m2=m2, i2=i2, h2=h2, w2=w2, xd=xd, md=md, idd=idd,
@@ -591,7 +614,7 @@ class BackboneEngine:
             p.grad = torch.zeros_like(p)
         return p.grad
 
-    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False, part=None, mask=None):
+    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False, part=None, mask=None, dry=False):
         """BN backward; `part` = column-reduction partials already produced by a fused dgrad epilogue; `mask` = ReLU bits
         to apply to g (default: the ones that travel with `act`)."""
         lib, st = L.lib(), L.stream()
@@ -618,6 +641,8 @@ class BackboneEngine:
             ready = 2
         if mask is None and act is not None:
             mask = getattr(act, "_relu_mask", None)
+        if dry and ready == 2:
+            return dx, gm
         L.check(lib.creid_bn2d_bwd_mask(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mask), L.ptr(mean), L.ptr(invstd),
                                         L.ptr(bn.weight), M, u.cout, self.dt, L.ptr(part), ready, L.ptr(sums), L.ptr(dgam),
                                         L.ptr(dbet), L.ptr(dx), L.ptr(gm), st), "bn2d_bwd")
@@ -752,7 +777,7 @@ class BackboneEngine:
             wg(b["c3"], s["a2"], dx3, s["h2"], s["w2"], early=True)
             da2, p2 = self._dgrad(b["c3"], dx3, B, s["h2"], s["w2"], bnred=(s["x2"], s["a2"], s["m2"], s["i2"]))
             wg(b["c3"], s["a2"], dx3, s["h2"], s["w2"], fin=(b["c2"], p2, M3, s["m2"], s["i2"]))
-            dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3, part=p2)
+            dx2, _ = self._bn_bwd(b["c2"], s["x2"], da2, s["a2"], s["m2"], s["i2"], M3, part=p2, dry=bool(self._apply_dry & 2))
             ibn1 = b["c1"].ibn is not None
             hw1 = s["h1"] * s["w1"]
             ibn_fused = ibn1 and hw1 % 128 == 0          # per-image statistics: the 128-row tiles must not straddle images
@@ -765,7 +790,7 @@ class BackboneEngine:
             if ibn1:
                 dx1, _ = self._ibn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], B, hw1, part=p1)
             else:
-                dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1, part=p1)
+                dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], M1, part=p1, dry=bool(self._apply_dry & 2))
             nxt = None if prev is None else (prev[1]["x3"], prev[1]["a3"], prev[1]["m3"], prev[1]["i3"])
             # the c1 data gradient writes the block-input gradient (the widest tensor of the block) that the previous block's
             # bn3 apply reads next; when it is larger than the carrier threshold the weight gradient goes first (its operand

@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift,
                                                          const T* __restrict__ res, int relu, int64_t M, int C,
-                                                         T* __restrict__ y, uint8_t* __restrict__ mask_out) {
+                                                         T* __restrict__ y, uint8_t* __restrict__ mask_out,
+                                                         const float* __restrict__ res_scale_shift) {
+  // res_scale_shift (nullable): `res` is the RAW output of the block's downsample convolution and its BatchNorm
+  // (scale, shift) is applied here, r = res * s2 + t2 -- bn3 + downsample-BN + add + ReLU in one pass
+  // (resnet.py:80-85), the normalised downsample tensor is never written
   // mask_out (bf16 only, V = 8): bit k of byte i = (y[8 i + k] > 0) -- the ReLU mask the backward needs, at 1/16 of the
   // bytes of re-reading y there
   constexpr int V = Vec16<T>::N;
@@ -159,6 +163,18 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x
     sc[k] = a.x; sc[k + 1] = a.y; sc[k + 2] = a.z; sc[k + 3] = a.w;
     sh[k] = b.x; sh[k + 1] = b.y; sh[k + 2] = b.z; sh[k + 3] = b.w;
   }
+  float sc2[V], sh2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { sc2[k] = 1.f; sh2[k] = 0.f; }
+  if (res_scale_shift) {
+#pragma unroll
+    for (int k = 0; k < V; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(res_scale_shift + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(res_scale_shift + C + c0 + k);
+      sc2[k] = a.x; sc2[k + 1] = a.y; sc2[k + 2] = a.z; sc2[k + 3] = a.w;
+      sh2[k] = b.x; sh2[k + 1] = b.y; sh2[k + 2] = b.z; sh2[k + 3] = b.w;
+    }
+  }
   for (int64_t i = gtid; i < total; i += 2 * nthreads) {      // two independent 16-B streams in flight per thread
     const int64_t i2 = i + nthreads;
     const bool two = i2 < total;
@@ -168,6 +184,10 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x
     if (res) {
       Vec16<T>::load(res + i * V, rv);
       if (two) Vec16<T>::load(res + i2 * V, rw);
+      if (res_scale_shift) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) { rv[k] = fmaf(rv[k], sc2[k], sh2[k]); if (two) rw[k] = fmaf(rw[k], sc2[k], sh2[k]); }
+      }
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -797,10 +817,25 @@ int creid_bn2d_apply_mask(const void* x, const float* scale_shift, const void* r
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
                                 (const float*)x, scale_shift, (const float*)residual, relu, M, (int)C, (float*)y,
-                                (uint8_t*)nullptr),
+                                (uint8_t*)nullptr, (const float*)nullptr),
              hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, (const unsigned short*)residual, relu, M,
-                                (int)C, (unsigned short*)y, mask_out));
+                                (int)C, (unsigned short*)y, mask_out, (const float*)nullptr));
+  CREID_LAUNCH_RET();
+}
+
+int creid_bn2d_apply_dual_mask(const void* x, const float* scale_shift, const void* x_res, const float* scale_shift_res, int relu,
+                               int64_t M, int64_t C, int dtype, void* y, uint8_t* mask_out, void* stream) {
+  CREID_CHECK_ARG(x && scale_shift && x_res && scale_shift_res && y && M > 0 && C > 0 && C % 8 == 0);
+  if (mask_out && dtype == CREID_F32) return CREID_E_DTYPE;
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
+                                (const float*)x, scale_shift, (const float*)x_res, relu, M, (int)C, (float*)y,
+                                (uint8_t*)nullptr, scale_shift_res),
+             hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+                                (const unsigned short*)x, scale_shift, (const unsigned short*)x_res, relu, M,
+                                (int)C, (unsigned short*)y, mask_out, scale_shift_res));
   CREID_LAUNCH_RET();
 }
 

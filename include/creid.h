@@ -452,6 +452,11 @@ int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residu
  * re-reading y (modelling/backbones/resnet.py:71,75,85 -- the three ReLUs of a Bottleneck). */
 int creid_bn2d_apply_mask(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M,
                           int64_t C, int dtype, void* y, uint8_t* mask_out, void* stream);
+/* bn3 + downsample BatchNorm + add + ReLU of a block with a downsample branch (resnet.py:80-85) in ONE pass:
+ * y = act(x * scale + shift + (x_res * scale_res + shift_res)); x_res is the RAW downsample convolution output -- its
+ * normalised tensor is never written (fp32: bit-identical to creid_bn2d_apply twice; bf16: one rounding fewer). */
+int creid_bn2d_apply_dual_mask(const void* x, const float* scale_shift, const void* x_res, const float* scale_shift_res,
+                               int relu, int64_t M, int64_t C, int dtype, void* y, uint8_t* mask_out, void* stream);
 int64_t creid_bn2d_bwd_rows(int64_t M);
 int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* mean, const float* invstd,
                    const float* gamma, int64_t M, int64_t C, int dtype, float* partial, int partial_ready,

@@ -620,3 +620,29 @@ def test_bn_finalize_carried_by_wgrad_matches_own_launch(arch):
         for n in other:
             a, b = other[n].double(), grads[2][n].double()
             assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9, (n, float((a - b).norm()), float(b.norm()))
+
+
+@pytest.mark.parametrize("arch,H,W", [("resnet50", 64, 32), ("resnet50_ibn_a", 64, 64)])
+def test_dual_apply_equals_separate_downsample_bn_fp32(arch, H, W, monkeypatch):
+    """bn3 + downsample BatchNorm + add + ReLU in one pass (creid_bn2d_apply_dual_mask) against the two separate apply
+    launches: in fp32 every element sees the same fmaf / add / max, so the training-mode embeddings, the running statistics
+    and every gradient are bit-identical."""
+    from oracle import backbone_oracle as bo
+    from centroids_reid_amd import backbone as bb
+    x = bo.synthetic_images(4, H, W, seed=21).cuda()
+    coef = torch.from_numpy(np.random.default_rng(5).standard_normal((4, 2048)).astype(np.float32)).cuda()
+    out = []
+    for dual in ("1", "0"):
+        monkeypatch.setenv("CREID_DUAL_APPLY", dual)
+        net, eng, _ = _build(arch, torch.float32, seed=31)
+        assert eng.dual_apply == (dual == "1")
+        _, feat = eng.forward(x, training=True)
+        eng.backward(coef)
+        torch.cuda.synchronize()
+        out.append((feat.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                    net.layer2[0].downsample[1].running_var.clone()))
+    (f1, g1, rv1), (f0, g0, rv0) = out
+    assert torch.equal(f1, f0) and torch.equal(rv1, rv0)
+    assert set(g1) == set(g0)
+    for n in g0:
+        assert torch.equal(g1[n], g0[n]), n

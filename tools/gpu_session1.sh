@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU session 1: parity suite, full bench line, step anatomy
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q --maxfail=25 -x --deselect tests/test_stream_eval_gpu.py::test_streamed_configs3_shard_6250x200000 > gpurun_out/s1_pytest.log 2>&1
+python -m pytest tests -m gpu -q --maxfail=25 --durations=15 > gpurun_out/s1_pytest.log 2>&1
 echo "pytest rc $?" >> gpurun_out/s1_pytest.log
 tail -30 gpurun_out/s1_pytest.log
 python bench.py > gpurun_out/s1_bench.json 2> gpurun_out/s1_bench.err
