@@ -143,5 +143,22 @@ def test_camset_query_camera_ids_are_validated():
         rm.eval_func(idx, [0, 1], [0, 1, 2], [[64], [0]], [[0], [1], [2]], respect_camids=True)
     with pytest.raises(L.CreidError):
         rm.eval_func(idx, [0, 1], [0, 1, 2], [[-1], [0]], [[0], [1], [2]], respect_camids=True)
-    with pytest.raises(L.CreidError):
-        rm.R1_mAP(num_query=1, dist_func="cosine").compute_chunked(torch.zeros(4, 8, device="cuda"), [0, 0, 1, 1], [0, 1, 0, 1])
+
+
+def test_compute_chunked_supports_cosine_and_unaligned_feature_width():
+    """The reference's `_commpute_batches_double` (utils/reid_metric.py:93-110) works with either SOLVER.DISTANCE_FUNC; here the
+    chunked path streams euclidean / fp32 / D % 4 == 0 and walks query chunks for everything else -- same results as compute()."""
+    from centroids_reid_amd import reid_metric as rm
+    rng = np.random.default_rng(8)
+    nq, ng = 37, 400
+    pids = rng.integers(0, 25, nq + ng); cams = rng.integers(0, 3, nq + ng)
+    for D, dist in ((64, "cosine"), (30, "euclidean"), (30, "cosine")):
+        f = torch.from_numpy(rng.standard_normal((nq + ng, D)).astype(np.float32)).cuda()
+        ref = rm.R1_mAP(num_query=nq, dist_func=dist).compute(f, pids, cams)
+        got = rm.R1_mAP(num_query=nq, dist_func=dist).compute_chunked(f, pids, cams, query_chunk=16)
+        np.testing.assert_array_equal(got[0], ref[0])
+        assert abs(got[1] - ref[1]) < 1e-12
+        np.testing.assert_allclose(got[2], ref[2], atol=1e-12)
+        if dist == "euclidean":                         # streamed=True with D % 4 != 0 takes the materialised kernels
+            st = rm.R1_mAP(num_query=nq, streamed=True).compute(f, pids, cams)
+            assert abs(st[1] - ref[1]) < 1e-12
