@@ -637,8 +637,11 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
 //   barrier B_t  <=  producers: their pieces of tile t have landed (vmcnt);  consumers: done reading tile t-1
 //   after B_t    :   producers issue tile t+NS-1 into slot (t-1)%NS, consumers multiply tile t.
 // Tiling, swizzle, zero page and the epilogue maths are those of igemm_bf16_dma_kernel (512 threads copy out).
-template <int BN, int NS>
-__global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) void igemm_bf16_ws_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
+// BM = 128: the consumer waves hold 64 x BN/2 sub-tiles (two workgroups per CU where the ring allows it).  BM = 256: 128 x BN/2
+// sub-tiles -- 0.75 instead of 1 fragment read per MFMA and 1.125 instead of 1.5 KB of LDS traffic per MFMA; one workgroup
+// per CU (the ring is 48 KB per stage), so only for grids that still fill the chip with 256-row tiles.
+template <int BN, int NS, int BM = 128>
+__global__ __launch_bounds__(512, (NS * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1) void igemm_bf16_ws_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
                                                                 const unsigned short* __restrict__ wgt,
                                                                 unsigned short* __restrict__ out,
                                                                 const unsigned short* __restrict__ add_src,
@@ -646,14 +649,16 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
                                                                 BnRedArgs bnred, WRedJob wred) {
   constexpr int NT = 512;
   constexpr int BK = 64, TNW = BN / 64, NBI = BN / 32;
-  constexpr int CPT = 128 + 4;                                   // transposed staging: [BN columns][128 rows + 4]
-  constexpr int TILE_A = 128 * BK, TILE_B = BN * BK, STAGE = TILE_A + TILE_B;
+  constexpr int MI = BM / 64, NAI = BM / 32;                     // 32-row blocks per consumer wave; A-tile DMA instructions per producer wave
+  constexpr int CPT = BM + 4;                                    // transposed staging: [BN columns][BM rows + 4]
+  constexpr int TILE_A = BM * BK, TILE_B = BN * BK, STAGE = TILE_A + TILE_B;
   constexpr int CPR = BN / 8, NRG = NT / CPR;
   constexpr int RED_ELEMS = NRG * 2 * BN * 2;                    // fp32 reduction scratch, in 2-byte units
   constexpr int LDS0 = (NS * STAGE) > (BN * CPT) ? (NS * STAGE) : (BN * CPT);
   constexpr int LDS_ELEMS = LDS0 > RED_ELEMS ? LDS0 : RED_ELEMS;
-  constexpr int LPT = 4 + NBI;
+  constexpr int LPT = NAI + NBI;
   static_assert(NS >= 2 && (NS - 2) * LPT <= 63, "ring depth");
+  static_assert(BM == 128 || BM == 256, "row tile");
   __shared__ __attribute__((aligned(1024))) unsigned short smem[LDS_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // piggybacked job: the LAST wred.nblocks workgroups sum the split partials of the PREVIOUS weight-gradient launch
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   const int wm = cw >> 1, wn = cw & 1;
   const int bid = xcd_remap((int)blockIdx.x, ntile_wgs);
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-  const int row0 = tile_m * 128, col0 = tile_n * BN;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
   const int l31 = lane & 31, kh = lane >> 5;
   // parity-class row order (g.parity): the tile's class fixes which taps exist; r, s step by 2 from (r0, s0)
   const int msub = g.M >> 2;
@@ -690,14 +695,14 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     return (b * g.OH + 2 * a + py) * g.OW + 2 * c + px;
   };
 
-  f32x16 acc[2][TNW];
+  f32x16 acc[MI][TNW];
   if (producer) {
     const int span_mask = (1 << g.log2span) - 1;
     const int lr8 = lane >> 3, lcp = lane & 7;
-    int oy[4], ox[4], bpix[4], gch[4];
-    bool vm[4];
+    int oy[NAI], ox[NAI], bpix[NAI], gch[NAI];
+    bool vm[NAI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NAI; ++i) {
       const int r = (i * 4 + cw) * 8 + lr8, m = row0 + r;
       vm[i] = m < g.M;
       const int mm = vm[i] ? m : row0;
@@ -716,8 +721,8 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       wbase[i] = wgt + (int64_t)(col0 + r) * g.K + ((lcp ^ ((r >> 1) & 7)) << 3);
       wp[i] = wbase[i];
     }
-    const unsigned short* aptr[4];
-    int amul[4];
+    const unsigned short* aptr[NAI];
+    int amul[NAI];
     int cur_tap = -1, cur_r = r0, cur_s = s0 - tstep;
     const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_zero_page);
     typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
           for (int i = 0; i < NBI; ++i) wp[i] = wbase[i] + ((cur_r * g.kw + cur_s) << g.log2span);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NAI; ++i) {
           int iy, ix;
           const bool ok = vm[i] && igemm_src_pixel(g, oy[i], ox[i], cur_r, cur_s, iy, ix);
           aptr[i] = ok ? src + (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + gch[i] : zpage;
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       unsigned short* la = smem + buf * STAGE + cw * 512;
       unsigned short* lb = smem + buf * STAGE + TILE_A + cw * 512;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NAI; ++i) {
         __builtin_amdgcn_global_load_lds((gptr_t)aptr[i], (lptr_t)(la + i * 2048), 16, 0, 0);
         aptr[i] += amul[i] ? BK : 0;                             // running pointers (see igemm_bf16_dma_kernel)
       }
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < TNW; ++j)
 #pragma unroll
@@ -782,12 +787,12 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       buf = (buf + 1 == NS) ? 0 : buf + 1;
       // fragment reads run one 16-wide k slice ahead of the MFMAs (register double buffer): the LDS latency of
       // slice kk+1 hides behind the MFMAs of slice kk instead of being exposed four times per k-tile
-      s16x8 a[2][2], b[2][TNW];
+      s16x8 a[2][MI], b[2][TNW];
       auto load_frags = [&](int kk, int sl) {
         const int ch = 2 * kk + kh;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int r = wm * 64 + i * 32 + l31;
+        for (int i = 0; i < MI; ++i) {
+          const int r = wm * (BM / 2) + i * 32 + l31;
           a[sl][i] = *reinterpret_cast<const s16x8*>(&As[r * BK + ((ch ^ ((r >> 1) & 7)) << 3)]);
         }
 #pragma unroll
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       };
       auto mma = [&](int sl) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < TNW; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[sl][i]),
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   // accumulators are staged through LDS (they used to start only after the C tile had been stored)
   // copy-out map (see below): a 16-lane group owns 4 rows x 4 column octets; lane = 16*g4 + 4*q4 + t4 stores row t4 of the
   // row quad, octet g4*4 + q4 of the wave's 16-octet strip
-  constexpr int NPRE = (128 * (BN / 8)) / 512;
+  constexpr int NPRE = BM == 128 ? (128 * (BN / 8)) / 512 : 1;   // (the fused BN reduction exists for 128-row tiles only)
   const int t4 = lane & 3, q4 = (lane >> 2) & 3, g4 = lane >> 4;
   auto unit_of = [&](int i, int& rl, int& ch) {
     const int Q = (wave + 8 * i) * 16 + g4 * 4 + q4;
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   };
   uint4 pre_x[NPRE], pre_a[NPRE];
   unsigned pre_m[NPRE];                                          // ReLU mask bits of the chunk (bnred.mask) instead of pre_a
-  if (bnred.x && bnred.prefetch) {
+  if (BM == 128 && bnred.x && bnred.prefetch) {
     const unsigned short* bx0 = reinterpret_cast<const unsigned short*>(bnred.x);
     const unsigned short* ba0 = reinterpret_cast<const unsigned short*>(bnred.act);
 #pragma unroll
@@ -863,10 +868,10 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       const int cl = wn * (BN / 2) + j * 32 + l31;
       const float sc = g.epi_scale[col0 + cl], sh = g.epi_shift[col0 + cl];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int rl = wm * 64 + i * 32 + 8 * q + 4 * kh;
+          const int rl = wm * (BM / 2) + i * 32 + 8 * q + 4 * kh;
           float v0 = fmaf(acc[i][j][4 * q], sc, sh), v1 = fmaf(acc[i][j][4 * q + 1], sc, sh);
           float v2 = fmaf(acc[i][j][4 * q + 2], sc, sh), v3 = fmaf(acc[i][j][4 * q + 3], sc, sh);
           if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
@@ -881,10 +886,10 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       const int cl = wn * (BN / 2) + j * 32 + l31;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int rl = wm * 64 + i * 32 + 8 * q + 4 * kh;
+          const int rl = wm * (BM / 2) + i * 32 + 8 * q + 4 * kh;
           const float v0 = acc[i][j][4 * q], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
           s1 += v0; s2 = fmaf(v0, v0, s2);
           s1 += v1; s2 = fmaf(v1, v1, s2);
@@ -901,7 +906,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
   // transposing reads: in a 16-lane group lane s supplies the 8-byte unit (column 8 * octet(s & 3) + (s >> 2), the row quad)
   // and lane l receives (row l & 3, columns 8 * octet(l >> 2) + 0..3); a second read 4 columns on completes the 16-byte chunk.
   // Every lane takes part (the data crosses lanes), only the global store is predicated.
-  constexpr int NIT = (128 * CPR) / NT;
+  constexpr int NIT = (BM * CPR) / NT;
   static_assert(16 % CPR == 0, "copy-out map: 8 or 16 column octets per tile row");
   u32x2 trlo[NIT], trhi[NIT];
   {
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
                    : "=&v"(trlo[i]), "=&v"(trhi[i]) : "v"(addr), "i"(4 * CPT * 2) : "memory");
     }
   }
-  const unsigned short* bx = reinterpret_cast<const unsigned short*>(bnred.x);
+  const unsigned short* bx = BM == 128 ? reinterpret_cast<const unsigned short*>(bnred.x) : nullptr;
   const unsigned short* bact = reinterpret_cast<const unsigned short*>(bnred.act);
   float rs1[8], rs2[8], rmu[8], ris[8];
   if (bx) {
@@ -969,8 +974,8 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       }
       *reinterpret_cast<uint4*>(out + off) = v;
       if (bx) {
-        uint4 xv = pre_x[i], av = pre_a[i];
-        unsigned mb = pre_m[i];
+        uint4 xv = pre_x[i % NPRE], av = pre_a[i % NPRE];        // (NPRE == NIT whenever bx can be non-null)
+        unsigned mb = pre_m[i % NPRE];
         if (!bnred.prefetch) {
           xv = *reinterpret_cast<const uint4*>(bx + off);
           av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
@@ -1020,7 +1025,12 @@ __global__ __launch_bounds__(512, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += NT) {
       const int which = i / BN, cl = i - which * BN;
-      bn_part[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl];
+      if constexpr (BM == 128) {
+        bn_part[((int64_t)tile_m * 2 + which) * g.N + col0 + cl] = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl];
+      } else {                                                   // partial rows stay per 128 rows: one per consumer-wave row half
+        bn_part[((int64_t)(tile_m * 2 + 0) * 2 + which) * g.N + col0 + cl] = red[(0 * 2 + which) * BN + cl];
+        if (row0 + 128 < g.M) bn_part[((int64_t)(tile_m * 2 + 1) * 2 + which) * g.N + col0 + cl] = red[(1 * 2 + which) * BN + cl];
+      }
     }
   }
 }
@@ -1178,10 +1188,10 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
   // measured plan for this GEMM shape (tune.hpp): N tile and ring depth of the producer/consumer kernel; the 4th key slot is
   // transposed | stride << 1 (a stride-2 and a stride-1 3x3 layer can share M, N, K but not their gather pattern)
   TunePlan tp;
-  int tuned_stages = 0, tuned_dma = 0, tuned_stream = 0;
+  int tuned_stages = 0, tuned_dma = 0, tuned_stream = 0, tuned_bm256 = 0;
   if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, g.transposed | (g.stride << 1), tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
-    bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2;
+    bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2; tuned_bm256 = tp.p2 == 3;
   }
   // persistent streaming kernel for the small-K 1x1 stride-1 forward convolutions (conv_stream.hip): plan kind 2, or
   // CREID_STREAM1X1=1 for every GEMM it covers
@@ -1218,9 +1228,30 @@ static int launch_igemm(const IGemmGeom& g, const void* src, const void* wgt, vo
         gp.parity = 1;
       int ws_stages = use_ws == 2 ? ws_stages_env() : ((bn == 64 && g.K >= ws_min_k) ? 3 : 2);
       if (tuned_stages && use_ws != 2) ws_stages = tuned_stages;
+      const dim3 block_ws(512);
+      // 256-row tiles (128 x 64 consumer sub-tiles, one workgroup per CU): plan kind 3, or CREID_IGEMM_BM=256 wherever the grid
+      // still has >= CREID_IGEMM_BM256_MIN_WGS (default 256) workgroups; not with the fused BN reduction / parity-class rows
+      {
+        const char* be = getenv("CREID_IGEMM_BM");                 // read per call: tests and the tuner toggle it
+        const int force_bm = be ? atoi(be) : 0;
+        static const int bm256_min = [] { const char* e = getenv("CREID_IGEMM_BM256_MIN_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+        const bool can256 = g.N % 128 == 0 && !bnred.x && !gp.parity;
+        const int64_t wgs256 = (int64_t)((g.M + 255) / 256) * (g.N / 128);
+        if (can256 && force_bm != 128 && (tuned_bm256 || (force_bm == 256 && wgs256 >= bm256_min))) {
+          const int st256 = (ws_stages >= 3 || g.K >= 256) ? 3 : 2;
+          const dim3 grid256((unsigned)(wgs256 + (wred.ws ? wred.nblocks : 0)));
+          const int tn256 = g.N / 128;
+          if (st256 == 3)
+            hipLaunchKernelGGL((igemm_bf16_ws_kernel<128, 3, 256>), grid256, block_ws, 0, s, gp, (const unsigned short*)src,
+                               (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tn256, bnred, wred);
+          else
+            hipLaunchKernelGGL((igemm_bf16_ws_kernel<128, 2, 256>), grid256, block_ws, 0, s, gp, (const unsigned short*)src,
+                               (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tn256, bnred, wred);
+          return (int)hipGetLastError();
+        }
+      }
       // 4 x 32 KB at BN = 128 is one workgroup per CU (the C staging reuses the ring): only on request of a measured plan
       if (ws_stages == 4 && bn == 128 && !(tuned_stages == 4 && use_ws != 2)) ws_stages = 3;
-      const dim3 block_ws(512);
       const dim3 grid_ws((unsigned)(tiles_m * tiles_n + (wred.ws ? wred.nblocks : 0)));
 #define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
   hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid_ws, block_ws, 0, s, gp, (const unsigned short*)src,       \

@@ -41,6 +41,8 @@ def test_hot_kernels_keep_their_occupancy_budget():
             assert int(kv.get("vgpr_spill", 0)) == 0, (name, kv)
             seen += 1
         if base == "igemm_bf16_ws_kernel":
-            # 512 threads = 2 waves per SIMD per workgroup; two workgroups per CU need 4 waves per SIMD = 128 VGPRs
-            assert int(kv["vgprs"]) + int(kv.get("agprs", 0)) <= 128, (name, kv)
+            # 512 threads = 2 waves per SIMD per workgroup; two workgroups per CU need 4 waves per SIMD = 128 VGPRs.
+            # The 256-row variant (third template argument) runs one workgroup per CU: 256 registers, no spills.
+            limit = 256 if (len(args) == 3 and args[2] == 256) else 128
+            assert int(kv["vgprs"]) + int(kv.get("agprs", 0)) <= limit, (name, kv)
     assert seen >= 6
