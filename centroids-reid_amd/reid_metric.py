@@ -58,6 +58,15 @@ def get_cosine(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-12) -> torch.Te
     return torch.abs(1 - cos).clamp(min=eps)
 
 
+def _pad_width(feats: torch.Tensor) -> torch.Tensor:
+    """The kernels load 16-byte k-chunks (D % 4 == 0).  Zero columns change neither a norm nor a dot product, so any other
+    width is padded up -- results identical, no kernel special case."""
+    D = feats.shape[1]
+    if D % 4 == 0:
+        return feats
+    return torch.nn.functional.pad(feats, (0, 4 - D % 4)).contiguous()
+
+
 def get_dist_func(func_name="euclidean"):
     if func_name == "cosine":
         return get_cosine
@@ -341,11 +350,10 @@ class R1_mAP:
     def compute(self, feats, pids, camids, respect_camids=False):
         if not isinstance(feats, torch.Tensor) or not feats.is_cuda:
             raise L.CreidError("R1_mAP.compute needs device features (no CPU fallback)")
-        feats = feats.float().contiguous()
+        feats = _pad_width(feats.float().contiguous())
         nq = self.num_query
         if (self.streamed and self.dist_name == "euclidean" and not respect_camids
-                and self.compute_dtype == torch.float32 and feats.shape[1] % 4 == 0):
-            # (the streamed contraction loads 16-byte k-chunks: D % 4 != 0 takes the materialised kernels below)
+                and self.compute_dtype == torch.float32):
             return self._compute_streamed(feats, pids, camids)
         if self.dist_name == "euclidean":
             if self.feat_norm:
@@ -409,9 +417,9 @@ class R1_mAP:
             raise L.CreidError("R1_mAP.compute_chunked needs device features (no CPU fallback)")
         from .parallel import merge_eval_results
         euclid = self.dist_name == "euclidean"
-        if euclid and self.compute_dtype == torch.float32 and feats.shape[1] % 4 == 0:
-            return self._compute_streamed(feats.float().contiguous(), pids, camids)
-        feats = feats.float().contiguous()
+        feats = _pad_width(feats.float().contiguous())
+        if euclid and self.compute_dtype == torch.float32:
+            return self._compute_streamed(feats, pids, camids)
         nq = self.num_query
         if not euclid:
             # SOLVER.DISTANCE_FUNC = cosine (utils/reid_metric.py:51-59,93-110 works with either function): the same

@@ -646,3 +646,50 @@ def test_dual_apply_equals_separate_downsample_bn_fp32(arch, H, W, monkeypatch):
     assert set(g1) == set(g0)
     for n in g0:
         assert torch.equal(g1[n], g0[n]), n
+
+
+def test_whole_network_gradient_error_is_at_the_fp32_noise_floor():
+    """Why whole-network gradients are compared in norm and not element-wise, SHOWN rather than asserted: the same ResNet50
+    training-mode forward / backward evaluated three ways -- torch-CPU fp64 (the yardstick), torch-CPU fp32 (a second valid
+    fp32 evaluation: other summation orders, hence a few ReLU masks and BatchNorm statistics that fall the other way) and the
+    HIP fp32 parity mode.  The HIP path must be no further from the fp64 gradients than a small multiple of what the
+    torch fp32 evaluation is: its error is the fp32 noise floor of this network, not a defect of the backward kernels
+    (which the layer-level tests above pin against fp64 within 1e-4)."""
+    from oracle import backbone_oracle as bo
+    torch.set_num_threads(32)
+    B, H, W = 8, 128, 64
+    x = bo.synthetic_images(B, H, W, seed=41)
+    coef = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 2048)).astype(np.float32))
+    net, eng, sd = _build("resnet50", torch.float32, seed=4321)
+
+    def oracle_grads(dtype):
+        params = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()
+                  if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+        full = {**{k: (v.to(dtype) if v.dtype.is_floating_point else v).clone() for k, v in sd.items()}, **params}
+        _, feat = bo.backbone_forward(x.to(dtype), full, "resnet50", 1, training=True)
+        (feat * coef.to(dtype)).sum().backward()
+        return {k: p.grad.double() for k, p in params.items()}, feat.detach().double()
+
+    g64, f64 = oracle_grads(torch.float64)
+    g32, f32 = oracle_grads(torch.float32)
+    _, feat = eng.forward(x.cuda(), training=True)
+    eng.backward(coef.cuda())
+    gh = {n: p.grad.detach().double().cpu() for n, p in net.named_parameters() if p.grad is not None}
+    names = [n for n in g64 if n in gh and n.endswith("weight") and g64[n].dim() == 4]       # every convolution weight
+    assert len(names) == 53
+
+    def rel(g):
+        num = sum(float((g[n] - g64[n]).pow(2).sum()) for n in names)
+        den = sum(float(g64[n].pow(2).sum()) for n in names)
+        return (num / den) ** 0.5
+    err_hip, err_t32 = rel(gh), rel(g32)
+    ferr_hip = float((feat.double().cpu() - f64).abs().max()); ferr_t32 = float((f32 - f64).abs().max())
+    print(f"conv-weight gradients vs fp64: HIP fp32 {err_hip:.3e}, torch-CPU fp32 {err_t32:.3e}; "
+          f"embeddings max-abs vs fp64: HIP {ferr_hip:.2e}, torch fp32 {ferr_t32:.2e}")
+    assert ferr_hip < 1e-4
+    assert err_hip < 5 * err_t32 + 2e-4, (err_hip, err_t32)
+    # per tensor: nowhere an outlier that the aggregate hides (an isolated bad layer would stand out by orders of magnitude)
+    worst = max((float((gh[n] - g64[n]).norm() / (g64[n].norm() + 1e-30)), n) for n in names)
+    worst_t = max((float((g32[n] - g64[n]).norm() / (g64[n].norm() + 1e-30)), n) for n in names)
+    print("worst tensor: HIP", worst, " torch fp32", worst_t)
+    assert worst[0] < 10 * worst_t[0] + 1e-3, (worst, worst_t)

@@ -25,6 +25,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64); ap.add_argument("--h", type=int, default=256); ap.add_argument("--w", type=int, default=128)
 ap.add_argument("--out", default=os.path.join(ROOT, "centroids-reid_amd", "tuned_plans.json"))
 ap.add_argument("--merge", default=None, help="existing plan file whose entries (other shapes) are kept")
+ap.add_argument("--fwd-only", action="store_true",
+                help="eval-mode shapes (embedding batch sizes): forward with the folded BatchNorm epilogue only, incl. the "
+                     "256-row tile variant (plan kind 3)")
 args = ap.parse_args()
 lib = L.lib()
 B = args.batch
@@ -52,6 +55,38 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
     M, K = B * oh * ow, k * k * cin
     dw = torch.zeros((cout, cin, k, k), device="cuda")
     name = f"{cin}->{cout} k{k} s{s} {h}x{w}"
+
+    if args.fwd_only:
+        ss = torch.stack([torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.1]).contiguous()
+        res_t = torch.randn_like(y) if (k == 1 and cout == 4 * cin) else None          # conv3: the block's residual rides in
+        fn = lambda: ly.conv2d_fwd_affine(x, krsc, s, pad, ss, res_t, True)
+        key = (M, cout, K, s << 1)
+        lib.creid_tune_clear()
+        tuned_keys.add((1, tuple(key)))
+        base = t_us(fn)
+        best = (base, None)
+        for bn in (64, 128):
+            if cout % bn:
+                continue
+            for st in (2, 3, 4):
+                if bn == 128 and st == 4:
+                    continue
+                for kind in (0, 1, 3):
+                    if kind == 3 and (bn != 128 or st == 4 or (M + 255) // 256 * (cout // 128) < 256):
+                        continue
+                    if kind == 1 and st > 3:
+                        continue
+                    lib.creid_tune_set(1, *key, bn, st, kind)
+                    sc = t_us(fn)
+                    if sc < best[0]:
+                        best = (sc, (bn, st, kind))
+        lib.creid_tune_clear()
+        if best[1] is not None and best[0] < 0.97 * base:
+            plans.append({"kind": 1, "key": list(key), "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2),
+                          "layer": f"fwd-eval {name} B={B}"})
+        log.append(f"fwd-eval {name:28s} x{cnt} rule {base:6.1f}  best {best[0]:6.1f} {best[1]}")
+        print(log[-1], flush=True)
+        continue
 
     # ---------------- weight gradient
     def wgrad_score():
@@ -145,8 +180,8 @@ if args.merge and os.path.exists(args.merge):
     # entries of shapes measured in this run are replaced (or dropped, when the built-in rule now wins); others are kept
     plans = [e for e in old if (e["kind"], tuple(e["key"])) not in tuned_keys] + plans
 out = {"_comment": "measured launch plans (tools/tune_plans.py) for the ResNet50 layer mix on one MI355X (B=64 256x128 = BASELINE "
-                   "configs[1]; B=56 320x320 = configs[3]); kind 0 = weight gradient (M, out_c, K) -> (tile rows, tile cols, splits), "
-                   "kind 1 = forward / data gradient (M, N, K, transposed) -> (N tile, ring depth).  Shapes without an entry use the "
+                   "configs[1]; B=56 320x320 = configs[3] training; B=128 256x128 and B=256 320x320 forward = the eval-mode embedding batches); kind 0 = weight gradient (M, out_c, K) -> (tile rows, tile cols, splits), "
+                   "kind 1 = forward / data gradient (M, N, K, transposed) -> (N tile, ring depth, kernel: 0 producer/consumer, 1 four-wave DMA, 2 persistent 1x1, 3 256-row tiles).  Shapes without an entry use the "
                    "built-in rules.",
        "device": torch.cuda.get_device_name(0), "plans": plans}
 json.dump(out, open(args.out, "w"), indent=1)
