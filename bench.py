@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest committed counter passes first
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_TFLOPS = 157.3        # f32-input MFMA dense peak
 MFMA_BF16_TFLOPS = 2500.0      # bf16 MFMA dense peak
@@ -104,10 +105,10 @@ def eval_inputs(nq, ng, D, rank, world):
 
 
 def pmc_traffic(key):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, falling back
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r0x_pmc_traffic.json, falling back
     to the round-1 file: FETCH_SIZE + WRITE_SIZE collected in separate counter-only runs); None if absent."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in PMC_FILES:
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 e = json.load(f)[key]
@@ -118,12 +119,16 @@ def pmc_traffic(key):
 
 
 def pmc_field(key, field):
-    """A per-kernel field of the committed counter passes (profiles/r02_pmc_traffic.json), e.g. "mfma_busy"."""
+    """A per-kernel field of the committed counter passes (profiles/r0x_pmc_traffic.json), e.g. "mfma_busy"."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")) as f:
-            return json.load(f)[key][field]
+        for name in PMC_FILES:
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    return json.load(f)[key][field]
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
 
 
 def run_eval(args, rank, world, steps=None, warmup=None, shape=None, extras=True):
@@ -228,6 +233,7 @@ def run_eval(args, rank, world, steps=None, warmup=None, shape=None, extras=True
                            "bound": "mfma", "achieved": flops / (t_count * 1e-3) / 1e12, "peak": MFMA_F32_TFLOPS,
                            "unit": "TFLOP/s", "frac": flops / (t_count * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
                            "traffic": pmc_traffic("sqdist_count_f32_kernel"), "ms": t_count,
+                           "traffic_source": "profiles/r0x_pmc_traffic.json: committed rocprofv3 --pmc passes, NOT measured in this run",
                            "mfma_busy_by_counter": pmc_field("sqdist_count_f32_kernel", "mfma_busy")}
         res["materialised"] = {
             "value": float(nq) * ng * world * steps / dt_m, "unit": "pairs/s", "ms_per_step": dt_m / steps * 1e3,

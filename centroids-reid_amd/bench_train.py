@@ -12,6 +12,7 @@ from .config import get_cfg_defaults
 from .train_ctl_model import CTLModel
 from . import parallel
 
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest committed counter passes first
 R50_FWD_BWD_GFLOP_PER_IMG = 24.32     # BASELINE.md section 3 (3 x forward conv FLOPs)
 MFMA_BF16_TFLOPS = 2500.0
 
@@ -273,19 +274,23 @@ def pmc_field(key, field):
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
-        with open(os.path.join(root, "profiles", "r02_pmc_traffic.json")) as f:
-            return json.load(f)[key][field]
+        for name in PMC_FILES:
+            path = os.path.join(root, "profiles", name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    return json.load(f)[key][field]
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
 
 
 def pmc_traffic(key):
     """Average HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc passes
-    (profiles/r02_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE -- FETCH_SIZE reads 0.5x on 16-byte streaming loads, see
+    (profiles/r0x_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE -- FETCH_SIZE reads 0.5x on 16-byte streaming loads, see
     the calibration block of that file -- collected in their own counter-only runs); None if absent."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in PMC_FILES:
         try:
             with open(os.path.join(root, "profiles", name)) as f:
                 e = json.load(f)[key]

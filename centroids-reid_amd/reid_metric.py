@@ -402,11 +402,18 @@ class R1_mAP:
             valid.index_copy_(0, rows, v2); ap.index_copy_(0, rows, a2); first.index_copy_(0, rows, f2)
         max_rank = min(self.max_rank, fg.shape[0])
         cmc, mAP, topk, _ = eval_reduce_device(valid, ap, first, max_rank)
-        valid_h = valid.cpu().numpy() == 1
+        # ONE read-back for everything the host needs (five separate .cpu() calls are five synchronisations):
+        # [cmc (max_rank) | mAP | topk (5) | valid (m) | ap (m)] as float64 (exact for the f32 / u8 members)
+        pack = torch.cat([cmc.double(), mAP, topk, valid.double(), ap]).cpu().numpy()
+        cmc_h = pack[:max_rank].astype(np.float32)
+        mAP_h = float(pack[max_rank])
+        topk_h = pack[max_rank + 1:max_rank + 6].copy()
+        valid_h = pack[max_rank + 6:max_rank + 6 + nq] == 1
+        ap_h = pack[max_rank + 6 + nq:]
         vi = np.nonzero(valid_h)[0]
-        single = np.stack([vi.astype(np.float64), pids[:nq][vi].astype(np.float64), ap.cpu().numpy()[vi]], axis=1)
+        single = np.stack([vi.astype(np.float64), pids[:nq][vi].astype(np.float64), ap_h[vi]], axis=1)
         self.last = dict(valid=valid, ap=ap, first=first, single_performance=single, plan=plan)
-        return cmc.cpu().numpy(), float(mAP.item()), topk.cpu().numpy()
+        return cmc_h, mAP_h, topk_h
 
     def compute_chunked(self, feats, pids, camids, query_chunk=4096):
         """Galleries whose m x n matrix must not be materialised (the reference's `_commpute_batches_double` path,

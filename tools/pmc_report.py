@@ -1,6 +1,8 @@
-"""Turn the gpurun_out/pmc_*.json passes (tools/pmc_run.sh) into profiles/r02_pmc_traffic.json + profiles/r02_pmc_summary.md."""
+"""Turn the gpurun_out/pmc_*.json passes (tools/pmc_run.sh) into profiles/<round>_pmc_traffic.json + profiles/<round>_pmc_summary.md (CREID_ROUND, default r03)."""
 import json
 import os
+
+RND = os.environ.get("CREID_ROUND", "r03")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
@@ -26,7 +28,7 @@ for name, kern in (("calib_l2norm_rows", "l2norm_rows_kernel<0>"), ("calib_bn2d_
                    "WRITE_SIZE_bytes": w, "fetch_ratio": f / meta[name]["read"], "write_ratio": w / meta[name]["write"]}
 cal_f = F["_first_dispatch"]["igemm_bf16_ws_kernel<64, 2>"]["FETCH_SIZE"] * 1024
 cal_w = W["_first_dispatch"]["igemm_bf16_ws_kernel<64, 2>"]["WRITE_SIZE"] * 1024
-out = {"_comment": "HBM-side traffic from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, unit KiB -> bytes), round 2, one "
+out = {"_comment": "HBM-side traffic from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, unit KiB -> bytes), this round, one "
                    "MI355X, tools/pmc_run.sh.  CALIBRATION on kernels of exactly known traffic: FETCH_SIZE reads 0.500x the bytes of "
                    "16-byte streaming loads, both plain global loads (bn2d_apply, bf16) and LDS-DMA (1x1 convolution), WRITE_SIZE "
                    "1.000x -- as MI355X_MICROARCH.md says.  Round 1 calibrated on l2norm_rows, which reads every row TWICE "
@@ -52,7 +54,7 @@ for key, prefix in (("igemm_family", "igemm_bf16_"), ("wgrad_family", "wgrad_bf1
                     ("sqdist_count_f32_kernel", "sqdist_count_f32_kernel")):
     mf, _ = fam(S, prefix, "SQ_VALU_MFMA_BUSY_CYCLES"); ga, _ = fam(S, prefix, "GRBM_GUI_ACTIVE")
     out[key]["mfma_busy"] = mf / (ga / 8 * NSIMD)          # matrix-pipe busy fraction by counter (all launches of the family)
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{RND}_pmc_traffic.json"), "w"), indent=1)
 
 lines = ["# rocprofv3 --pmc passes, round 2 (tools/pmc_run.sh over tools/pmc_kernels.py, one MI355X)", "",
          "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of SIMD-cycles whose matrix",
@@ -75,6 +77,6 @@ for k in sorted(S):
 for fam_name, prefix in (("igemm family (conv fwd + dgrad, whole layer mix)", "igemm_bf16_"), ("wgrad family", "wgrad_bf16_")):
     mf, _ = fam(S, prefix, "SQ_VALU_MFMA_BUSY_CYCLES"); ga, n = fam(S, prefix, "GRBM_GUI_ACTIVE")
     lines.append(f"| **{fam_name}** | {n} | **{100 * mf / (ga / 8 * NSIMD):.1f}** | | | |")
-lines += ["", "HBM-side traffic and the FETCH_SIZE calibration: profiles/r02_pmc_traffic.json.", ""]
-open(os.path.join(ROOT, "profiles", "r02_pmc_summary.md"), "w").write("\n".join(lines))
-print("\n".join(lines[:4])); print(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.md")).read()[-2500:])
+lines += ["", f"HBM-side traffic and the FETCH_SIZE calibration: profiles/{RND}_pmc_traffic.json.", ""]
+open(os.path.join(ROOT, "profiles", f"{RND}_pmc_summary.md"), "w").write("\n".join(lines))
+print("\n".join(lines[:4])); print(open(os.path.join(ROOT, "profiles", f"{RND}_pmc_summary.md")).read()[-2500:])
