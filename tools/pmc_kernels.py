@@ -30,7 +30,7 @@ xc = torch.randn((B * 8, 64, 64, 64), device="cuda").to(torch.bfloat16)         
 wt = torch.randn((64, 64, 1, 1), device="cuda") / 8
 krsc, crsk = ly.weight_prep(wt, torch.bfloat16)
 yc = ly.conv2d_fwd(xc, krsc, 1, 0)
-meta["calib_igemm_1x1_stream"] = {"read": xc.numel() * 2, "write": yc.numel() * 2, "kernel": "igemm_bf16_ws_kernel<64, 2>",
+meta["calib_igemm_1x1_stream"] = {"read": xc.numel() * 2, "write": yc.numel() * 2, "kernel": "igemm_bf16_ws_kernel<64, 2, 128>",
                                   "note": "the ONLY launch of this template instance before the family below starts; dispatch order"}
 del xc, yc
 torch.cuda.synchronize()
