@@ -135,7 +135,7 @@ def parse_step_trace(db_path):
     return out
 
 
-def insitu_trace(timeout_s=420):
+def insitu_trace(timeout_s=180):
     """IN-SITU kernel durations: re-runs this benchmark's captured training step and embedding forward for a few replays
     under `rocprofv3 --kernel-trace` in a child process and reads the per-launch durations back (parse_step_trace).  The
     per-family times are those of the launches inside the replayed step -- cold / warm operands, piggy-backed reductions
