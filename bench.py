@@ -75,7 +75,7 @@ def time_kernel(fn, iters, graph=True):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             fn()                                   # allocations settle before capture
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):   # see bench_train.CAPTURE_MODE
                 for _ in range(iters):
                     fn()
         torch.cuda.current_stream().wait_stream(side)
@@ -333,11 +333,17 @@ def cpu_baseline_train(P, K, H, W):
 
 # ----------------------------------------------------------------------------- main
 _REAL_STDOUT = sys.stdout
+_REAL_FD = 1
 
 
 def main():
     # the contract is ONE JSON line on stdout: library chatter (optimizer grouping notes, metric banners that mirror
-    # the reference's prints) goes to stderr
+    # the reference's prints) goes to stderr -- at the FILE-DESCRIPTOR level too: RCCL prints its version banner through C
+    # stdio, buffered until exit, i.e. AFTER the result line of a data-parallel run
+    global _REAL_FD
+    sys.stdout.flush()
+    _REAL_FD = os.dup(1)
+    os.dup2(2, 1)
     sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,8 +392,8 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": out.pop("dtype"), "data": "synthetic", **out}
-        print(json.dumps(line), file=_REAL_STDOUT, flush=True)
-    if world > 1:
+        os.write(_REAL_FD, (json.dumps(line) + "\n").encode())
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -13,6 +13,11 @@ from .train_ctl_model import CTLModel
 from . import parallel
 
 PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest committed counter passes first
+# hipGraph captures run in THREAD-LOCAL capture mode: in the default (global) mode ANY thread's event query is illegal while a
+# capture is open, and the NCCL/RCCL watchdog thread polls the events of earlier collectives (the eager warm-up steps, the
+# weight broadcast) -- found by `CREID_FORCE_DIST=1 python bench.py` on one GPU: "operation not permitted when stream is
+# capturing" in ProcessGroupNCCL's watchdog, process aborted.  Every data-parallel run would have died at its first capture.
+CAPTURE_MODE = "thread_local"
 R50_FWD_BWD_GFLOP_PER_IMG = 24.32     # BASELINE.md section 3 (3 x forward conv FLOPs)
 MFMA_BF16_TFLOPS = 2500.0
 
@@ -152,7 +157,7 @@ def insitu_trace(timeout_s=180):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tmp = tempfile.mkdtemp(prefix="creid_insitu_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", CREID_BENCH_NO_EVAL="1", CREID_BENCH_NO_INSITU="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CREID_FORCE_DIST"):
         env.pop(k, None)
     cmd = [exe, "--kernel-trace", "--stats", "-d", tmp, "-o", "insitu", "--", sys.executable, os.path.join(root, "bench.py"),
            "--inner-trace"]
@@ -193,7 +198,7 @@ class EmbedBench:
                 self._fwd()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             self.emb = self._fwd()
 
     def _fwd(self):
@@ -376,8 +381,8 @@ class DDPStepper:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for s in range(2):                              # eager warm-up (allocations, lazy inits), with real syncs
-                self._eager_step(s)
+            for s in range(3):                              # eager warm-up (allocations, lazy inits), with real syncs; three
+                self._eager_step(s)                         # steps like the single-graph path: same step count, comparable losses
             torch.cuda.synchronize()
             segs = [torch.cuda.CUDAGraph()]
             split_at = []
@@ -388,18 +393,18 @@ class DDPStepper:
                     split_at.append(k)
                     g = torch.cuda.CUDAGraph()
                     segs.append(g)
-                    g.capture_begin(pool=segs[0].pool())
+                    g.capture_begin(pool=segs[0].pool(), capture_error_mode=CAPTURE_MODE)
             eng.on_group_done = cap_hook
             open_graph = None
             try:
-                segs[0].capture_begin()
+                segs[0].capture_begin(capture_error_mode=CAPTURE_MODE)
                 open_graph = segs
                 self.out = model.forward_backward(self.static, 0)
                 segs[-1].capture_end()
                 open_graph = None
                 eng.on_group_done = None
                 self.gopt = torch.cuda.CUDAGraph()
-                self.gopt.capture_begin(pool=segs[0].pool())
+                self.gopt.capture_begin(pool=segs[0].pool(), capture_error_mode=CAPTURE_MODE)
                 open_graph = [self.gopt]
                 model.apply_optimizers()
                 self.gopt.capture_end()
@@ -466,7 +471,7 @@ def fake_mix_step(model, batches, P, K, steps=30, warmup=5):
             model.training_step(static, s)
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
         out = model.training_step(static, 0)
 
     def one(s):
@@ -499,7 +504,7 @@ def fp32_mode_step(P, K, H, W, steps=6, warmup=2):
             model.training_step(static, s)
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
         out = model.training_step(static, 0)
     for _ in range(warmup):
         graph.replay()
@@ -522,6 +527,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
     if os.environ.get("CREID_BENCH_CONFIG3", "0") == "1":      # side line: the training half of BASELINE configs[3]
         arch, P, H, W = "resnet50_ibn_a", 14, 320, 320         # (configs/320_resnet50_ibn_a.yml: 320 x 320, 14 x 4 images)
     f32 = os.environ.get("CREID_BENCH_DTYPE", "bf16") == "f32"   # side measurement: the exact-f32 parity mode
+    torch.manual_seed(int(os.environ.get("CREID_BENCH_SEED", "0")))   # random-init weights: the same ones in every run
     model = make_model(arch=arch, dtype=torch.float32 if f32 else torch.bfloat16)
     ddp = world > 1 or (dist.is_available() and dist.is_initialized())      # CREID_FORCE_DIST=1: one-rank RCCL group
     overlap = False
@@ -580,7 +586,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
         torch.cuda.current_stream().wait_stream(side)
         if not split_graph:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                 gout = model.training_step(static, 0)
 
             def one_step(s):
@@ -590,11 +596,11 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
         else:
             model.grad_sync = None
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, capture_error_mode=CAPTURE_MODE):
                 gout = model.forward_backward(static, 0)
             if sync is not None:
                 sync(model)                      # also fixes opt.grad_scale = 1/world before graph B is captured
-            with torch.cuda.graph(gb, pool=ga.pool()):
+            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=CAPTURE_MODE):
                 model.apply_optimizers()
 
             def one_step(s):

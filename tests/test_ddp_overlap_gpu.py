@@ -34,3 +34,27 @@ def test_rccl_one_rank_group_matches_step_without_group():
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert "RCCL_WORLD1_OK" in out and "RCCL_WORLD1_MISMATCH" not in out, out[-3000:]
+
+
+def test_bench_data_parallel_path_over_one_rank_rccl_group_matches_single_process_bench():
+    """`bench.py` itself on the data-parallel path (hipGraph segments + bucketed RCCL all-reduces on a side stream) with a
+    one-rank `nccl` group at the REAL benchmark size, against the plain single-process bench: same loss after the same steps.
+    (This run is what found that hipGraph capture in the default global mode aborts the process as soon as the RCCL watchdog
+    thread polls an event -- every capture of the bench now uses the thread-local mode.)"""
+    import json
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CREID_BENCH_NO_EVAL="1", CREID_BENCH_NO_INSITU="1", CREID_DETERMINISTIC="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        base.pop(k, None)
+    losses = {}
+    for mode, extra in (("single", {}), ("rccl1", {"CREID_FORCE_DIST": "1", "MASTER_PORT": "29541"})):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                           cwd=ROOT, env=dict(base, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])
+        out_lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+        assert len(out_lines) == 1, out_lines                      # the bench contract: ONE line on stdout (RCCL's banner included)
+        line = json.loads(out_lines[0])
+        assert line["hip_graph"] and line["n_gpus"] == 1
+        losses[mode] = (line["final_loss"], line["ms_per_step"])
+    assert losses["single"][0] == losses["rccl1"][0], losses
+    # three graph replays + four host-issued collectives per step instead of one replay: a bounded overhead
+    assert losses["rccl1"][1] < 1.5 * losses["single"][1] + 1.0, losses
