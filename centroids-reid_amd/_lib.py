@@ -28,6 +28,7 @@ SIGNATURES = {
     "creid_sqdist_matrix": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, C.c_int, _p, _i64, _p]),
     "creid_rank_rows_workspace_bytes": (_sz, [_i64, _i64]),
     "creid_rank_rows": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
+    "creid_rank_rows_eval": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_cmc_ap_ranked": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_cmc_ap_ranked_camsets": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_topk_rows": (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),

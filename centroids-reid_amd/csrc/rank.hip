@@ -130,9 +130,17 @@ __device__ __forceinline__ unsigned rl_bucket(unsigned k, unsigned kmin, float i
   return b < (unsigned)RL_NB ? b : (unsigned)(RL_NB - 1);
 }
 
+// Optional per-query evaluation (utils/eval_reid.py:36-90 for plain camera ids) while the ranked row is still in LDS: the
+// separate CMC / AP pass re-read the int64 index matrix (8 B per pair, the largest stream of the evaluation) only to gather
+// two labels per entry.  q_pids == nullptr: ranking only.
+struct RankEval {
+  const int64_t* q_pids; const int64_t* g_pids; const int64_t* q_cams; const int64_t* g_cams;
+  uint8_t* valid; double* ap; int32_t* first;
+};
+
 __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restrict__ dist, int64_t m, int n, int64_t ld,
                                                            int64_t* __restrict__ out_idx,
-                                                           uint8_t* __restrict__ fallback) {
+                                                           uint8_t* __restrict__ fallback, RankEval ev) {
   extern __shared__ __attribute__((aligned(16))) unsigned rl_smem[];
   const int n4 = (n + 3) & ~3;
   unsigned* keys2 = rl_smem;                                    // [n4] keys grouped by bucket
@@ -255,6 +263,62 @@ __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restri
     } else {
       for (int i = tid; i < n; i += RT) orow[i] = (int64_t)keys2[i];
     }
+    if (ev.q_pids) {
+      // cmc_ap_ranked_wide_kernel<false> on the LDS-resident ranked row (same wave segments, same ballots, same float64
+      // summation order -> bit-identical per-query results); the bucket tables are dead by now and hold the scratch
+      unsigned long long* masks = reinterpret_cast<unsigned long long*>(off);       // [groups][2] (16-B aligned)
+      int* s_i = reinterpret_cast<int*>(cnt);                                       // [3][RW]
+      double* s_d = reinterpret_cast<double*>(cnt + 64);                            // [RW]
+      const long long qp = ev.q_pids[row], qc = ev.q_cams[row];
+      const int groups = (n + 63) >> 6, gseg = (groups + RW - 1) / RW;
+      const int g0 = min(wave * gseg, groups), g1 = min(g0 + gseg, groups);
+      const unsigned long long lt = lanemask_lt();
+      int nkeep = 0, nmatch = 0;
+      for (int gidx = g0; gidx < g1; ++gidx) {
+        const int k = gidx * 64 + lane;
+        bool keep = false, mk = false;
+        if (k < n) {
+          const unsigned gi = keys2[k];
+          const bool match = ev.g_pids[gi] == qp;
+          keep = !(match && ev.g_cams[gi] == qc);
+          mk = match && keep;
+        }
+        const unsigned long long km = __ballot(keep), mm = __ballot(mk);
+        if (lane == 0) { masks[2 * gidx] = km; masks[2 * gidx + 1] = mm; }
+        nkeep += __popcll(km); nmatch += __popcll(mm);
+      }
+      if (lane == 0) { s_i[wave] = nkeep; s_i[RW + wave] = nmatch; }
+      __syncthreads();
+      int bk = 0, bm = 0, tot_match = 0;
+#pragma unroll
+      for (int w = 0; w < RW; ++w) { if (w < wave) { bk += s_i[w]; bm += s_i[RW + w]; } tot_match += s_i[RW + w]; }
+      double apv = 0.0;
+      int firstv = 0x7fffffff;
+      for (int gidx = g0; gidx < g1; ++gidx) {
+        const unsigned long long km = masks[2 * gidx], mm = masks[2 * gidx + 1];
+        if ((mm >> lane) & 1ull) {
+          const int p = bk + __popcll(km & lt) + 1;        // 1-based kept position
+          const int c = bm + __popcll(mm & lt) + 1;        // matches up to and including this one
+          apv += (double)c / (double)p;
+          firstv = min(firstv, p - 1);
+        }
+        bk += __popcll(km); bm += __popcll(mm);
+      }
+      apv = wave_sum_d(apv);
+      firstv = wave_min_i(firstv);
+      if (lane == 0) { s_d[wave] = apv; s_i[2 * RW + wave] = firstv; }
+      __syncthreads();
+      if (tid == 0) {
+        double a = 0.0;
+        int f = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) { a += s_d[w]; f = min(f, s_i[2 * RW + w]); }
+        const bool valid = tot_match > 0;
+        ev.valid[row] = valid ? 1 : 0;
+        ev.ap[row] = valid ? a / (double)tot_match : 0.0;
+        ev.first[row] = valid ? f : -1;
+      }
+    }
     __syncthreads();                                             // LDS is reused by the next row
   }
 }
@@ -272,10 +336,12 @@ __global__ __launch_bounds__(256) void cmc_ap_ranked_kernel(const int64_t* __res
                                                             const int64_t* __restrict__ g_cams,
                                                             uint8_t* __restrict__ out_valid,
                                                             double* __restrict__ out_ap,
-                                                            int32_t* __restrict__ out_first) {
+                                                            int32_t* __restrict__ out_first,
+                                                            const uint8_t* __restrict__ only_rows) {
   __shared__ int s_keep[4], s_match[4], s_first[4];
   __shared__ double s_ap[4];
   const int64_t qi = blockIdx.x;
+  if (only_rows && !only_rows[qi]) return;                 // rows the fused rank + evaluate kernel has already done
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t qp = q_pids[qi], qc = q_cams[qi];
   const int64_t* row = idx + qi * n;
@@ -345,12 +411,14 @@ __global__ __launch_bounds__(1024) void cmc_ap_ranked_wide_kernel(const int64_t*
                                                                   const int64_t* __restrict__ g_cams,
                                                                   uint8_t* __restrict__ out_valid,
                                                                   double* __restrict__ out_ap,
-                                                                  int32_t* __restrict__ out_first) {
+                                                                  int32_t* __restrict__ out_first,
+                                                                  const uint8_t* __restrict__ only_rows) {
   constexpr int CW = 16;
   extern __shared__ __attribute__((aligned(16))) unsigned long long cm_masks[];    // [groups][2]
   __shared__ int s_keep[CW], s_match[CW], s_first[CW];
   __shared__ double s_ap[CW];
   const int64_t qi = blockIdx.x;
+  if (only_rows && !only_rows[qi]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t qp = q_pids[qi], qc = q_cams[qi];
   const int64_t* row = idx + qi * n;
@@ -557,8 +625,8 @@ size_t creid_rank_rows_workspace_bytes(int64_t m, int64_t n) {
   return rank_radix_ws_bytes(m, n) + (((size_t)m + 255) & ~(size_t)255);     // + per-row fallback flags
 }
 
-int creid_rank_rows(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t* out_idx, void* ws,
-                    size_t ws_bytes, void* stream) {
+static int rank_rows_impl(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t* out_idx, void* ws, size_t ws_bytes,
+                          void* stream, RankEval ev) {
   CREID_CHECK_ARG(m >= 0 && n >= 0 && ld >= n);
   if (m == 0 || n == 0) return 0;
   CREID_CHECK_ARG(dist && out_idx && ws);
@@ -582,12 +650,40 @@ int creid_rank_rows(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t
     }
     const int64_t wgs = m < 1024 ? m : 1024;
     hipLaunchKernelGGL(rank_rows_lds_kernel, dim3((unsigned)wgs), dim3(RT), lds_bytes, s, dist, m, (int)n, ld, out_idx,
-                       flags);
+                       flags, ev);
     only_flagged = flags;
   }
   hipLaunchKernelGGL(rank_rows_kernel, dim3((unsigned)slots), dim3(RT), 0, s, dist, m, n, ld, out_idx, (unsigned*)ws,
                      only_flagged);
+  if (ev.q_pids) {
+    // rows the one-pass kernel did not take (pathological ties, or a gallery that does not fit its LDS layout): the separate
+    // scan over the index matrix, restricted to those rows
+    if (m > 0x7fffffffLL || n > 0x7fffff00LL) return CREID_E_SHAPE;
+    const size_t mask_bytes = (size_t)((n + 63) / 64) * 16;
+    if (mask_bytes <= 48 * 1024)
+      hipLaunchKernelGGL(cmc_ap_ranked_wide_kernel<false>, dim3((unsigned)m), dim3(1024), mask_bytes, s, out_idx, m, n, ev.q_pids,
+                         ev.g_pids, ev.q_cams, ev.g_cams, ev.valid, ev.ap, ev.first, only_flagged);
+    else
+      hipLaunchKernelGGL(cmc_ap_ranked_kernel<false>, dim3((unsigned)m), dim3(256), 0, s, out_idx, m, n, ev.q_pids, ev.g_pids,
+                         ev.q_cams, ev.g_cams, ev.valid, ev.ap, ev.first, only_flagged);
+  }
   CREID_LAUNCH_RET();
+}
+
+int creid_rank_rows(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t* out_idx, void* ws,
+                    size_t ws_bytes, void* stream) {
+  return rank_rows_impl(dist, m, n, ld, out_idx, ws, ws_bytes, stream, RankEval{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+}
+
+/* creid_rank_rows + creid_cmc_ap_ranked in one pass where the row fits the one-pass rank kernel: the per-query (valid, AP,
+ * first match) are computed while the ranked row is still in LDS; the int64 index matrix is written (the caller wants it) but
+ * never read back.  Identical results to the two separate calls. */
+int creid_rank_rows_eval(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t* out_idx, void* ws, size_t ws_bytes,
+                         const int64_t* q_pids, const int64_t* g_pids, const int64_t* q_camids, const int64_t* g_camids,
+                         uint8_t* out_valid, double* out_ap, int32_t* out_first, void* stream) {
+  CREID_CHECK_ARG(q_pids && g_pids && q_camids && g_camids && out_valid && out_ap && out_first);
+  return rank_rows_impl(dist, m, n, ld, out_idx, ws, ws_bytes, stream,
+                        RankEval{q_pids, g_pids, q_camids, g_camids, out_valid, out_ap, out_first});
 }
 
 int creid_cmc_ap_ranked(const int64_t* idx, int64_t m, int64_t n, const int64_t* q_pids, const int64_t* g_pids,
@@ -600,10 +696,10 @@ int creid_cmc_ap_ranked(const int64_t* idx, int64_t m, int64_t n, const int64_t*
   const size_t mask_bytes = (size_t)((n + 63) / 64) * 16;
   if (mask_bytes <= 48 * 1024)
     hipLaunchKernelGGL(cmc_ap_ranked_wide_kernel<false>, dim3((unsigned)m), dim3(1024), mask_bytes, as_stream(stream), idx,
-                       m, n, q_pids, g_pids, q_camids, g_camids, out_valid, out_ap, out_first);
+                       m, n, q_pids, g_pids, q_camids, g_camids, out_valid, out_ap, out_first, (const uint8_t*)nullptr);
   else
     hipLaunchKernelGGL(cmc_ap_ranked_kernel<false>, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
-                       g_pids, q_camids, g_camids, out_valid, out_ap, out_first);
+                       g_pids, q_camids, g_camids, out_valid, out_ap, out_first, (const uint8_t*)nullptr);
   CREID_LAUNCH_RET();
 }
 
@@ -617,10 +713,10 @@ int creid_cmc_ap_ranked_camsets(const int64_t* idx, int64_t m, int64_t n, const 
   const size_t mask_bytes = (size_t)((n + 63) / 64) * 16;
   if (mask_bytes <= 48 * 1024)
     hipLaunchKernelGGL(cmc_ap_ranked_wide_kernel<true>, dim3((unsigned)m), dim3(1024), mask_bytes, as_stream(stream), idx,
-                       m, n, q_pids, g_pids, q_camids, g_cam_masks, out_valid, out_ap, out_first);
+                       m, n, q_pids, g_pids, q_camids, g_cam_masks, out_valid, out_ap, out_first, (const uint8_t*)nullptr);
   else
     hipLaunchKernelGGL(cmc_ap_ranked_kernel<true>, dim3((unsigned)m), dim3(256), 0, as_stream(stream), idx, m, n, q_pids,
-                       g_pids, q_camids, g_cam_masks, out_valid, out_ap, out_first);
+                       g_pids, q_camids, g_cam_masks, out_valid, out_ap, out_first, (const uint8_t*)nullptr);
   CREID_LAUNCH_RET();
 }
 

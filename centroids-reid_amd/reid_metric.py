@@ -88,6 +88,26 @@ def rank_rows(distmat: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def rank_rows_eval(distmat: torch.Tensor, q_pids, g_pids, q_camids, g_camids):
+    """rank_rows + the per-query half of eval_func (plain camera ids) in one pass over the distance matrix
+    (creid_rank_rows_eval): returns (indices int64 [m, n], valid u8 [m], ap f64 [m], first i32 [m]) -- the index matrix is
+    written for the caller but never read back by the evaluation."""
+    L.require_gpu(distmat)
+    assert distmat.dtype == torch.float32 and distmat.dim() == 2
+    m, n = distmat.shape
+    dev = distmat.device
+    qp, gp, qc, gc = (_dev_i64(a, dev) for a in (q_pids, g_pids, q_camids, g_camids))
+    out = torch.empty((m, n), dtype=torch.int64, device=dev)
+    valid = torch.empty(m, dtype=torch.uint8, device=dev)
+    ap = torch.empty(m, dtype=torch.float64, device=dev)
+    first = torch.empty(m, dtype=torch.int32, device=dev)
+    nbytes = L.lib().creid_rank_rows_workspace_bytes(m, n)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    L.check(L.lib().creid_rank_rows_eval(L.ptr(distmat), m, n, n, L.ptr(out), L.ptr(ws), nbytes, L.ptr(qp), L.ptr(gp), L.ptr(qc),
+                                         L.ptr(gc), L.ptr(valid), L.ptr(ap), L.ptr(first), L.stream()), "creid_rank_rows_eval")
+    return out, valid, ap, first
+
+
 def topk_rows(distmat: torch.Tensor, k: int):
     """(indices int64 [m, k], distances fp32 [m, k]): the first k columns of np.argsort(distmat, axis=1) and the
     distances there (inference/get_similar.py:114-119), selected without sorting the whole row."""
@@ -366,14 +386,27 @@ class R1_mAP:
         else:
             f = l2_normalize(feats) if self.feat_norm else feats
             distmat = self.dist_func(f[:nq].contiguous(), f[nq:].contiguous())
-        indices = rank_rows(distmat)
         pids = np.asarray(pids)
-        if not respect_camids:
-            camids = np.asarray(camids)     # (ragged list-of-lists in camera-set mode: keep as a list)
-        cmc, mAP, all_topk, single = eval_func(indices, pids[:nq], pids[nq:], camids[:nq], camids[nq:],
-                                               self.max_rank, respect_camids)
-        self.last = dict(distmat=distmat, indices=indices, single_performance=single)
-        return cmc, mAP, all_topk
+        if respect_camids:                      # (ragged list-of-lists of camera sets: keep as a list)
+            indices = rank_rows(distmat)
+            cmc, mAP, all_topk, single = eval_func(indices, pids[:nq], pids[nq:], camids[:nq], camids[nq:],
+                                                   self.max_rank, respect_camids)
+            self.last = dict(distmat=distmat, indices=indices, single_performance=single)
+            return cmc, mAP, all_topk
+        # np.argsort + eval_func's per-query loop in ONE pass: the ranked rows are evaluated while they are still in LDS
+        camids = np.asarray(camids)
+        indices, valid, ap, first = rank_rows_eval(distmat, pids[:nq], pids[nq:], camids[:nq], camids[nq:])
+        max_rank = self.max_rank
+        if distmat.shape[1] < max_rank:         # utils/eval_reid.py:33-35
+            max_rank = distmat.shape[1]
+            print("Note: number of gallery samples is quite small, got {}".format(distmat.shape[1]))
+        cmc, mAP, topk, _ = eval_reduce_device(valid, ap, first, max_rank)
+        pack = torch.cat([cmc.double(), mAP, topk, valid.double(), ap]).cpu().numpy()          # one read-back
+        valid_h = pack[max_rank + 6:max_rank + 6 + nq] == 1
+        vi = np.nonzero(valid_h)[0]
+        single = np.stack([vi.astype(np.float64), pids[:nq][vi].astype(np.float64), pack[max_rank + 6 + nq:][vi]], axis=1)
+        self.last = dict(distmat=distmat, indices=indices, single_performance=single, valid=valid, ap=ap, first=first)
+        return pack[:max_rank].astype(np.float32), float(pack[max_rank]), pack[max_rank + 1:max_rank + 6].copy()
 
     def _compute_streamed(self, feats, pids, camids, plan=None):
         nq = self.num_query

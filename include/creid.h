@@ -61,6 +61,13 @@ int creid_sqdist_matrix(const void* q, const void* g, const float* qq, const flo
 size_t creid_rank_rows_workspace_bytes(int64_t m, int64_t n);
 int creid_rank_rows(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t* out_idx,
                     void* ws, size_t ws_bytes, void* stream);
+/* np.argsort + eval_func's per-query loop (utils/reid_metric.py:129-132 + utils/eval_reid.py:36-90, plain camera ids) in ONE
+ * pass: the ranked row is evaluated while it is still in LDS, so the int64 index matrix (8 B per pair) is written for the
+ * caller but never read back; rows the one-pass rank kernel cannot take are evaluated by creid_cmc_ap_ranked's kernel.
+ * out_idx / ws as creid_rank_rows, out_valid / out_ap / out_first as creid_cmc_ap_ranked; results identical to the two calls. */
+int creid_rank_rows_eval(const float* dist, int64_t m, int64_t n, int64_t ld, int64_t* out_idx, void* ws, size_t ws_bytes,
+                         const int64_t* q_pids, const int64_t* g_pids, const int64_t* q_camids, const int64_t* g_camids,
+                         uint8_t* out_valid, double* out_ap, int32_t* out_first, void* stream);
 
 /* ------------------------------------------------------------------ stage E: CMC / mAP */
 

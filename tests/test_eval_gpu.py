@@ -196,3 +196,34 @@ def test_topk_rows_equals_rank_prefix(m, n, k):
     assert torch.equal(idx, ref)
     assert torch.equal(dsel, torch.gather(dt, 1, ref))
     np.testing.assert_array_equal(idx.cpu().numpy(), np.argsort(d, axis=1, kind="stable")[:, :k])
+
+
+@pytest.mark.parametrize("m,n", [(5, 40), (37, 6000), (129, 17661), (9, 3000), (3, 30000)])
+def test_rank_rows_eval_equals_rank_then_eval(rm, m, n):
+    """creid_rank_rows_eval (ranked rows evaluated while still in LDS; other rows through the scan kernel) == creid_rank_rows
+    followed by creid_cmc_ap_ranked, bit for bit -- the one-pass rank kernel (512 <= n <= 21.5 k), its flagged rows
+    (pathological ties -> radix kernel + scan), galleries outside its range, queries without any match -- and both equal to
+    the CPU oracle's per-query results on a stable argsort of the same matrix."""
+    from oracle import reid_oracle as ro
+    rng = np.random.default_rng(m * 13 + n)
+    d = (2.0 + 0.1 * rng.standard_normal((m, n))).astype(np.float32)
+    if m > 4:
+        d[1] = 1.25                                             # all equal -> flagged where the LDS kernel applies
+        d[2, : n // 2] = 0.5
+        d[3] = np.round(d[3], 2)
+    qp = rng.integers(0, 12, m); gp = rng.integers(0, 11, n)    # pid 11 never in the gallery -> invalid queries
+    qp[0] = 11
+    qc = rng.integers(0, 3, m); gc = rng.integers(0, 3, n)
+    dt = torch.from_numpy(d).cuda()
+    idx0 = rm.rank_rows(dt)
+    _, _, _, _, v0, a0, f0 = rm.eval_func_device(idx0, qp, gp, qc, gc, 50)
+    idx1, v1, a1, f1 = rm.rank_rows_eval(dt, qp, gp, qc, gc)
+    assert torch.equal(idx1, idx0)
+    assert torch.equal(v1, v0) and torch.equal(f1, f0) and torch.equal(a1, a0)
+    assert int(v1[0]) == 0
+    o_idx = np.argsort(d + 0.0, axis=1, kind="stable")
+    np.testing.assert_array_equal(idx1.cpu().numpy(), o_idx)
+    _, _, _, ex = ro.eval_market(o_idx, qp, gp, qc, gc)
+    np.testing.assert_array_equal(v1.cpu().numpy() == 1, ex["valid"])
+    np.testing.assert_array_equal(f1.cpu().numpy()[ex["valid"]], ex["first"][ex["valid"]])
+    np.testing.assert_allclose(a1.cpu().numpy()[ex["valid"]], ex["ap"][ex["valid"]], rtol=0, atol=1e-14)
