@@ -148,10 +148,30 @@ __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restri
   unsigned* cnt = off + RL_NB + 4;                              // [RL_NB] counters / cursors (16-B aligned)
   unsigned* red = cnt + RL_NB;                                  // [3 * RW] reduction scratch
   unsigned short* idx2 = reinterpret_cast<unsigned short*>(red + 3 * RW);   // [n] gallery index of each slot
+  // fused evaluation: (keep, match) of every GALLERY entry for this query as two bitmaps, [ceil(n / 64)] 64-bit words each,
+  // filled in phase A from coalesced label loads -- the evaluation then looks ranked entries up in LDS instead of gathering
+  // two labels per entry from global memory (64 distinct cache lines per wave instruction: 18 us per row, measured)
+  unsigned long long* bm_keep = reinterpret_cast<unsigned long long*>(idx2 + n4);
+  unsigned long long* bm_match = bm_keep + ((n + 63) >> 6);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   for (int64_t row = blockIdx.x; row < m; row += gridDim.x) {
     const float* drow = dist + row * ld;
+    if (ev.q_pids) {
+      // (keeping all 21 label loads of a thread in flight next to the 21 distance loads costs 42 more live registers at the
+      // 128-VGPR cap of a 1024-thread workgroup: 129 spills, the whole kernel 25 % slower -- measured; three per trip it is)
+      const long long qp = ev.q_pids[row], qc = ev.q_cams[row];
+#pragma unroll 3
+      for (int j = 0; j < RL_KPT; ++j) {
+        const int i = tid + j * RT;
+        if (i - lane >= n) break;                                  // (wave-uniform)
+        const bool in = i < n;
+        const bool match = in && ev.g_pids[i] == qp;
+        const bool keep = in && !(match && ev.g_cams[i] == qc);    // camera fetched for the rare matches only
+        const unsigned long long km = __ballot(keep), mm = __ballot(match && keep);
+        if (lane == 0) { bm_keep[i >> 6] = km; bm_match[i >> 6] = mm; }
+      }
+    }
     // ---- A: the row's keys go into registers once (RL_KPT independent loads in flight per thread; the three
     //         passes below would otherwise each pay ~n/1024 dependent L2 round trips), min / max key
     unsigned kreg[RL_KPT];
@@ -269,7 +289,6 @@ __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restri
       unsigned long long* masks = reinterpret_cast<unsigned long long*>(off);       // [groups][2] (16-B aligned)
       int* s_i = reinterpret_cast<int*>(cnt);                                       // [3][RW]
       double* s_d = reinterpret_cast<double*>(cnt + 64);                            // [RW]
-      const long long qp = ev.q_pids[row], qc = ev.q_cams[row];
       const int groups = (n + 63) >> 6, gseg = (groups + RW - 1) / RW;
       const int g0 = min(wave * gseg, groups), g1 = min(g0 + gseg, groups);
       const unsigned long long lt = lanemask_lt();
@@ -279,9 +298,8 @@ __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restri
         bool keep = false, mk = false;
         if (k < n) {
           const unsigned gi = keys2[k];
-          const bool match = ev.g_pids[gi] == qp;
-          keep = !(match && ev.g_cams[gi] == qc);
-          mk = match && keep;
+          keep = (bm_keep[gi >> 6] >> (gi & 63u)) & 1ull;
+          mk = (bm_match[gi >> 6] >> (gi & 63u)) & 1ull;
         }
         const unsigned long long km = __ballot(keep), mm = __ballot(mk);
         if (lane == 0) { masks[2 * gidx] = km; masks[2 * gidx + 1] = mm; }
@@ -638,7 +656,8 @@ static int rank_rows_impl(const float* dist, int64_t m, int64_t n, int64_t ld, i
   // rows that fit in LDS next to the bucket tables take the one-pass bucket kernel (CREID_RANK_LDS=0 disables)
   static const int use_lds = [] { const char* e = getenv("CREID_RANK_LDS"); return e ? atoi(e) : 1; }();
   const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
-  const size_t lds_bytes = n4 * 4 + (size_t)(2 * RL_NB + 4 + 3 * RW) * 4 + n4 * 2;
+  const size_t lds_bytes = n4 * 4 + (size_t)(2 * RL_NB + 4 + 3 * RW) * 4 + n4 * 2 +
+                           (ev.q_pids ? (size_t)2 * ((n + 63) / 64) * 8 : 0);      // + the evaluation's two bitmaps
   const uint8_t* only_flagged = nullptr;
   if (use_lds && n >= 512 && n <= (int64_t)RL_KPT * RT && lds_bytes <= 156 * 1024) {
     static bool attr_set = false;
