@@ -44,5 +44,7 @@ def test_hot_kernels_keep_their_occupancy_budget():
             # 512 threads = 2 waves per SIMD per workgroup; two workgroups per CU need 4 waves per SIMD = 128 VGPRs.
             # The 256-row variant (third template argument) runs one workgroup per CU: 256 registers, no spills.
             limit = 256 if (len(args) == 3 and args[2] == 256) else 128
+            if args[:2] == [64, 2] and (len(args) < 3 or args[2] == 128):
+                limit = 80                                   # the 128 x 64 two-stage tile runs THREE workgroups per CU (6 waves / SIMD)
             assert int(kv["vgprs"]) + int(kv.get("agprs", 0)) <= limit, (name, kv)
     assert seen >= 6
