@@ -333,6 +333,28 @@ def cpu_baseline_train(P, K, H, W):
 
 
 
+def cpu_baseline_embed(B=64, H=256, W=128, reps=3):
+    """The CPU oracle's eval-mode embedding forward (backbone + GAP + BNNeck, torch-CPU fp32) on <= 32 host threads: `reps` batches
+    of B images after one warm-up batch -- the baseline beside the `embed` object."""
+    from oracle import backbone_oracle as bo
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = bo.make_state_dict("resnet50", 1, seed=1)
+    bn_w, bn_b, bn_rm, bn_rv = torch.ones(2048), torch.zeros(2048), torch.zeros(2048), torch.ones(2048)
+
+    def fwd():
+        with torch.no_grad():
+            _, feat = bo.backbone_forward(torch.randn(B, 3, H, W), sd, "resnet50", 1, training=False)
+            return bo.bnneck_forward(feat, bn_w, bn_b, bn_rm, bn_rv, False)
+    fwd()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fwd()
+    dt = time.perf_counter() - t0
+    return {"value": reps * B / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} eval-mode forwards of {B} images after 1 warm-up, torch-CPU oracle", "seconds": dt}
+
+
 # ----------------------------------------------------------------------------- main
 _REAL_STDOUT = sys.stdout
 _REAL_FD = 1
@@ -374,6 +396,8 @@ def main():
         args.warmup = args.warmup if args.warmup is not None else 5
         out = bench_train.run(args, rank, world, barrier_sync, time_kernel,
                               None if args.no_cpu_baseline else cpu_baseline_train)
+        if rank == 0 and world == 1 and "embed" in out and not args.no_cpu_baseline:
+            out["embed"]["cpu_baseline"] = cpu_baseline_embed()
         if os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
             # the other half of BASELINE.metric (eval query x gallery dist-pairs/s) rides in the same line, timed by
             # the same invocation: 5 steps after 2 warm-up of the configs[4] workload
