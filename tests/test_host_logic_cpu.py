@@ -1,0 +1,55 @@
+"""CPU: host-side logic that the GPU paths and the bench line rely on -- the numpy construction of the streamed-evaluation index
+(the checker of the device build), the roofline arithmetic of the bench, the feature-width padding."""
+import numpy as np
+import torch
+
+
+def test_host_stream_plan_against_brute_force():
+    """StreamPlan (numpy construction; utils/eval_reid.py:36-65 per query): groups, positive counts, capacity and overflow
+    list against a per-query brute-force count."""
+    from centroids_reid_amd import reid_metric as rm
+    rng = np.random.default_rng(1)
+    nq, ng = 60, 900
+    pids = rng.integers(0, 25, nq + ng) * 3 - 7              # non-dense, negative pids included
+    cams = rng.integers(0, 4, nq + ng)
+    pids[0] = 1000                                           # absent from the gallery
+    pids[nq:nq + 200] = 5; pids[1] = 5                       # 200 gallery entries of one pid -> overflow for its queries
+    plan = rm.StreamPlan(pids[:nq], pids[nq:], cams[:nq], cams[nq:], "cpu")
+    gp, gc = pids[nq:], cams[nq:]
+    n_pos = np.array([int(((gp == pids[i]) & (gc != cams[i])).sum()) for i in range(nq)])
+    np.testing.assert_array_equal(plan.n_pos, n_pos)
+    np.testing.assert_array_equal(plan.overflow, np.nonzero(n_pos > 128)[0])
+    assert len(plan.overflow) > 0
+    mx = n_pos[n_pos <= 128].max()
+    assert plan.cap >= mx and plan.cap // 2 < max(mx, 2) and plan.cap & (plan.cap - 1) == 0
+    slot = plan.q_slot.numpy(); csr = plan.csr_off.numpy(); order = plan.g_order.numpy()
+    assert slot[0] == -1
+    for i in range(1, nq):
+        grp = order[csr[slot[i]]:csr[slot[i] + 1]]
+        np.testing.assert_array_equal(np.sort(grp), np.nonzero(gp == pids[i])[0])
+        assert (np.diff(grp) > 0).all()                      # the host build keeps gallery-index order inside a group
+
+
+def test_bench_flop_counts_match_the_survey():
+    """ResNet50 256x128 = 4.0533 GMAC per image forward (8.11 GFLOP), 24.32 GFLOP forward + backward; the igemm
+    family of one B = 64 step (forward + data gradient of the 52 non-stem convolutions + the stem's forward) = 1.028 TFLOP;
+    ResNet50(-IBN-a) 320x320 = 25.33 GFLOP per image forward."""
+    from centroids_reid_amd import bench_train as bt
+    fwd = bt.forward_flops(1, 256, 128)
+    assert abs(fwd / 2 / 1e9 - 4.0533) < 2e-3
+    assert abs(3 * fwd / 1e9 - bt.R50_FWD_BWD_GFLOP_PER_IMG) < 0.02
+    assert abs(bt.forward_flops(1, 320, 320) / 1e9 - 25.33) < 0.02
+    step = bt.igemm_step_flops(64, 256, 128)
+    stem = 2.0 * 64 * 128 * 64 * 64 * 147
+    assert abs(step - (2 * (bt.forward_flops(64, 256, 128) - stem) + stem)) < 1.0
+    assert abs(step / 1e12 - 1.0278) < 1e-3
+    assert len(bt.conv_shapes(64, 256, 128)) == 52
+
+
+def test_feature_width_padding_changes_no_distance():
+    from centroids_reid_amd import reid_metric as rm
+    f = torch.randn(7, 30)
+    p = rm._pad_width(f)
+    assert p.shape == (7, 32) and torch.equal(p[:, :30], f) and float(p[:, 30:].abs().sum()) == 0.0
+    assert rm._pad_width(p) is p
+    assert torch.equal(torch.cdist(p, p), torch.cdist(f, f))
