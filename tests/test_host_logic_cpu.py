@@ -48,8 +48,10 @@ def test_bench_flop_counts_match_the_survey():
 
 def test_feature_width_padding_changes_no_distance():
     from centroids_reid_amd import reid_metric as rm
-    f = torch.randn(7, 30)
+    f = torch.randn(7, 30, generator=torch.Generator().manual_seed(0))
     p = rm._pad_width(f)
     assert p.shape == (7, 32) and torch.equal(p[:, :30], f) and float(p[:, 30:].abs().sum()) == 0.0
     assert rm._pad_width(p) is p
-    assert torch.equal(torch.cdist(p, p), torch.cdist(f, f))
+    d_p = (p.double()[:, None] - p.double()[None]).pow(2).sum(-1)
+    d_f = (f.double()[:, None] - f.double()[None]).pow(2).sum(-1)
+    assert torch.allclose(d_p, d_f, rtol=1e-13, atol=0)     # zero columns add zeros to every sum (reduction trees may differ)
