@@ -49,6 +49,19 @@ __device__ __forceinline__ void tr_wait8_n(s16x4& a, s16x4& b, s16x4& c, s16x4& 
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(NW) : "memory");
 }
 
+// s_waitcnt lgkmcnt(NW) naming the 2 * (IM + JN) destination registers of one fragment set (IM + JN transposing read pairs)
+template <int NW, int IM, int JN>
+__device__ __forceinline__ void tr_wait_set(s16x4 (&al)[IM], s16x4 (&ah)[IM], s16x4 (&bl)[JN], s16x4 (&bh)[JN]) {
+  if constexpr (IM == 2 && JN == 2)
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]) : "n"(NW) : "memory");
+  else if constexpr (IM == 2 && JN == 1)
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]) : "n"(NW) : "memory");
+  else if constexpr (IM == 1 && JN == 2)
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(al[0]), "+v"(ah[0]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]) : "n"(NW) : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(al[0]), "+v"(ah[0]), "+v"(bl[0]), "+v"(bh[0]) : "n"(NW) : "memory");
+}
+
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
                                                          const unsigned short* __restrict__ x, int NCO,
@@ -185,11 +198,15 @@ template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_
 // NS-stage LDS ring (see igemm_bf16_dma_kernel: with two stages the loop runs at global->LDS latency).
 // WS = true: 512 threads, waves 4-7 issue the DMA (producers), waves 0-3 read fragments and multiply (consumers),
 // one s_barrier per k-tile between them -- the split of igemm_bf16_ws_kernel.
-template <int TM, int TN, int NS, bool WS = false>
-__global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024) ? (WS ? 4 : 2) : (WS ? 2 : 1)) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
+// KG = 2 (non-WS): 512 threads = two k-groups of four waves.  Each group runs the whole pipeline (its own LDS ring, its own DMA
+// and fragment reads) over HALF of the split's pixel range on the SAME output tile; at the end group 1 hands its accumulators to
+// group 0 through LDS (fixed order: deterministic) and one partial tile leaves the CU.  Same waves per CU as two workgroups of
+// a split twice as fine, half the fp32 partial-tile traffic (write here + re-read by the split reduction).
+template <int TM, int TN, int NS, bool WS = false, int KG = 1>
+__global__ __launch_bounds__(WS ? 512 : 256 * KG, (KG * NS * (TM + TN) * 128 <= 80 * 1024) ? ((WS || KG == 2) ? 4 : 2) : ((WS || KG == 2) ? 2 : 1)) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
                                                                  const unsigned short* __restrict__ x, int NCO,
                                                                  float* __restrict__ ws, int tiles_k, int m_per_split,
-                                                                 int xcd_tiles, int xcd_splits, BnBwdFinJob fin) {
+                                                                 int xcd_tiles, int xcd_splits, BnBwdFinJob fin, int abl) {
   constexpr int IM = TM / 64, JN = TN / 64;
   constexpr int LPR_A = TM / 8, LPR_B = TN / 8;                // lanes (16-B chunks) per tile row
   constexpr int RPI_A = 64 / LPR_A, RPI_B = 64 / LPR_B;        // rows per wave-instruction
@@ -197,8 +214,11 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024)
   constexpr int TILE_A = WKS * TM, TILE_B = WKS * TN, STAGE = TILE_A + TILE_B;
   constexpr int LPT = NIA + NIB;
   static_assert((NS - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
-  __shared__ __attribute__((aligned(1024))) unsigned short smem[NS * STAGE];
+  static_assert(KG == 1 || (!WS && KG == 2 && KG * NS * STAGE * 2 <= 160 * 1024 && TM * TN * 2 <= KG * NS * STAGE), "k-groups");
+  __shared__ __attribute__((aligned(1024))) unsigned short smem_all[KG * NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;       // role-local wave index
+  const int kg = KG > 1 ? (tid >> 8) : 0;                                    // k-group of this wave
+  unsigned short* smem = smem_all + kg * NS * STAGE;                         // the group's own ring
   const bool producer = !WS || (tid >> 6) >= 4, consumer = !WS || (tid >> 6) < 4;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware split placement (xcd_tiles > 0, 1-D grid): workgroup b runs on XCD b % 8, and every XCD has its own
@@ -213,7 +233,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024)
   if (fin.partial) {
     const int nf8 = (fin.nblocks + 7) & ~7;
     if (bid0 < nf8) {
-      if (bid0 < fin.nblocks) bn_bwd_finalize_block<WS ? 512 : 256>(fin, bid0, smem);
+      if (bid0 < fin.nblocks) bn_bwd_finalize_block<WS ? 512 : 256 * KG>(fin, bid0, smem_all);
       return;
     }
     bid0 -= nf8;
@@ -234,7 +254,10 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024)
   }
   const int tile_co = tile / tiles_k, tile_k = tile - tile_co * tiles_k;
   const int co0 = tile_co * TM, k0 = tile_k * TN;
-  const int m_begin = split * m_per_split, m_end = min(g.M, m_begin + m_per_split);
+  // the split's pixel range, cut into KG runs of nt k-steps (every group executes nt barriers; a run past the range reads zeros)
+  const int m_begin0 = split * m_per_split, m_end0 = min(g.M, m_begin0 + m_per_split);
+  const int nt = ((m_end0 - m_begin0 + WKS - 1) / WKS + KG - 1) / KG;
+  const int m_begin = m_begin0 + kg * nt * WKS, m_end = min(m_end0, m_begin + nt * WKS);
   const int span_mask = (1 << g.log2span) - 1;
   const int tap = k0 >> g.log2span, cc = k0 & span_mask;
   const int tr = tap / g.kw, ts = tap - tr * g.kw;
@@ -302,6 +325,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024)
     }
   }
   auto issue = [&](int mb, int buf) {
+    if ((abl & 2) && mb != m_begin) return;                      // timing ablation: only the first k-tile is fetched
     unsigned short* la = smem + buf * STAGE + wave * 512;
     unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
     if (linear) {
@@ -382,33 +406,38 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024)
     fb[j] = lds0 + 2u * (unsigned)(TILE_A + t_row * TN + (((col >> 5) ^ keyB) << 5) + (col & 31));
   }
 
-  const int nt = (m_end - m_begin + WKS - 1) / WKS;
-  // fragment reads run one 16-pixel slice ahead of the MFMAs (two register sets): `s_waitcnt lgkmcnt(8)`
-  // retires the older slice's eight transposing reads while the younger slice's eight stay in flight
+  // fragment reads run one 16-pixel slice ahead of the MFMAs (two register sets): `s_waitcnt lgkmcnt(NRD)`
+  // retires the older slice's NRD transposing reads while the younger slice's NRD stay in flight.  A slice reads exactly the
+  // IM + JN fragments the wave multiplies (a 64-wide tile side used to be read twice: a third of the LDS read traffic of the
+  // 128 x 64 tile nearly every plan picks)
+  constexpr int NRD = 2 * (IM + JN);
   auto compute = [&](unsigned sb) {
-    s16x4 al[2][2], ah[2][2], bl[2][2], bh[2][2];
+    s16x4 al[2][IM], ah[2][IM], bl[2][JN], bh[2][JN];
 #define WG_LOAD(KK, S)                                                                                   \
-    tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[0] + sb, al[S][0], ah[S][0]);              \
-    tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[IM - 1] + sb, al[S][1], ah[S][1]);         \
-    tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[0] + sb, bl[S][0], bh[S][0]);              \
-    tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[JN - 1] + sb, bl[S][1], bh[S][1]);
+    _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                       \
+      tr_load2<(KK) * 16 * TM * 2, ((KK) * 16 + 4) * TM * 2>(fa[i] + sb, al[S][i], ah[S][i]);            \
+    _Pragma("unroll") for (int j = 0; j < JN; ++j)                                                       \
+      tr_load2<(KK) * 16 * TN * 2, ((KK) * 16 + 4) * TN * 2>(fb[j] + sb, bl[S][j], bh[S][j]);
 #define WG_MMA(S, NWAIT)                                                                                 \
     {                                                                                                    \
-      tr_wait8_n<NWAIT>(al[S][0], ah[S][0], al[S][1], ah[S][1], bl[S][0], bh[S][0], bl[S][1], bh[S][1]); \
+      tr_wait_set<NWAIT, IM, JN>(al[S], ah[S], bl[S], bh[S]);                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
       s16x8 a[IM], b[JN];                                                                                \
       _Pragma("unroll") for (int i = 0; i < IM; ++i) a[i] = __builtin_shufflevector(al[S][i], ah[S][i], 0, 1, 2, 3, 4, 5, 6, 7); \
       _Pragma("unroll") for (int j = 0; j < JN; ++j) b[j] = __builtin_shufflevector(bl[S][j], bh[S][j], 0, 1, 2, 3, 4, 5, 6, 7); \
+      if (!(abl & 1)) {                                                                                  \
       _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                     \
         _Pragma("unroll") for (int j = 0; j < JN; ++j)                                                   \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),          \
                                                               __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0); \
+      }                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
     }
+    if (abl & 4) return;                                                                                 
     WG_LOAD(0, 0)
-    WG_LOAD(1, 1) WG_MMA(0, 8)
-    WG_LOAD(2, 0) WG_MMA(1, 8)
-    WG_LOAD(3, 1) WG_MMA(0, 8)
+    WG_LOAD(1, 1) WG_MMA(0, NRD)
+    WG_LOAD(2, 0) WG_MMA(1, NRD)
+    WG_LOAD(3, 1) WG_MMA(0, NRD)
     WG_MMA(1, 0)
 #undef WG_LOAD
 #undef WG_MMA
@@ -450,6 +479,27 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NS * (TM + TN) * 128 <= 80 * 1024)
       compute((unsigned)(buf * STAGE * 2));
       buf = (buf + 1 == NS) ? 0 : buf + 1;
     }
+  }
+  if constexpr (KG > 1) {
+    __syncthreads();                                             // both rings are dead
+    float* ex = reinterpret_cast<float*>(smem_all);
+    const int t256 = tid & 255;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ex[((i * JN + j) * 16 + r) * 256 + t256] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((i * JN + j) * 16 + r) * 256 + t256];
   }
   const int l31 = lane & 31, kh = lane >> 5;
   float* wsp = ws + (int64_t)split * NCO * g.K;
@@ -645,7 +695,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __r
 // ------------------------------------------------------------------------------------ host
 static int ilog2x(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return ((1LL << l) == v) ? l : -1; }
 
-struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split, xcd, stages, ws; };   // stages / ws: 0 = default
+struct WgradPlan { int tm, tn, tiles, tiles_k, splits, m_per_split, xcd, stages, ws, kg; };   // stages / ws / kg: 0 = default
 
 static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype, int stride = 1) {
   // The fp32 partial tiles cost  workgroups x TM x TN x 8 bytes  of traffic per layer (write + re-read by the
@@ -659,13 +709,14 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype, int stride = 1) {
   const int ks = (dtype == CREID_BF16) ? WKS : WKF;
   const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   WgradPlan p;
-  p.stages = 0; p.ws = 0;
+  p.stages = 0; p.ws = 0; p.kg = 0;
   TunePlan tp;
   if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_WGRAD, M, NCO, K, stride << 1, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       (tp.p1 == 64 || tp.p1 == 128) && NCO % tp.p0 == 0 && K % tp.p1 == 0 && tp.p2 >= 1) {
-    // measured plan for this shape: tile tp.p0 x tp.p1, tp.p2 = pixel splits | ring depth << 16 | producer/consumer << 20
+    // measured plan for this shape: tile tp.p0 x tp.p1, tp.p2 = pixel splits | ring depth << 16 | producer/consumer << 20 |
+    // two k-groups << 21
     p.tm = tp.p0; p.tn = tp.p1;
-    p.stages = (tp.p2 >> 16) & 15; p.ws = (tp.p2 >> 20) & 1;
+    p.stages = (tp.p2 >> 16) & 15; p.ws = (tp.p2 >> 20) & 1; p.kg = (tp.p2 >> 21) & 1;
     tp.p2 &= 0xffff;
     p.tiles_k = K / p.tn;
     p.tiles = (NCO / p.tm) * p.tiles_k;
@@ -724,6 +775,7 @@ static bool launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
   const dim3 grid_x((p.splits >= 8 ? (unsigned)(p.tiles * ((p.splits + 7) / 8) * 8) : (unsigned)(8 * ((p.tiles + share - 1) / share))) + nf8);
   const dim3 grid_dma = xcd_on ? grid_x : grid;
   static const int use_dma = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+  static const int wg_abl = creid_ablation_env("CREID_WGRAD_ABL");   // 1: no MFMA, 2: no DMA after the first k-tile, 4: no fragment reads either
   static const int stages_env = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
   static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
   const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0 && stem_dma;
@@ -731,18 +783,28 @@ static bool launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
     static const int use_ws_env = [] { const char* e = getenv("CREID_WGRAD_WS"); return e ? atoi(e) : 0; }();
     const int use_ws = p.ws ? 1 : use_ws_env;
     const int stages = (p.stages >= 2 && p.stages <= 4) ? p.stages : stages_env;
-    if (use_ws && !stem_geom)
+    static const int kg_env = [] { const char* e = getenv("CREID_WGRAD_KG"); return e ? atoi(e) : 0; }();
+    const bool kg2 = (p.kg || kg_env == 2) && !use_ws && !stem_geom;
+    constexpr bool kg3_fits = 2 * 3 * (TM + TN) * 128 <= 160 * 1024;
+    if (kg2 && stages >= 3 && kg3_fits) {
+      if constexpr (kg3_fits)
+        hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 3, false, 2>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
+                           (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
+    } else if (kg2)
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, false, 2>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
+    else if (use_ws && !stem_geom)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, true>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin);
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
     else if (stages == 2)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin);
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
     else if (stages == 3)
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 3>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin);
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
     else
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 4>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin);
+                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
     return fin.partial != nullptr;
   }
   else if (dtype == CREID_BF16)

@@ -693,3 +693,40 @@ def test_whole_network_gradient_error_is_at_the_fp32_noise_floor():
     worst_t = max((float((g32[n] - g64[n]).norm() / (g64[n].norm() + 1e-30)), n) for n in names)
     print("worst tensor: HIP", worst, " torch fp32", worst_t)
     assert worst[0] < 10 * worst_t[0] + 1e-3, (worst, worst_t)
+
+
+@pytest.mark.parametrize("case", [(8, 16, 8, 256, 256, 3, 1, 128, 64, 2, 0), (8, 16, 8, 256, 1024, 1, 1, 128, 64, 3, 0),
+                                  (8, 16, 8, 512, 512, 3, 1, 128, 128, 1, 0), (4, 64, 32, 64, 64, 3, 1, 64, 64, 5, 0),
+                                  (8, 32, 16, 128, 128, 3, 2, 64, 128, 2, 3), (3, 10, 6, 128, 256, 1, 1, 128, 64, 1, 3),
+                                  (8, 32, 16, 512, 128, 1, 1, 128, 64, 4, 3)])
+def test_wgrad_two_k_groups_matches_fp64(case):
+    """wgrad_bf16_dma_kernel<.., KG = 2> (plan word bit 21: two k-groups of four waves share an output tile, each over half of
+    the split's pixel range, accumulators merged through LDS) against the fp64 product of the same bf16 operands and against
+    the one-group kernel: uneven halves, ranges shorter than one k-step per group, odd image sizes (non-linear gather), stride 2
+    and the 3-deep ring included.  Same tolerance as the one-group kernel's case table (fp32 accumulation, another grouping)."""
+    import ctypes as C
+    from centroids_reid_amd import layers as ly, _lib as L
+    B, H, W, cin, cout, k, stride, tm, tn, splits, depth = case
+    lib = L.lib()
+    pad = k // 2
+    rng = np.random.default_rng(sum(case))
+    x = torch.from_numpy(rng.standard_normal((B, H, W, cin)).astype(np.float32)).to(torch.bfloat16).cuda()
+    d, oh, ow = ly.conv_desc(B, H, W, cin, cout, k, stride, pad)
+    dy = torch.from_numpy(rng.standard_normal((B, oh, ow, cout)).astype(np.float32)).to(torch.bfloat16).cuda()
+    M, K = B * oh * ow, k * k * cin
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (cout, cin, k, k), dy.permute(0, 3, 1, 2).double(),
+                                      stride=stride, padding=pad)
+    try:
+        lib.creid_tune_clear()
+        one = ly.conv2d_wgrad(x, dy, k, stride, pad)
+        lib.creid_tune_set(0, M, cout, K, stride << 1, tm, tn, splits | (1 << 21) | (depth << 16))
+        two = ly.conv2d_wgrad(x, dy, k, stride, pad)
+        again = ly.conv2d_wgrad(x, dy, k, stride, pad)
+    finally:
+        lib.creid_tune_clear()
+        L.load_tuned_plans()
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((two.double() - ref).abs().max()) <= 2e-5 * scale + 1e-4, "two k-groups vs fp64"
+    assert float((two - one).abs().max()) <= 2e-5 * scale + 1e-4, "two k-groups vs one"
+    assert torch.equal(two, again), "fixed summation order: run-to-run identical"

@@ -28,6 +28,7 @@ ap.add_argument("--merge", default=None, help="existing plan file whose entries 
 ap.add_argument("--fwd-only", action="store_true",
                 help="eval-mode shapes (embedding batch sizes): forward with the folded BatchNorm epilogue only, incl. the "
                      "256-row tile variant (plan kind 3)")
+ap.add_argument("--wgrad-only", action="store_true", help="re-measure the weight-gradient plans only (forward / data-gradient entries of --merge are kept)")
 args = ap.parse_args()
 lib = L.lib()
 B = args.batch
@@ -112,6 +113,22 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
             cands.append((sc, (tm, tn, sp)))
             if sc < best[0]:
                 best = (sc, (tm, tn, sp))
+    # two k-groups per workgroup (512 threads, plan word bit 21): half the workgroups for the same wave count, half the partials
+    for tm, tn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+        if cout % tm or K % tn or cin < tn:
+            continue
+        tiles = (cout // tm) * (K // tn)
+        for sp in SPLITS:
+            if not (96 <= tiles * sp <= 800) or sp > M // 128:
+                continue
+            for depth in (0, 3):
+                if depth == 3 and 2 * 3 * (tm + tn) * 128 > 160 * 1024:
+                    continue
+                word = sp | (1 << 21) | (depth << 16)
+                lib.creid_tune_set(0, M, cout, K, s << 1, tm, tn, word)
+                sc, _, _ = wgrad_score()
+                if sc < best[0]:
+                    best = (sc, (tm, tn, word))
     # ring depth 3 / producer-consumer split on the three best (tile, split) choices (plan word: splits | depth<<16 | ws<<20)
     for sc0, (tm, tn, sp) in sorted(cands)[:3]:
         for extra in ((3 << 16), (1 << 20)):
@@ -124,7 +141,12 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
     lib.creid_tune_clear()
     if best[1] is not None and best[0] < 0.97 * base:
         plans.append({"kind": 0, "key": [M, cout, K, s << 1], "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2), "layer": name})
-    log.append(f"wgrad {name:28s} x{cnt} rule {base:6.1f} (partials {bp:5.1f} + reduce {br:5.1f})  best {best[0]:6.1f} {best[1]}")
+    bw = best[1][2] if best[1] else 0
+    log.append(f"wgrad {name:28s} x{cnt} rule {base:6.1f} (partials {bp:5.1f} + reduce {br:5.1f})  best {best[0]:6.1f} "
+               f"{best[1][:2] if best[1] else None} splits {bw & 0xffff} depth {(bw >> 16) & 15} ws {(bw >> 20) & 1} kg2 {(bw >> 21) & 1}")
+    if args.wgrad_only:
+        print(log[-1], flush=True)
+        continue
 
     # ---------------- forward and data gradient
     # the data gradient as the training schedule runs it: with the next BatchNorm-backward's column sums in the epilogue
