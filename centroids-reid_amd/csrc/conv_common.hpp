@@ -34,6 +34,8 @@ struct IGemmGeom {
   const float* epi_scale;   // nullable: per-output-channel affine y = acc * scale + shift applied to the fp32 accumulators --
   const float* epi_shift;   // eval-mode BatchNorm (running statistics are constants) folded into the convolution
   int epi_relu;             // ReLU after the affine and after "+ add_src" (the block's residual) when that is given
+  int abl;                  // timing-only ablation bits (CREID_IGEMM_ABL, producer/consumer kernel): 1 no MFMA, 2 no DMA after the
+                            // first k-tile, 4 no fragment reads, 8 no copy-out stores -- results are WRONG when set
 };
 
 static inline void igemm_finish_geom(IGemmGeom& g) {
@@ -45,6 +47,7 @@ static inline void igemm_finish_geom(IGemmGeom& g) {
   g.epi_scale = nullptr;
   g.epi_shift = nullptr;
   g.epi_relu = 0;
+  g.abl = 0;
 }
 
 // Source pixel of output row (oy, ox) under tap (r, s); returns false when it falls outside.
