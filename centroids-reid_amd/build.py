@@ -34,8 +34,8 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src: str, obj: str, verbose: bool):
-    cmd = [hipcc(), *FLAGS, "-c", src, "-o", obj]
+def _compile(src: str, obj: str, verbose: bool, extra=()):
+    cmd = [hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -63,7 +63,15 @@ def _compile(src: str, obj: str, verbose: bool):
         print("\n".join(other), file=sys.stderr)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, ablation: bool = False) -> str:
+    """ablation=True: the timing-ablation build (CREID_IGEMM_ABL / CREID_WGRAD_ABL switches compiled into the k-loops) as
+    lib/libcreid_hip_abl.so, for tools/debug/*_abl.py via CREID_LIB_PATH; never loaded by default."""
+    if ablation:
+        return _build(os.path.join(LIBDIR, "obj_abl"), os.path.join(LIBDIR, "libcreid_hip_abl.so"), force, verbose, ("-DCREID_ABL_BUILD=1",))
+    return _build(OBJDIR, LIB, force, verbose, ())
+
+
+def _build(OBJDIR: str, LIB: str, force: bool, verbose: bool, extra) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
@@ -75,7 +83,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             jobs.append((s, o))
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-            for f in [ex.submit(_compile, s, o, verbose) for s, o in jobs]:
+            for f in [ex.submit(_compile, s, o, verbose, extra) for s, o in jobs]:
                 f.result()
     if jobs or _stale(LIB, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
@@ -88,4 +96,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))

@@ -35,8 +35,16 @@ struct IGemmGeom {
   const float* epi_shift;   // eval-mode BatchNorm (running statistics are constants) folded into the convolution
   int epi_relu;             // ReLU after the affine and after "+ add_src" (the block's residual) when that is given
   int abl;                  // timing-only ablation bits (CREID_IGEMM_ABL, producer/consumer kernel): 1 no MFMA, 2 no DMA after the
-                            // first k-tile, 4 no fragment reads, 8 no copy-out stores -- results are WRONG when set
+                            // first k-tile, 4 no fragment reads, 8 no copy-out stores -- results are WRONG when set.  Only the
+                            // ablation build (build.py --ablation -> libcreid_hip_abl.so) looks at them
 };
+
+// The switches cost 0.07 ms per step when compiled into the k-loops (same-box A/B), so the shipped library folds them away.
+#ifdef CREID_ABL_BUILD
+#define CREID_ABL_ON(word, bits) ((word) & (bits))
+#else
+#define CREID_ABL_ON(word, bits) 0
+#endif
 
 static inline void igemm_finish_geom(IGemmGeom& g) {
   g.inv_ohow = 1.0f / (float)(g.OH * g.OW);

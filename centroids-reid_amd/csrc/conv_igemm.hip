@@ -730,7 +730,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
     typedef const void __attribute__((address_space(1)))* gptr_t;
     typedef void __attribute__((address_space(3)))* lptr_t;
     auto issue = [&](int t, int buf) {
-      if ((g.abl & 2) && t > 0) return;
+      if (CREID_ABL_ON(g.abl, 2) && t > 0) return;
       const int tap = (t * BK) >> g.log2span;
       if (tap != cur_tap) {
         cur_tap = tap;
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
         }
       };
       auto mma = [&](int sl) {
-        if (g.abl & 1) return;
+        if (CREID_ABL_ON(g.abl, 1)) return;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[sl][i]),
                                                                 __builtin_bit_cast(bf16x8, b[sl][j]), acc[i][j], 0, 0, 0);
       };
-      if (g.abl & 4) continue;
+      if (CREID_ABL_ON(g.abl, 4)) continue;
       load_frags(0, 0);
       __builtin_amdgcn_sched_barrier(0);
       load_frags(1, 1); mma(0);
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
           }
         }
       }
-      if (!(g.abl & 8)) *reinterpret_cast<uint4*>(out + off) = v;
+      if (!CREID_ABL_ON(g.abl, 8)) *reinterpret_cast<uint4*>(out + off) = v;
       if (bx) {
         uint4 xv = pre_x[i % NPRE], av = pre_a[i % NPRE];        // (NPRE == NIT whenever bx can be non-null)
         unsigned mb = pre_m[i % NPRE];
@@ -1182,7 +1182,11 @@ static int ws_stages_env() {
 static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt, void* out, const void* add_src,
                         float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
                         const WRedJob* wred_in = nullptr) {
+#ifdef CREID_ABL_BUILD
   static const int abl_env = creid_ablation_env("CREID_IGEMM_ABL");
+#else
+  const int abl_env = 0;
+#endif
   IGemmGeom g = g_in;
   g.abl = abl_env;
   WRedJob wred{};

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(WS ? 512 : 256 * KG, (KG * NS * (TM + TN) * 128 <= 
     }
   }
   auto issue = [&](int mb, int buf) {
-    if ((abl & 2) && mb != m_begin) return;                      // timing ablation: only the first k-tile is fetched
+    if (CREID_ABL_ON(abl, 2) && mb != m_begin) return;                      // timing ablation: only the first k-tile is fetched
     unsigned short* la = smem + buf * STAGE + wave * 512;
     unsigned short* lb = smem + buf * STAGE + TILE_A + wave * 512;
     if (linear) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(WS ? 512 : 256 * KG, (KG * NS * (TM + TN) * 128 <= 
       s16x8 a[IM], b[JN];                                                                                \
       _Pragma("unroll") for (int i = 0; i < IM; ++i) a[i] = __builtin_shufflevector(al[S][i], ah[S][i], 0, 1, 2, 3, 4, 5, 6, 7); \
       _Pragma("unroll") for (int j = 0; j < JN; ++j) b[j] = __builtin_shufflevector(bl[S][j], bh[S][j], 0, 1, 2, 3, 4, 5, 6, 7); \
-      if (!(abl & 1)) {                                                                                  \
+      if (!CREID_ABL_ON(abl, 1)) {                                                                                 \
       _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                     \
         _Pragma("unroll") for (int j = 0; j < JN; ++j)                                                   \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),          \
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(WS ? 512 : 256 * KG, (KG * NS * (TM + TN) * 128 <= 
       }                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
     }
-    if (abl & 4) return;                                                                                 
+    if (CREID_ABL_ON(abl, 4)) return;                                                                                 
     WG_LOAD(0, 0)
     WG_LOAD(1, 1) WG_MMA(0, NRD)
     WG_LOAD(2, 0) WG_MMA(1, NRD)
@@ -775,7 +775,11 @@ static bool launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
   const dim3 grid_x((p.splits >= 8 ? (unsigned)(p.tiles * ((p.splits + 7) / 8) * 8) : (unsigned)(8 * ((p.tiles + share - 1) / share))) + nf8);
   const dim3 grid_dma = xcd_on ? grid_x : grid;
   static const int use_dma = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+#ifdef CREID_ABL_BUILD
   static const int wg_abl = creid_ablation_env("CREID_WGRAD_ABL");   // 1: no MFMA, 2: no DMA after the first k-tile, 4: no fragment reads either
+#else
+  const int wg_abl = 0;                                              // (the switches exist in the ablation build only: conv_common.hpp)
+#endif
   static const int stages_env = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
   static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
   const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0 && stem_dma;

@@ -1,8 +1,10 @@
 """Timing ablation of the producer/consumer igemm kernel (run on the GPU box, one process per CREID_IGEMM_ABL value): per
 distinct convolution of the B = 64 step, the training forward (BatchNorm statistics epilogue) and the plain data gradient with
 the shipped launch plans, 10 back-to-back launches in a graph.  Shapes the plans route to the four-wave DMA kernel do not react."""
+import os
 import sys
 import torch
+os.environ.setdefault("CREID_LIB_PATH", "centroids-reid_amd/lib/libcreid_hip_abl.so")   # python centroids-reid_amd/build.py --ablation
 sys.path.insert(0, ".")
 from centroids_reid_amd import layers as ly
 from centroids_reid_amd.bench_train import conv_shapes

@@ -1,8 +1,10 @@
 """Timing ablation of the weight-gradient partial-tile kernel (run on the GPU box, one process per CREID_WGRAD_ABL value):
 per distinct convolution of the B = 64 step, the partial-tile launch alone (no split reduce), 10 back-to-back launches in a graph."""
 import ctypes as C
+import os
 import sys
 import torch
+os.environ.setdefault("CREID_LIB_PATH", "centroids-reid_amd/lib/libcreid_hip_abl.so")   # python centroids-reid_amd/build.py --ablation
 sys.path.insert(0, ".")
 from centroids_reid_amd import layers as ly, _lib as L
 from centroids_reid_amd.bench_train import conv_shapes
