@@ -243,6 +243,33 @@ def run_embed(arch="resnet50", B=128, H=256, W=128, steps=20, warmup=3, insitu=N
     return res
 
 
+def run_embed_ranks(world, barrier_sync, B=128, H=256, W=128, steps=20, warmup=3):
+    """Embeddings/s of the whole job (north_star's multi-GPU target is quoted in embeddings/s): every rank runs the eval-mode
+    embedding forward on its own resident batch -- the partitioning of validation_step, no collective on the data path --
+    between two barriers; the slowest rank's time counts.  Called by EVERY rank."""
+    eb = EmbedBench("resnet50", B, H, W)
+    for _ in range(warmup):
+        eb.graph.replay()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eb.graph.replay()
+    barrier_sync(world)
+    tmax = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item()) / steps
+    ok = bool(torch.isfinite(eb.emb).all())
+    del eb
+    torch.cuda.empty_cache()
+    assert ok, "non-finite embeddings in the benchmark"
+    return {"metric": "embed_images_per_sec", "value": world * B / dt, "unit": "images/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "dtype": "bf16", "hip_graph": True, "scaling": "weak",
+            "config": {"workload": f"resnet50 {H}x{W} eval-mode embedding forward (validation_step: backbone + GAP + BNNeck), batch {B} "
+                                   "per rank, BatchNorm folded into the conv epilogues; max over ranks between two barriers",
+                       "batch_per_rank": B, "parallelism": f"dp{world}"}}
+
+
 def hbm_stage_rates(time_kernel, B, H, W):
     """Achieved GB/s of the bandwidth-bound passes of the step on their largest instance (layer1 block output,
     [B*H/4*W/4, 256] bf16): BN apply (+residual, ReLU), BN backward (reduce + finalize + apply), and Adam over the
@@ -682,6 +709,10 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
                 "resnet50_ibn_a", 256, 320, 320, steps=5, warmup=2,
                 label="ResNet50-IBN-a 320x320 eval-mode embedding forward, batch 256 (embedding half of BASELINE configs[3], "
                       "TEST.IMS_PER_BATCH 256)")
+    if ddp and arch == "resnet50" and not f32 and (H, W) == (256, 128) and os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
+        er = run_embed_ranks(world, barrier_sync)            # every rank takes part; rank 0 reports
+        if rank == 0:
+            res["embed_ranks" if "embed" in res else "embed"] = er
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
             "ms_per_step": dt / args.steps * 1e3, "dtype": "f32" if f32 else "bf16",
             "config": {"workload": ("ResNet50" if arch == "resnet50" else arch) +
