@@ -90,6 +90,7 @@ SIGNATURES = {
     "creid_stem_conv_wgrad_workspace_bytes": (_sz, [_i64, _i64, _i64, C.c_int]),
     "creid_stem_conv_wgrad": (C.c_int, [_i64, _i64, _i64, _p, _p, _p, C.c_int, _p, _sz, C.c_int, _p]),
     "creid_image_to_nhwc4_pad": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
+    "creid_augment_u8": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64] + [C.c_float] * 9 + [C.c_int32, C.c_int32, _p, _p]),
     "creid_weight_prep": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),
     "creid_weight_prep_entry_bytes": (_i64, []),
     "creid_weight_prep_multi": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),

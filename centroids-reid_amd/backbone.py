@@ -408,6 +408,17 @@ class BackboneEngine:
                                                  L.ptr(residual), 1 if relu else 0, self.dt, st), "conv2d_fwd_affine")
         return a, oh, ow
 
+    def _stem_operand(self, x, B, H, W):
+        """The stem convolution's operand: zero-padded NHWC4 [B, H + 8, W + 6, 4] in the compute dtype.  An fp32 NCHW batch
+        goes through the layout pass; a transforms.StemOperand (the device-side input transforms wrote that layout directly)
+        is used as it is."""
+        if not isinstance(x, torch.Tensor):
+            assert x.xpad.dtype == self.dtype and tuple(x.xpad.shape) == (B, H + 8, W + 6, 4), "stem operand of another dtype / shape"
+            return x.xpad
+        xpad = self._empty(B, H + 8, W + 6, 4)
+        L.check(L.lib().creid_image_to_nhwc4_pad(L.ptr(x), B, H, W, self.dt, L.ptr(xpad), L.stream()), "image_pad")
+        return xpad
+
     def _forward_eval_folded(self, x_nchw, want_base_out):
         """validation_step / inference forward (modelling/bases.py:169-177, inference/inference_utils.py:104-113): 53
         convolutions with their BatchNorm folded in + pad, max-pool, GAP -- no statistics, no separate normalisation
@@ -415,8 +426,7 @@ class BackboneEngine:
         lib, st = L.lib(), L.stream()
         B, _, H, W = x_nchw.shape
         self.fold_bn()
-        xpad = self._empty(B, H + 8, W + 6, 4)
-        L.check(lib.creid_image_to_nhwc4_pad(L.ptr(x_nchw), B, H, W, self.dt, L.ptr(xpad), st), "image_pad")
+        xpad = self._stem_operand(x_nchw, B, H, W)
         H1, W1 = H // 2, W // 2
         y0 = self._empty(B * H1 * W1, 64)
         L.check(lib.creid_stem_conv_fwd_affine(B, H, W, L.ptr(xpad), L.ptr(self.stem.w_krsc), L.ptr(y0), L.ptr(self.stem.fold),
@@ -533,9 +543,13 @@ class BackboneEngine:
         return a, mean, invstd
 
     # ---- forward
-    def forward(self, x_nchw: torch.Tensor, training: bool, want_base_out: bool = False):
-        L.require_gpu(x_nchw)
-        assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3
+    def forward(self, x_nchw, training: bool, want_base_out: bool = False):
+        """x_nchw: fp32 [B, 3, H, W] on the GPU, or a transforms.StemOperand (same batch, already in the stem's layout)."""
+        if isinstance(x_nchw, torch.Tensor):
+            L.require_gpu(x_nchw)
+            assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3
+        else:
+            L.require_gpu(x_nchw.xpad)
         if self.weights_dirty or self._wsig != self._weight_signature():
             self.prep_weights()
         lib, st = L.lib(), L.stream()
@@ -548,8 +562,7 @@ class BackboneEngine:
                 self._pending_steps = torch.zeros((), dtype=torch.long, device=self.device)
             self._pending_steps += 1
         # stem
-        xpad = self._empty(B, H + 8, W + 6, 4)
-        L.check(lib.creid_image_to_nhwc4_pad(L.ptr(x_nchw), B, H, W, self.dt, L.ptr(xpad), st), "image_pad")
+        xpad = self._stem_operand(x_nchw, B, H, W)
         H1, W1 = H // 2, W // 2
         M0 = B * H1 * W1
         x0 = self._empty(M0, 64)

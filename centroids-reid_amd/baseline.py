@@ -47,7 +47,8 @@ class Baseline(nn.Module):
 
     def forward(self, x):
         eng = self.engine
-        x = x.contiguous().float()
+        if isinstance(x, torch.Tensor):                 # (a transforms.StemOperand passes through: already the stem's layout)
+            x = x.contiguous().float()
         if self.training and torch.is_grad_enabled():
             base_out, feat = bb._BackboneFn.apply(x, self.base.conv1.weight, eng, self.return_base_out)
             if base_out.numel() == 0:

@@ -295,8 +295,18 @@ def hbm_stage_rates(time_kernel, B, H, W):
     hyper = torch.tensor([3.5e-4, 1.0, 0.1, 0.03], device=dev)
     t_adam = time_kernel(lambda: L.check(lib.creid_adam_step_dev(L.ptr(p), L.ptr(gr), L.ptr(m1), L.ptr(v1), n, L.ptr(hyper),
                                                                     0.9, 0.999, 1e-8, 5e-4, 1.0, L.stream()), "adam"), 10)
+    # input transforms (flip, pad-crop, ToTensor, Normalize, RandomErasing) of a uint8 batch, written straight into the stem's
+    # padded NHWC4 operand: 3 bytes in, 8 out per pixel (+ the zero border)
+    from .transforms import DeviceTransform
+    tr = DeviceTransform((H, W), [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], is_train=True, padding=10)
+    Ba = 4 * B                                                   # a batch this small is a 10 us kernel: time four of them at once
+    u8 = torch.randint(0, 256, (Ba, H, W, 3), dtype=torch.uint8, device=dev)
+    prm = torch.from_numpy(tr.draw(Ba)).to(dev)
+    t_aug = time_kernel(lambda: tr(u8, prm, layout="stem", dtype=torch.bfloat16), 20)
+    aug_bytes = Ba * H * W * 3 + Ba * (H + 8) * (W + 6) * 4 * 2
     e = M * Cc * 2
-    return {"bn2d_apply_GBs": 3 * e / (t_apply * 1e-3) / 1e9,                 # read x, residual; write y
+    return {"augment_u8_GBs": aug_bytes / (t_aug * 1e-3) / 1e9, "augment_u8_us_per_batch": t_aug * 1e3 / 4,
+            "bn2d_apply_GBs": 3 * e / (t_apply * 1e-3) / 1e9,                 # read x, residual; write y
             "bn2d_bwd_GBs": (3 * e + 3 * e + 2 * e) / (t_bwd * 1e-3) / 1e9,     # reduce: x,g,act; apply: x,g,act -> dx,gm
             "adam_GBs": 7 * n * 4 / (t_adam * 1e-3) / 1e9,                     # read p,g,m,v; write p,m,v
             "peak_GBs": 8000.0}

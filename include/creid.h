@@ -15,7 +15,9 @@
  *   - sizes / leading dimensions are int64_t element counts, row-major;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *   - returns 0 on success, <0 for an argument error (CREID_E_*), >0 = hipError_t of the
- *     launch; never throws, never synchronises the stream, re-entrant, no global state.
+ *     launch; never throws, never synchronises the stream, re-entrant.  Process-global state is limited to immutable
+ *     kernel handles / zero pages and the optional launch-plan registry (creid_tune_set / creid_tune_clear below: host-side,
+ *     written before the first launch, read-only afterwards).
  */
 #ifndef CREID_H
 #define CREID_H
@@ -138,8 +140,9 @@ int creid_stream_finalize(const int32_t* npos, const uint32_t* hist, int64_t m, 
                           double* ap, int32_t* first, void* stream);
 
 /* Measured launch plans (optional).  kind 0 = weight gradient: key (M = batch*out_h*out_w, out_c, K = kh*kw*in_c, 0) ->
- * (tile rows 64|128, tile cols 64|128, pixel splits); kind 1 = implicit-GEMM forward / data gradient: key (GEMM rows M,
- * GEMM cols N, K, transposed 0|1) -> (N tile 64|128, LDS ring depth 2|3|4, 0).  A plan only selects among kernel variants
+ * (tile rows 64|128, tile cols 64|128, pixel splits | ring depth << 16 | producer/consumer waves << 20 | two k-groups << 21);
+ * kind 1 = implicit-GEMM forward / data gradient: key (GEMM rows M, GEMM cols N, K, transposed 0|1 | stride << 1) ->
+ * (N tile 64|128, LDS ring depth 2|3|4, kernel 0 producer/consumer | 1 four-wave DMA | 2 persistent 1x1 | 3 256-row tiles).  A plan only selects among kernel variants
  * the library already has; shapes without an entry use the built-in rules.  Not thread-safe against running launches:
  * register before the first convolution (the Python binding does it at load time from tuned_plans.json). */
 int creid_tune_set(int32_t kind, int64_t a, int64_t b, int64_t c, int64_t d, int32_t p0, int32_t p1, int32_t p2);
@@ -424,6 +427,17 @@ int creid_stem_conv_wgrad(int64_t batch, int64_t H, int64_t W, const void* xpad,
                           float* dw_oihw, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);
 int creid_image_to_nhwc4_pad(const float* x_nchw, int64_t B, int64_t H, int64_t W, int dtype, void* xpad,
                              void* stream);
+/* Input transforms after the Resize (datasets/transforms/build.py:16-31, datasets/transforms/random_erasing.py:31-55) on a whole
+ * uint8 batch: RandomHorizontalFlip -> Pad(pad, 0) -> RandomCrop(H, W) -> ToTensor -> Normalize -> RandomErasing, as a pure
+ * function of the pixels and of the host-made draws.  src_hwc: uint8 [B, H, W, 3]; params: int32 [B, 8] =
+ * {flip, crop_top, crop_left, erase, x1, y1, h, w} (crop offsets in the (H + 2 pad) x (W + 2 pad) padded frame; the erased block
+ * is rows x1..x1+h, columns y1..y1+w of the output and receives (erase0, erase1, erase2) AS IS -- the reference writes
+ * PIXEL_MEAN into the normalised tensor); params NULL = the test transform (ToTensor + Normalize only, pad must be 0).
+ * layout 0: fp32 NCHW [B, 3, H, W] (dtype must be CREID_F32); layout 1: the stem's operand, zero-padded NHWC4
+ * [B, H + 8, W + 6, 4] in `dtype` (f32 | bf16), identical to creid_image_to_nhwc4_pad of the layout-0 result. */
+int creid_augment_u8(const uint8_t* src_hwc, const int32_t* params, int64_t B, int64_t H, int64_t W, int64_t pad,
+                     float mean0, float mean1, float mean2, float std0, float std1, float std2, float erase0, float erase1,
+                     float erase2, int32_t layout, int32_t dtype, void* out, void* stream);
 /* fp32 OIHW master weights -> compute-dtype [O][r][s][I] (forward) and [I][r][s][O] (dgrad, nullable). */
 int creid_weight_prep(const float* w_oihw, int64_t O, int64_t I, int64_t kh, int64_t kw, int dtype,
                       void* w_krsc, void* w_crsk, void* stream);

@@ -300,7 +300,7 @@ def gen_backbone(ref, name, arch, B, H, W):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.load()
-    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
+    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed", "transforms")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
     if "eval" in which:
         gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
         gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
@@ -508,3 +508,41 @@ if __name__ == "__main__" and "surface_r2" in sys.argv[1:]:
 if __name__ == "__main__" and "ibn320" in sys.argv[1:]:
     # BASELINE configs[3] input size: ResNet50-IBN-a at 320 x 320 (20 x 20 final maps), batch 2
     gen_backbone(ref_import.load(), "backbone_r50ibn_2x320x320", "resnet50_ibn_a", 2, 320, 320)
+
+
+def gen_transforms():
+    """Input transforms: the reference's own RandomErasing (datasets/transforms/random_erasing.py, imported from the read-only
+    reference tree; it needs only `math` and `random`) applied to normalised tensors made with torch's CPU ops from random uint8
+    images under explicit flip / crop draws.  torchvision is absent from this image, so flip / pad / crop / ToTensor / Normalize
+    are spelled with the torch / numpy ops torchvision documents (see oracle/transforms_oracle.py: PARITY UNPINNED for those);
+    the erasing draws and the erased tensor are the reference's."""
+    import importlib.util
+    import random
+    spec = importlib.util.spec_from_file_location("ref_random_erasing", os.path.join(ref_import.REF, "datasets", "transforms", "random_erasing.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mean, std, pad = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], 10
+    rng = np.random.default_rng(71)
+    rec = {"mean": np.array(mean, np.float64), "std": np.array(std, np.float64), "pad": np.int64(pad)}
+    cases = [(64, 32, 1.0, s) for s in range(5)] + [(64, 32, 0.5, s) for s in (10, 12, 15)] + [(256, 128, 1.0, 3), (33, 17, 1.0, 5)]
+    for i, (H, W, prob, seed) in enumerate(cases):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        flip, top, left = int(rng.integers(0, 2)), int(rng.integers(0, 2 * pad + 1)), int(rng.integers(0, 2 * pad + 1))
+        im = img[:, ::-1] if flip else img
+        im = np.pad(im, ((pad, pad), (pad, pad), (0, 0)))[top:top + H, left:left + W]
+        t = torch.from_numpy(np.ascontiguousarray(im)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)      # ToTensor
+        t = t.clone().sub_(torch.tensor(mean)[:, None, None]).div_(torch.tensor(std)[:, None, None])                 # Normalize
+        before = t.clone()
+        random.seed(seed)
+        out = mod.RandomErasing(probability=prob, mean=mean)(t)
+        state_after = random.random()                 # the next value of the stream: pins the NUMBER of draws consumed
+        rec[f"c{i}_img"] = img; rec[f"c{i}_draw"] = np.array([flip, top, left, seed], np.int64); rec[f"c{i}_prob"] = np.float64(prob)
+        rec[f"c{i}_out"] = out.numpy().copy(); rec[f"c{i}_next"] = np.float64(state_after)
+        rec[f"c{i}_changed"] = np.int64(int((out != before).sum()))
+    rec["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "transforms"), **rec)
+    print(f"[transforms] {len(cases)} cases, erased elements: {[int(rec[f'c{i}_changed']) for i in range(len(cases))]}")
+
+
+if __name__ == "__main__" and "transforms" in sys.argv[1:]:
+    gen_transforms()
