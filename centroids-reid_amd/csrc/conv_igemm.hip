@@ -26,6 +26,8 @@ bool wgrad_make_reduce_job(const creid_conv_desc* d, int dtype, const void* ws, 
 int wgrad_reduce_job_launch(const WRedJob& j, hipStream_t s);
 // defined in conv_stream.hip
 int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, hipStream_t s);
+int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, const void* add_src,
+                   const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, hipStream_t s);
 
 // Out-of-image taps read this 128-byte page of zeros instead of selecting zeros per dword (saves 3 VALU
 // per load in the gather path).
@@ -1200,10 +1202,10 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   // measured plan for this GEMM shape (tune.hpp): N tile and ring depth of the producer/consumer kernel; the 4th key slot is
   // transposed | stride << 1 (a stride-2 and a stride-1 3x3 layer can share M, N, K but not their gather pattern)
   TunePlan tp;
-  int tuned_stages = 0, tuned_dma = 0, tuned_stream = 0, tuned_bm256 = 0;
+  int tuned_stages = 0, tuned_dma = 0, tuned_stream = 0, tuned_bm256 = 0, tuned_stream2 = 0;
   if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, g.transposed | (g.stride << 1), tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
-    bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2; tuned_bm256 = tp.p2 == 3;
+    bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2; tuned_bm256 = tp.p2 == 3; tuned_stream2 = tp.p2 == 4;
   }
   // persistent streaming kernel for the small-K 1x1 stride-1 forward convolutions (conv_stream.hip): plan kind 2, or
   // CREID_STREAM1X1=1 for every GEMM it covers
@@ -1214,6 +1216,18 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
                            g.kw == 1 && g.check_bounds && !add_src && !bnred.x && !wred.ws && g.pitch == g.K && !g.epi_scale;
     if (plain_1x1 && (force_stream || tuned_stream)) {
       const int rc = launch_stream1x1(g.M, g.K, g.N, src, wgt, out, bn_part, s);
+      if (rc != CREID_E_SHAPE) return rc;
+    }
+    // second form (plan kind 4 / CREID_STREAM2=1): also the folded eval-mode epilogue with the block's residual
+    const char* f2 = getenv("CREID_STREAM2");
+    const int force2 = f2 ? atoi(f2) : 0;
+    const bool fwd_1x1 = dtype == CREID_BF16 && !g.transposed && g.K == (1 << g.log2span) && g.stride == 1 && g.pad == 0 &&
+                         g.kw == 1 && g.check_bounds && !bnred.x && !wred.ws && g.pitch == g.K && !g.add_compact && !g.add_mask &&
+                         !(bn_part && (g.epi_scale || add_src));
+    if (fwd_1x1 && (force2 || tuned_stream2)) {
+      // (plan: p1 = 2 -> widest column slab the LDS allows, 3 -> at most 128 columns, 4 -> 64)
+      const int cap = tuned_stream2 ? (tuned_stages == 3 ? 128 : (tuned_stages == 4 ? 64 : 0)) : 0;
+      const int rc = launch_stream2(g.M, g.K, g.N, src, wgt, out, bn_part, add_src, g.epi_scale, g.epi_shift, g.epi_relu, cap, s);
       if (rc != CREID_E_SHAPE) return rc;
     }
   }

@@ -237,3 +237,291 @@ int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void
 #undef CREID_ST_LAUNCH
   return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------ second form (round 3)
+// Same idea -- resident workgroups, weight slab in LDS once, A tiles streamed into a ring -- with the two things the first form
+// lacked (profiles/r02_stream1x1_experiment.md: it lost on wide outputs because 256 threads stored alone and the epilogue ran
+// serially after the MFMAs), and with the epilogues of the eval-mode forward:
+//   * all eight waves are alike: wave (wr, wc) multiplies rows wr * 32 .. + 31 of the 128-row tile against the 32-column blocks
+//     2 j + wc, stages them column-major (packed 8-byte LDS stores, read back through the transposing LDS read -- the copy-out of
+//     igemm_bf16_ws_kernel) and all 512 threads copy out;
+//   * everything a tile needs from memory is requested ONE TILE EARLIER and nothing is waited for inside the tile that issued
+//     it: the A rows of tile t + 2 and the residual chunks of tile t + 1 are loaded into registers at the top of tile t, the A
+//     registers of tile t + 1 (loaded a tile ago) go to the LDS ring there, and the finished 16-byte chunks of tile t - 1 are
+//     stored there.  The operands come through REGISTERS, not the LDS-DMA: with DMA writes in flight the compiler has to
+//     drain vmcnt before every LDS access of a wave that also loads and stores (it cannot tell which LDS bytes a DMA owns) --
+//     measured: every load and store then sat on the critical path (ablation: stores + 27, residual + 28, compute 32 of 77 us);
+//   * epilogues: BatchNorm column sums of the fp32 accumulators (training forward), or the folded eval-mode affine (+ ReLU)
+//     with the block's residual added in the copy-out (the arithmetic of igemm_bf16_ws_kernel: identical bits).
+// K = 64 or 128 (KCH = 1, 2); BN = 64 / 128 / 256 columns per workgroup (256 only for K = 64: LDS); RT = 2 ring slots.
+template <int BN, int KCH, int RT>
+__global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned short* __restrict__ src, int M, int K, int N,
+                                                                   const unsigned short* __restrict__ wgt,
+                                                                   unsigned short* __restrict__ out, float* __restrict__ bn_part,
+                                                                   const unsigned short* __restrict__ add_src,
+                                                                   const float* __restrict__ epi_scale,
+                                                                   const float* __restrict__ epi_shift, int epi_relu,
+                                                                   int tiles_m, int tiles_n, int abl) {
+  constexpr int TW = BN / 64;                          // 32-column blocks per wave
+  constexpr int HB = BN > 128 ? 128 : BN;              // columns staged / copied out at a time
+  constexpr int NH = BN / HB;
+  constexpr int CPT = 128 + 4;                         // staging pitch: [HB columns][128 rows + 4]
+  constexpr int CPR = HB / 8, NIT = (128 * CPR) / 512; // 16-byte chunks per row; chunks per thread and half
+  constexpr int W_ELEMS = KCH * BN * 64, TILE_ELEMS = KCH * 128 * 64, RING_ELEMS = RT * TILE_ELEMS, STAGE_ELEMS = HB * CPT;
+  constexpr int RED_ELEMS = 4 * 2 * BN * 2;            // fp32 [4 row waves][2][BN] in 2-byte units
+  static_assert(2 * (W_ELEMS + RING_ELEMS + STAGE_ELEMS + RED_ELEMS) <= 160 * 1024, "LDS budget");
+  static_assert(16 % CPR == 0 && RT == 2, "copy-out map / ring");
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[W_ELEMS + RING_ELEMS + STAGE_ELEMS + RED_ELEMS];
+  unsigned short* Ws = smem;                           // [KCH][BN][64]
+  unsigned short* ring = smem + W_ELEMS;               // [RT][KCH][128][64]
+  unsigned short* stage = ring + RING_ELEMS;           // [HB][CPT]
+  float* red = reinterpret_cast<float*>(stage + STAGE_ELEMS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave & 3, wc = wave >> 2;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int lr8 = lane >> 3, lcp = lane & 7;
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  const unsigned short* zpage = reinterpret_cast<const unsigned short*>(g_stream_zero_page);
+
+  const int groups = (int)gridDim.x / tiles_n;
+  const int tile_n = (int)blockIdx.x % tiles_n, wg_in_group = (int)blockIdx.x / tiles_n;
+  const int col0 = tile_n * BN;
+  const int n_iter = wg_in_group < tiles_m ? (tiles_m - 1 - wg_in_group) / groups + 1 : 0;
+  if (n_iter == 0) return;
+
+  // weight slab -> LDS, once (row r of k-chunk kc at [kc][r][64], 16-byte chunks XOR-swizzled by (r >> 1) & 7)
+  {
+    constexpr int NW = KCH * (BN / 8);
+    for (int i = wave; i < NW; i += 8) {
+      const int kc = i / (BN / 8), r = (i - kc * (BN / 8)) * 8 + lr8;
+      const uint4 v = *reinterpret_cast<const uint4*>(wgt + (int64_t)(col0 + r) * K + kc * 64 + lcp * 8);
+      *reinterpret_cast<uint4*>(Ws + (kc * BN + r) * 64 + ((lcp ^ ((r >> 1) & 7)) << 3)) = v;
+    }
+  }
+  // A tile of iteration `it`: KCH * 16 wave-loads of 8 rows x 128 B, two per wave and k-chunk, into registers ...
+  uint4 areg[KCH][2];
+  auto load_a = [&](int it) {
+    const int row0 = (wg_in_group + it * groups) * 128;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = (wave + 8 * u) * 8 + lr8, m = row0 + r;
+        // (branch-free: a row past M reads row M - 1 and is zeroed -- predicated loads would break the compiler's counted waits)
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (!CREID_ABL_ON(abl, 4)) v = *reinterpret_cast<const uint4*>(src + (int64_t)min(m, M - 1) * K + kc * 64 + lcp * 8);
+        areg[kc][u] = m < M ? v : make_uint4(0u, 0u, 0u, 0u);
+      }
+  };
+  // ... and from there into ring slot it % RT (same LDS image as the DMA kernels)
+  auto put_a = [&](int it) {
+    unsigned short* slot = ring + (it % RT) * TILE_ELEMS;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = (wave + 8 * u) * 8 + lr8;
+        *reinterpret_cast<uint4*>(slot + kc * (128 * 64) + r * 64 + ((lcp ^ ((r >> 1) & 7)) << 3)) = areg[kc][u];
+      }
+  };
+  // copy-out map of one half (see igemm_bf16_ws_kernel): lane = 16 g4 + 4 q4 + t4 owns row t4 of a row quad, one column octet
+  const int t4 = lane & 3, q4 = (lane >> 2) & 3, g4 = lane >> 4;
+  auto unit_of = [&](int i, int& rl, int& ch) {
+    const int Q = (wave + 8 * i) * 16 + g4 * 4 + q4;
+    ch = Q % CPR;
+    rl = 4 * (Q / CPR) + t4;
+  };
+  uint4 resn[NH][NIT];                                  // residual chunks of the NEXT tile (loaded one tile ahead)
+  uint4 outv[NH][NIT];                                  // finished chunks of the PREVIOUS tile (stored one tile late)
+  auto load_res = [&](int it) {
+    const int row0 = (wg_in_group + it * groups) * 128;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        int rl, ch;
+        unit_of(i, rl, ch);
+        const int rr = row0 + rl;
+        resn[h][i] = make_uint4(0u, 0u, 0u, 0u);
+        if (!CREID_ABL_ON(abl, 2)) resn[h][i] = *reinterpret_cast<const uint4*>(add_src + (int64_t)min(rr, M - 1) * N + col0 + h * HB + ch * 8);
+      }
+  };
+  auto store_out = [&](int it) {
+    const int row0 = (wg_in_group + it * groups) * 128;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        int rl, ch;
+        unit_of(i, rl, ch);
+        const int rr = row0 + rl;
+        if (rr < M && !CREID_ABL_ON(abl, 1)) *reinterpret_cast<uint4*>(out + (int64_t)rr * N + col0 + h * HB + ch * 8) = outv[h][i];
+      }
+  };
+
+  load_a(0);
+  put_a(0);                                                       // tile 0 is in the ring before the first barrier
+  if (n_iter > 1) load_a(1);
+  if (add_src) load_res(0);
+  float sc[TW], sh[TW];
+  if (epi_scale) {
+#pragma unroll
+    for (int j = 0; j < TW; ++j) { sc[j] = epi_scale[col0 + (2 * j + wc) * 32 + l31]; sh[j] = epi_shift[col0 + (2 * j + wc) * 32 + l31]; }
+  }
+  const bool relu_now = epi_relu && !add_src;
+
+  for (int it = 0; it < n_iter; ++it) {
+    const int tile_m = wg_in_group + it * groups;
+    __syncthreads();                                              // tile `it` is in the ring; everyone is done with tile it - 1
+    // first everything that CONSUMES loads issued a tile ago (whatever the wait before it, it is short) ...
+    if (it + 1 < n_iter) put_a(it + 1);                           // into the slot tile it - 1 just left
+    uint4 resc[NH][NIT];
+    if (add_src) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) resc[h][i] = resn[h][i];
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) asm volatile("" : "+v"(resc[h][i].x), "+v"(resc[h][i].y), "+v"(resc[h][i].z), "+v"(resc[h][i].w));
+    // ... then this tile's requests: nothing below waits for them before the next trip (loads first: the compiler guards the
+    // re-use of their destination registers with a full wait, which must not see the stores)
+    if (it + 2 < n_iter) load_a(it + 2);
+    if (add_src && it + 1 < n_iter) load_res(it + 1);
+    if (it > 0) store_out(it - 1);
+    f32x16 acc[TW];
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const unsigned short* At = ring + (it % RT) * TILE_ELEMS;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      const unsigned short* As = At + kc * (128 * 64);
+      const unsigned short* Bs = Ws + kc * BN * 64;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int chk = 2 * kk + kh;
+        const int r = wr * 32 + l31;
+        const s16x8 a = *reinterpret_cast<const s16x8*>(&As[r * 64 + ((chk ^ ((r >> 1) & 7)) << 3)]);
+        s16x8 b[TW];
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+          const int cc = (2 * j + wc) * 32 + l31;
+          b[j] = *reinterpret_cast<const s16x8*>(&Bs[cc * 64 + ((chk ^ ((cc >> 1) & 7)) << 3)]);
+        }
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[j]), acc[j], 0, 0, 0);
+      }
+    }
+    if (bn_part) {                                                // column sums of the fp32 accumulators (rows >= M are zero)
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[j][r]; s1 += v; s2 = fmaf(v, v, s2); }
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        const int cl = (2 * j + wc) * 32 + l31;
+        if (kh == 0) { red[(wr * 2 + 0) * BN + cl] = s1; red[(wr * 2 + 1) * BN + cl] = s2; }
+      }
+    }
+    if (CREID_ABL_ON(abl, 8)) continue;                           // (timing ablation: no staging / copy-out at all)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      if (h > 0) asm volatile("s_barrier" ::: "memory");          // the previous half has been read out of the staging area
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        if (((2 * j + wc) * 32) / HB != h) continue;              // (wave-uniform)
+        const int cl = (2 * j + wc) * 32 - h * HB + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rl = wr * 32 + 8 * q + 4 * kh;
+          float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
+          if (epi_scale) {
+            v0 = fmaf(v0, sc[j], sh[j]); v1 = fmaf(v1, sc[j], sh[j]); v2 = fmaf(v2, sc[j], sh[j]); v3 = fmaf(v3, sc[j], sh[j]);
+            if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          }
+          *reinterpret_cast<uint2*>(&stage[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+        }
+      }
+      __syncthreads();                                            // the half is staged (and `red` is complete)
+      if (h == 0 && bn_part) {
+        for (int i = tid; i < 2 * BN; i += 512) {
+          const int which = i / BN, cl = i - which * BN;
+          bn_part[((int64_t)tile_m * 2 + which) * N + col0 + cl] =
+              (red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl]) + (red[(2 * 2 + which) * BN + cl] + red[(3 * 2 + which) * BN + cl]);
+        }
+      }
+      u32x2 trlo[NIT], trhi[NIT];
+      {
+        const int sq = lane & 3, sj = (lane >> 2) & 3;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int Qs = (wave + 8 * i) * 16 + g4 * 4 + sq;
+          const unsigned addr = (unsigned)(uintptr_t)&stage[((Qs % CPR) * 8 + sj) * CPT + 4 * (Qs / CPR)];
+          asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                       : "=&v"(trlo[i]), "=&v"(trhi[i]) : "v"(addr), "i"(4 * CPT * 2) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) asm volatile("" : "+v"(trlo[i]), "+v"(trhi[i]));
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        uint4 v = make_uint4(trlo[i].x, trlo[i].y, trhi[i].x, trhi[i].y);
+        if (add_src) {
+          const uint4 a = resc[h][i];
+          unsigned* vw = &v.x; const unsigned* aw = &a.x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+            float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+            if (epi_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            vw[q] = f32x2_to_bf16x2_bits(lo, hi);
+          }
+        }
+        outv[h][i] = v;
+      }
+    }
+  }
+  store_out(n_iter - 1);
+}
+
+// Returns CREID_E_SHAPE when the GEMM is outside the kernel's scope (the caller then uses conv_igemm.hip's kernels).
+int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, const void* add_src,
+                   const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, hipStream_t s) {
+  if (K != 64 && K != 128) return CREID_E_SHAPE;
+  int bn = N >= 256 ? 256 : N;
+  if (K == 128 && bn > 128) bn = 128;                  // LDS: weight slab + ring + staging
+  if (bn != 64 && bn != 128 && bn != 256) return CREID_E_SHAPE;
+  if (N % bn != 0) return CREID_E_SHAPE;
+  { const char* e = getenv("CREID_STREAM2_BN"); const int v = e ? atoi(e) : 0; if (v == 64 || v == 128) bn_cap = v; }   // (experiments)
+  if ((bn_cap == 64 || bn_cap == 128) && bn_cap < bn && N % bn_cap == 0) bn = bn_cap;
+  const int tiles_m = (M + 127) / 128, tiles_n = N / bn;
+  int wgs = 256;
+  { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
+  int groups = wgs / tiles_n;
+  if (groups < 1) groups = 1;
+  if (groups > tiles_m) groups = tiles_m;
+  const dim3 grid((unsigned)(groups * tiles_n)), block(512);
+#ifdef CREID_ABL_BUILD
+  static const int abl = creid_ablation_env("CREID_STREAM2_ABL");   // 1 no stores, 2 no residual loads, 4 no A loads, 8 no copy-out
+#else
+  const int abl = 0;
+#endif
+#define CREID_ST2_LAUNCH(BN_, KCH_, RT_)                                                                                \
+  hipLaunchKernelGGL((igemm1x1_stream2_kernel<BN_, KCH_, RT_>), grid, block, 0, s, (const unsigned short*)src, M, K, N, \
+                     (const unsigned short*)wgt, (unsigned short*)out, bn_part, (const unsigned short*)add_src, epi_scale, \
+                     epi_shift, epi_relu, tiles_m, tiles_n, abl)
+  if (K == 64) {
+    if (bn == 256) CREID_ST2_LAUNCH(256, 1, 2); else if (bn == 128) CREID_ST2_LAUNCH(128, 1, 2); else CREID_ST2_LAUNCH(64, 1, 2);
+  } else {
+    if (bn == 128) CREID_ST2_LAUNCH(128, 2, 2); else CREID_ST2_LAUNCH(64, 2, 2);
+  }
+#undef CREID_ST2_LAUNCH
+  return (int)hipGetLastError();
+}

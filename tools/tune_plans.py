@@ -72,10 +72,12 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
             for st in (2, 3, 4):
                 if bn == 128 and st == 4:
                     continue
-                for kind in (0, 1, 3):
+                for kind in (0, 1, 3, 4):
                     if kind == 3 and (bn != 128 or st == 4 or (M + 255) // 256 * (cout // 128) < 256):
                         continue
                     if kind == 1 and st > 3:
+                        continue
+                    if kind == 4 and (bn != 128 or not (k == 1 and s == 1 and cin in (64, 128))):   # second persistent 1x1 kernel; st = slab cap
                         continue
                     lib.creid_tune_set(1, *key, bn, st, kind)
                     sc = t_us(fn)
@@ -191,6 +193,12 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
             sc = t_us(fn)
             if sc < best[0]:
                 best = (sc, (64, 2, 2))
+        if tag == "fwd" and k == 1 and s == 1 and cin in (64, 128):         # its second form; the ring-depth slot = column-slab cap
+            for st in (2, 3, 4):
+                lib.creid_tune_set(1, *key, 128, st, 4)
+                sc = t_us(fn)
+                if sc < best[0]:
+                    best = (sc, (128, st, 4))
         lib.creid_tune_clear()
         if best[1] is not None and best[0] < 0.97 * base:
             plans.append({"kind": 1, "key": list(key), "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2), "layer": f"{tag} {name}"})
@@ -203,7 +211,7 @@ if args.merge and os.path.exists(args.merge):
     plans = [e for e in old if (e["kind"], tuple(e["key"])) not in tuned_keys] + plans
 out = {"_comment": "measured launch plans (tools/tune_plans.py) for the ResNet50 layer mix on one MI355X (B=64 256x128 = BASELINE "
                    "configs[1]; B=56 320x320 = configs[3] training; B=128 256x128 and B=256 320x320 forward = the eval-mode embedding batches); kind 0 = weight gradient (M, out_c, K) -> (tile rows, tile cols, splits), "
-                   "kind 1 = forward / data gradient (M, N, K, transposed) -> (N tile, ring depth, kernel: 0 producer/consumer, 1 four-wave DMA, 2 persistent 1x1, 3 256-row tiles).  Shapes without an entry use the "
+                   "kind 1 = forward / data gradient (M, N, K, transposed) -> (N tile, ring depth, kernel: 0 producer/consumer, 1 four-wave DMA, 2 persistent 1x1, 3 256-row tiles, 4 persistent 1x1 second form with the ring-depth slot as column-slab cap).  Shapes without an entry use the "
                    "built-in rules.",
        "device": torch.cuda.get_device_name(0), "plans": plans}
 json.dump(out, open(args.out, "w"), indent=1)
