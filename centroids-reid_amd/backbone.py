@@ -216,6 +216,7 @@ class BackboneEngine:
         self.net = net
         self.dtype = dtype
         self.dt = L._DT[dtype]
+        self.eval_ds_side = os.environ.get("CREID_EVAL_DS_SIDE", "0") == "1"   # eval forward: downsample conv on a side stream
         self.units = []
         self.stem = _ConvUnit(net.conv1, net.bn1)
         self.blocks = []
@@ -439,12 +440,22 @@ class BackboneEngine:
         h, w = H2, W2
         for b in self.blocks:
             a_in, hin, win = a, h, w
+            side = b["ds"] is not None and self.eval_ds_side
+            if side:
+                # the downsample convolution depends on the block input only: it runs on a side stream (a parallel branch of a
+                # captured graph) beside conv1 / conv2 and is joined before conv3, whose epilogue adds it
+                with self._fork_side(a_in):
+                    r = self._conv_fold(b["ds"], a_in, B, hin, win, False)[0]
             if b["c1"].ibn is not None:
                 _, a1, _, _, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, False, True)
             else:
                 a1, h1, w1 = self._conv_fold(b["c1"], a_in, B, hin, win, True)
             a2, h2, w2 = self._conv_fold(b["c2"], a1, B, h1, w1, True)
-            r = a_in if b["ds"] is None else self._conv_fold(b["ds"], a_in, B, hin, win, False)[0]
+            if side:
+                self._join_side()
+                r.record_stream(torch.cuda.current_stream())
+            else:
+                r = a_in if b["ds"] is None else self._conv_fold(b["ds"], a_in, B, hin, win, False)[0]
             a, h, w = self._conv_fold(b["c3"], a2, B, h2, w2, True, residual=r)
         feat = self._empty(B, 2048, dtype=torch.float32)
         L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), st), "gap_fwd")
