@@ -248,9 +248,11 @@ int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void
 //   * everything a tile needs from memory is requested ONE TILE EARLIER and nothing is waited for inside the tile that issued
 //     it: the A rows of tile t + 2 and the residual chunks of tile t + 1 are loaded into registers at the top of tile t, the A
 //     registers of tile t + 1 (loaded a tile ago) go to the LDS ring there, and the finished 16-byte chunks of tile t - 1 are
-//     stored there.  The operands come through REGISTERS, not the LDS-DMA: with DMA writes in flight the compiler has to
-//     drain vmcnt before every LDS access of a wave that also loads and stores (it cannot tell which LDS bytes a DMA owns) --
-//     measured: every load and store then sat on the critical path (ablation: stores + 27, residual + 28, compute 32 of 77 us);
+//     stored there.  The operands come through REGISTERS and every load is branch-free: in the first version (LDS-DMA for
+//     A, predicated residual loads and stores in the same waves) the compiler's counted waits did not survive the control
+//     flow and it placed full vmcnt(0) waits right after the requests of the SAME tile -- every load and store sat on the
+//     critical path (ablation: compute 32 + stores 27 + residual 28 of 77 us).  Now the only full waits stand where
+//     everything outstanding is a tile old (ISA checked: put_a / the residual hand-over, then loads, then stores, then MFMAs);
 //   * epilogues: BatchNorm column sums of the fp32 accumulators (training forward), or the folded eval-mode affine (+ ReLU)
 //     with the block's residual added in the copy-out (the arithmetic of igemm_bf16_ws_kernel: identical bits).
 // K = 64 or 128 (KCH = 1, 2); BN = 64 / 128 / 256 columns per workgroup (256 only for K = 64: LDS); RT = 2 ring slots.
