@@ -255,7 +255,8 @@ int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void
 //     everything outstanding is a tile old (ISA checked: put_a / the residual hand-over, then loads, then stores, then MFMAs);
 //   * epilogues: BatchNorm column sums of the fp32 accumulators (training forward), or the folded eval-mode affine (+ ReLU)
 //     with the block's residual added in the copy-out (the arithmetic of igemm_bf16_ws_kernel: identical bits).
-// K = 64 or 128 (KCH = 1, 2); BN = 64 / 128 / 256 columns per workgroup (256 only for K = 64: LDS); RT = 2 ring slots.
+// K = 64 / 128 / 256 (KCH = 1, 2, 4); BN = 64 / 128 / 256 columns per workgroup; RT = 2 ring slots, or 1 where LDS allows no more
+// (K = 256 with 64-column slabs, K = 128 with 256-column slabs): the tile is then written into the slot between two barriers.
 template <int BN, int KCH, int RT>
 __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned short* __restrict__ src, int M, int K, int N,
                                                                    const unsigned short* __restrict__ wgt,
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
   constexpr int W_ELEMS = KCH * BN * 64, TILE_ELEMS = KCH * 128 * 64, RING_ELEMS = RT * TILE_ELEMS, STAGE_ELEMS = HB * CPT;
   constexpr int RED_ELEMS = 4 * 2 * BN * 2;            // fp32 [4 row waves][2][BN] in 2-byte units
   static_assert(2 * (W_ELEMS + RING_ELEMS + STAGE_ELEMS + RED_ELEMS) <= 160 * 1024, "LDS budget");
-  static_assert(16 % CPR == 0 && RT == 2, "copy-out map / ring");
+  static_assert(16 % CPR == 0 && (RT == 1 || RT == 2), "copy-out map / ring");
   __shared__ __attribute__((aligned(1024))) unsigned short smem[W_ELEMS + RING_ELEMS + STAGE_ELEMS + RED_ELEMS];
   unsigned short* Ws = smem;                           // [KCH][BN][64]
   unsigned short* ring = smem + W_ELEMS;               // [RT][KCH][128][64]
@@ -363,8 +364,10 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
   };
 
   load_a(0);
-  put_a(0);                                                       // tile 0 is in the ring before the first barrier
-  if (n_iter > 1) load_a(1);
+  if constexpr (RT == 2) {
+    put_a(0);                                                     // tile 0 is in the ring before the first barrier
+    if (n_iter > 1) load_a(1);
+  }
   if (add_src) load_res(0);
   float sc[TW], sh[TW];
   if (epi_scale) {
@@ -375,9 +378,13 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
 
   for (int it = 0; it < n_iter; ++it) {
     const int tile_m = wg_in_group + it * groups;
-    __syncthreads();                                              // tile `it` is in the ring; everyone is done with tile it - 1
+    __syncthreads();                                              // RT = 2: tile `it` is in the ring; everyone is done with tile it - 1
     // first everything that CONSUMES loads issued a tile ago (whatever the wait before it, it is short) ...
-    if (it + 1 < n_iter) put_a(it + 1);                           // into the slot tile it - 1 just left
+    if constexpr (RT == 2) {
+      if (it + 1 < n_iter) put_a(it + 1);                         // into the slot tile it - 1 just left
+    } else {
+      put_a(it);                                                  // one slot (K = 256 / wide slabs: LDS): this tile, loaded a tile ago
+    }
     uint4 resc[NH][NIT];
     if (add_src) {
 #pragma unroll
@@ -391,9 +398,10 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
       for (int i = 0; i < NIT; ++i) asm volatile("" : "+v"(resc[h][i].x), "+v"(resc[h][i].y), "+v"(resc[h][i].z), "+v"(resc[h][i].w));
     // ... then this tile's requests: nothing below waits for them before the next trip (loads first: the compiler guards the
     // re-use of their destination registers with a full wait, which must not see the stores)
-    if (it + 2 < n_iter) load_a(it + 2);
+    if (it + RT < n_iter) load_a(it + RT);
     if (add_src && it + 1 < n_iter) load_res(it + 1);
     if (it > 0) store_out(it - 1);
+    if constexpr (RT == 1) __syncthreads();                       // the slot holds tile `it`
     f32x16 acc[TW];
 #pragma unroll
     for (int j = 0; j < TW; ++j)
@@ -496,9 +504,9 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
 // Returns CREID_E_SHAPE when the GEMM is outside the kernel's scope (the caller then uses conv_igemm.hip's kernels).
 int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, const void* add_src,
                    const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, hipStream_t s) {
-  if (K != 64 && K != 128) return CREID_E_SHAPE;
+  if (K != 64 && K != 128 && K != 256) return CREID_E_SHAPE;
   int bn = N >= 256 ? 256 : N;
-  if (K == 128 && bn > 128) bn = 128;                  // LDS: weight slab + ring + staging
+  if (K == 256 && bn > 64) bn = 64;                    // LDS: weight slab + one 64 KB tile slot + staging
   if (bn != 64 && bn != 128 && bn != 256) return CREID_E_SHAPE;
   if (N % bn != 0) return CREID_E_SHAPE;
   { const char* e = getenv("CREID_STREAM2_BN"); const int v = e ? atoi(e) : 0; if (v == 64 || v == 128) bn_cap = v; }   // (experiments)
@@ -521,8 +529,10 @@ int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* 
                      epi_shift, epi_relu, tiles_m, tiles_n, abl)
   if (K == 64) {
     if (bn == 256) CREID_ST2_LAUNCH(256, 1, 2); else if (bn == 128) CREID_ST2_LAUNCH(128, 1, 2); else CREID_ST2_LAUNCH(64, 1, 2);
+  } else if (K == 128) {
+    if (bn == 256) CREID_ST2_LAUNCH(256, 2, 1); else if (bn == 128) CREID_ST2_LAUNCH(128, 2, 2); else CREID_ST2_LAUNCH(64, 2, 2);
   } else {
-    if (bn == 128) CREID_ST2_LAUNCH(128, 2, 2); else CREID_ST2_LAUNCH(64, 2, 2);
+    CREID_ST2_LAUNCH(64, 4, 1);
   }
 #undef CREID_ST2_LAUNCH
   return (int)hipGetLastError();

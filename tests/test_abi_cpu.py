@@ -111,8 +111,8 @@ def test_tuned_plan_file_is_well_formed_and_registers():
             assert plan[0] in (64, 128) and plan[1] in (2, 3, 4) and plan[2] in (0, 1, 2, 3, 4)
             if kind == 1 and plan[2] == 3:                  # 256-row tiles exist as <128, 2 | 3, 256> only
                 assert plan[0] == 128 and plan[1] in (2, 3)
-            if kind == 1 and plan[2] == 4:                  # second persistent 1x1 kernel: K = 64 | 128, forward only
-                assert plan[0] == 128 and key[2] in (64, 128) and key[3] == 2
+            if kind == 1 and plan[2] == 4:                  # second persistent 1x1 kernel: K = 64 | 128 | 256, forward only
+                assert plan[0] == 128 and key[2] in (64, 128, 256) and key[3] == 2
             assert key[1] % plan[0] == 0 and key[3] in (2, 3, 4, 5)          # transposed | stride << 1
     lib = L.lib()
     assert L.load_tuned_plans(path) == len(plans)

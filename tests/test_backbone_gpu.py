@@ -139,7 +139,8 @@ def test_stream_1x1_forward_matches_tile_kernel(B, H, W, cin, cout, wgs, monkeyp
 
 @pytest.mark.parametrize("wgs", [256, 5])
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 8, 64, 256), (2, 16, 16, 128, 512), (5, 32, 16, 64, 64), (1, 10, 10, 64, 256),
-                                            (7, 24, 12, 128, 128), (2, 12, 12, 64, 128), (9, 40, 20, 64, 256), (3, 33, 17, 128, 64)])
+                                            (7, 24, 12, 128, 128), (2, 12, 12, 64, 128), (9, 40, 20, 64, 256), (3, 33, 17, 128, 64),
+                                            (3, 20, 10, 256, 64), (2, 16, 16, 256, 128), (5, 16, 8, 256, 1024)])
 def test_stream2_forward_matches_tile_kernel(B, H, W, cin, cout, wgs, monkeypatch):
     """Second form of the persistent 1x1 kernel (igemm1x1_stream2_kernel: eight like waves, copy-out one tile behind) against the
     tile-per-workgroup kernels on the same inputs, all three epilogues: training forward (identical bf16 output, statistics

@@ -8,7 +8,8 @@ sys.path.insert(0, ".")
 from centroids_reid_amd import layers as ly
 from bench import time_kernel
 
-SHAPES = [(64, 64, 64, 32, "c1"), (64, 256, 64, 32, "c3"), (128, 512, 32, 16, "c3")]
+SHAPES = [(64, 64, 64, 32, "c1"), (64, 256, 64, 32, "c3"), (128, 512, 32, 16, "c3"), (256, 64, 64, 32, "c1"), (256, 128, 64, 32, "c1"),
+          (256, 1024, 16, 8, "c3")]
 
 
 def t_us(fn):

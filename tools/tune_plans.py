@@ -77,7 +77,7 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
                         continue
                     if kind == 1 and st > 3:
                         continue
-                    if kind == 4 and (bn != 128 or not (k == 1 and s == 1 and cin in (64, 128))):   # second persistent 1x1 kernel; st = slab cap
+                    if kind == 4 and (bn != 128 or not (k == 1 and s == 1 and cin in (64, 128, 256))):   # second persistent 1x1 kernel; st = slab cap
                         continue
                     lib.creid_tune_set(1, *key, bn, st, kind)
                     sc = t_us(fn)
@@ -193,7 +193,7 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
             sc = t_us(fn)
             if sc < best[0]:
                 best = (sc, (64, 2, 2))
-        if tag == "fwd" and k == 1 and s == 1 and cin in (64, 128):         # its second form; the ring-depth slot = column-slab cap
+        if tag == "fwd" and k == 1 and s == 1 and cin in (64, 128, 256):    # its second form; the ring-depth slot = column-slab cap
             for st in (2, 3, 4):
                 lib.creid_tune_set(1, *key, 128, st, 4)
                 sc = t_us(fn)
