@@ -19,23 +19,35 @@ from . import _lib as L
 from . import reid_metric as rm
 
 
-def _inference(model, batch, use_cuda=True, normalize_with_bn=True):
-    """inference_utils.py:104-113: eval-mode backbone (+ BNNeck)."""
+def _inference(model, batch, use_cuda=True, normalize_with_bn=True, transform=None):
+    """inference_utils.py:104-113: eval-mode backbone (+ BNNeck).  `data` is the reference's fp32 NCHW batch, or -- with
+    `transform` = ReidTransforms(cfg).build_transforms(is_train=False) -- a uint8 [B, H, W, 3] batch of resized images: the test
+    transform (build.py:27-31 after the Resize) then runs on the device and writes the stem convolution's operand directly."""
     model.eval()
     with torch.no_grad():
         data, _, filename = batch
-        _, global_feat = model.backbone(data.cuda() if use_cuda else data)
+        if data.dtype == torch.uint8:
+            if transform is None:
+                raise ValueError("uint8 image batches need `transform` (transforms.ReidTransforms(cfg).build_transforms(False))")
+            data = transform(data.cuda(), layout="stem", dtype=model.backbone.engine.dtype)
+        else:
+            data = data.cuda() if use_cuda else data
+        _, global_feat = model.backbone(data)
         if normalize_with_bn:
             global_feat = model.bn(global_feat)
         return global_feat, filename
 
 
-def run_inference(model, val_loader, cfg=None, print_freq=0, use_cuda=True):
+def run_inference(model, val_loader, cfg=None, print_freq=0, use_cuda=True, transform=None):
     """inference_utils.py:116-131 -> (embeddings float32 [N, D] ndarray, paths ndarray); the embeddings are
-    also kept on the device in `run_inference.last_device_embeddings` for a following get_similar()."""
+    also kept on the device in `run_inference.last_device_embeddings` for a following get_similar().  A loader of uint8
+    [B, H, W, 3] batches is normalised on the device (`transform`, or the test transform built from `cfg`)."""
     embs, paths = [], []
+    if transform is None and cfg is not None:
+        from .transforms import ReidTransforms
+        transform = ReidTransforms(cfg).build_transforms(is_train=False)
     for batch in val_loader:
-        e, p = _inference(model, batch, use_cuda)
+        e, p = _inference(model, batch, use_cuda, transform=transform)
         embs.append(e.float())
         paths.extend(list(p))
     dev = torch.cat(embs)

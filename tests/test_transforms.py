@@ -158,3 +158,30 @@ def test_backbone_takes_the_stem_operand(dtype):
         torch.cuda.synchronize()
         grads.append((f.detach().clone(), model.backbone.base.conv1.weight.grad.detach().clone()))
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+@pytest.mark.gpu
+def test_run_inference_takes_uint8_batches():
+    """inference.run_inference on a loader of uint8 [B, H, W, 3] batches (test transform on the device, straight into the stem
+    operand) == on the reference-style loader of fp32 NCHW tensors made by the oracle's ToTensor + Normalize: same embeddings, bit
+    for bit, same paths; a uint8 batch without a transform is refused."""
+    from oracle import backbone_oracle as bo
+    from centroids_reid_amd import inference as inf
+    from centroids_reid_amd.bench_train import make_model
+    from centroids_reid_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    cfg.INPUT.SIZE_TEST = [64, 32]
+    model = make_model(num_classes=10, dtype=torch.float32, K=2)
+    model.backbone.base.load_state_dict(bo.make_state_dict("resnet50", 1, seed=4))
+    model.backbone.base.cuda()
+    rng = np.random.default_rng(1)
+    u8 = [rng.integers(0, 256, (3, 64, 32, 3), dtype=np.uint8) for _ in range(2)]
+    paths = [[f"img_{b}_{i}.jpg" for i in range(3)] for b in range(2)]
+    mean, std = cfg.INPUT.PIXEL_MEAN, cfg.INPUT.PIXEL_STD
+    ref_loader = [(torch.from_numpy(np.stack([to.test_transform(im, mean, std) for im in b])), "", p) for b, p in zip(u8, paths)]
+    u8_loader = [(torch.from_numpy(b), "", p) for b, p in zip(u8, paths)]
+    e0, p0 = inf.run_inference(model, ref_loader, cfg)
+    e1, p1 = inf.run_inference(model, u8_loader, cfg)
+    assert np.array_equal(e0, e1) and list(p0) == list(p1) and e0.shape == (6, 2048)
+    with pytest.raises(ValueError):
+        inf._inference(model, u8_loader[0])
