@@ -563,6 +563,8 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
     arch = os.environ.get("CREID_BENCH_ARCH", "resnet50")      # resnet50_ibn_a: side measurement, not the headline config
     if os.environ.get("CREID_BENCH_CONFIG3", "0") == "1":      # side line: the training half of BASELINE configs[3]
         arch, P, H, W = "resnet50_ibn_a", 14, 320, 320         # (configs/320_resnet50_ibn_a.yml: 320 x 320, 14 x 4 images)
+    if os.environ.get("CREID_BENCH_P"):                        # side measurement: another batch size (P identities x K = 4)
+        P = int(os.environ["CREID_BENCH_P"])
     f32 = os.environ.get("CREID_BENCH_DTYPE", "bf16") == "f32"   # side measurement: the exact-f32 parity mode
     torch.manual_seed(int(os.environ.get("CREID_BENCH_SEED", "0")))   # random-init weights: the same ones in every run
     model = make_model(arch=arch, dtype=torch.float32 if f32 else torch.bfloat16)
@@ -680,7 +682,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
         from . import _lib as L
         res["plans"] = "tuned" if (L.lib() and L.N_PLANS > 0) else "rules"   # tuned_plans.json covers the configs[1] / [3] shapes only
         tf, ig_ms, slow, fast = igemm_roofline(P * K, H, W, time_kernel)
-        headline = world == 1 and arch == "resnet50" and not f32 and (H, W) == (256, 128)
+        headline = world == 1 and arch == "resnet50" and not f32 and (H, W) == (256, 128) and P == 16
         insitu = insitu_trace() if headline else None
         roof = {"kernel": "igemm_bf16_{dma,ws}_kernel (conv fwd + dgrad + stem fwd, 105 launches/step, real layer mix)",
                 "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_TFLOPS,
