@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest committed counter passes first
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest committed counter passes first
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_TFLOPS = 157.3        # f32-input MFMA dense peak
 MFMA_BF16_TFLOPS = 2500.0      # bf16 MFMA dense peak
@@ -120,14 +120,12 @@ def pmc_traffic(key):
 
 def pmc_field(key, field):
     """A per-kernel field of the committed counter passes (profiles/r0x_pmc_traffic.json), e.g. "mfma_busy"."""
-    try:
-        for name in PMC_FILES:
-            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-            if os.path.exists(path):
-                with open(path) as f:
-                    return json.load(f)[key][field]
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in PMC_FILES:                                  # newest pass that has the kernel AND the field
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)) as f:
+                return json.load(f)[key][field]
+        except (OSError, KeyError, ValueError):
+            continue
     return None
 
 

@@ -28,6 +28,9 @@ int wgrad_reduce_job_launch(const WRedJob& j, hipStream_t s);
 int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, hipStream_t s);
 int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, const void* add_src,
                    const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, hipStream_t s);
+// defined in conv_pipe.hip
+int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src, float* bn_part,
+                    int variant, hipStream_t s);
 
 // Out-of-image taps read this 128-byte page of zeros instead of selecting zeros per dword (saves 3 VALU
 // per load in the gather path).
@@ -1185,7 +1188,9 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
                         float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
                         const WRedJob* wred_in = nullptr) {
 #ifdef CREID_ABL_BUILD
-  static const int abl_env = creid_ablation_env("CREID_IGEMM_ABL");
+  const char* abl_e = getenv("CREID_IGEMM_ABL");                  // per call: the probes sweep it inside one process
+  const int abl_env = abl_e ? atoi(abl_e) : 0;
+  { static int warned = -1; if (abl_env && abl_env != warned) { warned = abl_env; creid_ablation_env("CREID_IGEMM_ABL"); } }
 #else
   const int abl_env = 0;
 #endif
@@ -1202,10 +1207,25 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   // measured plan for this GEMM shape (tune.hpp): N tile and ring depth of the producer/consumer kernel; the 4th key slot is
   // transposed | stride << 1 (a stride-2 and a stride-1 3x3 layer can share M, N, K but not their gather pattern)
   TunePlan tp;
-  int tuned_stages = 0, tuned_dma = 0, tuned_stream = 0, tuned_bm256 = 0, tuned_stream2 = 0;
-  if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, g.transposed | (g.stride << 1), tp) && (tp.p0 == 64 || tp.p0 == 128) &&
-      g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
+  int tuned_stages = 0, tuned_dma = 0, tuned_stream = 0, tuned_bm256 = 0, tuned_stream2 = 0, tuned_pp = -1;
+  // (folded eval-mode launches -- epi_scale set -- look for a plan measured with THAT epilogue first: key bit 3; plans recorded
+  // before the bit existed carry no mode and serve both)
+  const int plan_d = g.transposed | (g.stride << 1);
+  const bool have_plan = dtype == CREID_BF16 && ((g.epi_scale && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, plan_d | 8, tp)) ||
+                                                  creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, plan_d, tp));
+  if (have_plan && tp.p2 == 5) {
+    tuned_pp = tp.p0;                                              // plan kind 5: all-waves-multiply persistent kernel, p0 = its variant word
+  } else if (have_plan && (tp.p0 == 64 || tp.p0 == 128) && g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
     bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2; tuned_bm256 = tp.p2 == 3; tuned_stream2 = tp.p2 == 4;
+  }
+  // all-waves-multiply persistent kernel (conv_pipe.hip): plan kind 5, or CREID_IGEMM_PP = 0x1000 | variant for every launch it covers
+  {
+    const char* pe = getenv("CREID_IGEMM_PP");                     // read per call: tests and the tuner toggle it
+    const int force_pp = pe ? (int)strtol(pe, nullptr, 0) : 0;
+    if (dtype == CREID_BF16 && !bnred.x && !wred.ws && g.log2span >= 6 && (force_pp || tuned_pp >= 0)) {
+      const int rc = launch_igemm_pp(g, src, wgt, out, add_src, bn_part, force_pp ? (force_pp & 0xfff) : tuned_pp, s);
+      if (rc != CREID_E_SHAPE) return rc;
+    }
   }
   // persistent streaming kernel for the small-K 1x1 stride-1 forward convolutions (conv_stream.hip): plan kind 2, or
   // CREID_STREAM1X1=1 for every GEMM it covers

@@ -100,6 +100,33 @@ def test_streamed_duke_shape_equals_materialised():
     assert 0 < rb[1] < 1
 
 
+def test_north_star_3000x15000_streamed_materialised_oracle():
+    """north_star's own target shape (3000 queries x 15000 gallery x 2048 fp32; utils/reid_metric.py:112-151): the streamed
+    path equals the materialised one, the ranking has the size-independent properties, the integer stage equals the oracle on
+    the device's ranking and a 64-query slice of the distance matrix matches float64 CPU arithmetic."""
+    from oracle import reid_oracle as ro
+    gen = torch.Generator(device="cuda").manual_seed(3000)
+    nq, ng, D = 3000, 15000, 2048
+    feats = torch.randn((nq + ng, D), generator=gen, device="cuda", dtype=torch.float32)
+    rng = np.random.default_rng(3000)
+    pids = rng.integers(0, 751, nq + ng); cams = rng.integers(0, 6, nq + ng)
+    a, ra, b, rb = _both(feats, pids, cams, nq)
+    _assert_same(a, ra, b, rb, pids, cams, nq)
+    d, idx = a.last["distmat"], a.last["indices"]
+    srt = torch.sort(idx, dim=1).values
+    assert torch.equal(srt, torch.arange(ng, device="cuda").expand(nq, ng))          # every row a permutation
+    ds = torch.gather(d, 1, idx)
+    assert bool((ds[:, 1:] >= ds[:, :-1]).all())                                     # non-decreasing distances
+    tie = ds[:, 1:] == ds[:, :-1]
+    assert bool((idx[:, 1:][tie] > idx[:, :-1][tie]).all())                          # ties in gallery-index order
+    assert float(d.min()) > 0.0 and float(d.max()) < 4.0                             # unit vectors
+    cmc_o, mAP_o, topk_o, _ = ro.eval_market(idx.cpu().numpy(), pids[:nq], pids[nq:], cams[:nq], cams[nq:])
+    np.testing.assert_array_equal(ra[0], cmc_o)
+    assert abs(ra[1] - mAP_o) < 1e-12 and abs(rb[1] - mAP_o) < 1e-12
+    qn, gn = ro.l2_normalize(feats[:64].cpu().double()), ro.l2_normalize(feats[nq:nq + 512].cpu().double())
+    np.testing.assert_allclose(d[:64, :512].cpu().numpy(), ro.sqdist_matrix(qn, gn).numpy(), rtol=0, atol=5e-6)
+
+
 def test_streamed_configs3_shard_6250x200000():
     """The per-rank shard of BASELINE configs[3]: 6250 queries x 200 000 gallery x 2048 fp32, streamed (the 5 GB
     distance matrix and the 10 GB index matrix are never written).  Full-size properties + equality with the

@@ -29,6 +29,9 @@ ap.add_argument("--fwd-only", action="store_true",
                 help="eval-mode shapes (embedding batch sizes): forward with the folded BatchNorm epilogue only, incl. the "
                      "256-row tile variant (plan kind 3)")
 ap.add_argument("--wgrad-only", action="store_true", help="re-measure the weight-gradient plans only (forward / data-gradient entries of --merge are kept)")
+ap.add_argument("--pp-only", action="store_true",
+                help="measure only the all-waves-multiply persistent kernel (conv_pipe.hip, plan kind 5) against the plans of --merge "
+                     "(which stay registered as the baseline): training forward, or with --fwd-only the folded eval-mode forward")
 args = ap.parse_args()
 lib = L.lib()
 B = args.batch
@@ -39,6 +42,16 @@ def t_us(fn, reps=2, iters=10):
     return min(time_kernel(fn, iters) for _ in range(reps)) * 1e3
 
 
+PP_VARIANTS = [(bm // 128) | ((bn // 128) << 2) | (kph << 4) | (mode << 8)
+               for (bm, bn) in ((256, 256), (128, 256), (256, 128)) for (kph, mode) in ((1, 0), (2, 0), (1, 2))]
+
+
+def register(entries):
+    for e in entries:
+        lib.creid_tune_set(e["kind"], *e["key"], *e["plan"])
+
+
+merge_plans = json.load(open(args.merge)).get("plans", []) if (args.merge and os.path.exists(args.merge)) else []
 plans, log = [], []
 tuned_keys = set()                                          # every (kind, key) measured in this run
 seen = {}
@@ -56,6 +69,37 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
     M, K = B * oh * ow, k * k * cin
     dw = torch.zeros((cout, cin, k, k), device="cuda")
     name = f"{cin}->{cout} k{k} s{s} {h}x{w}"
+
+    if args.pp_only:
+        ss = torch.stack([torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.1]).contiguous()
+        res_t = torch.randn_like(y) if (k == 1 and cout == 4 * cin) else None
+        if args.fwd_only:
+            fn = lambda: ly.conv2d_fwd_affine(x, krsc, s, pad, ss, res_t, True)
+            key = (M, cout, K, (s << 1) | 8)
+        else:
+            fn = lambda: ly.conv2d_fwd(x, krsc, s, pad, with_stats=True)
+            key = (M, cout, K, s << 1)
+        if cout % 128 or K < 256:
+            continue
+        lib.creid_tune_clear()
+        register([e for e in merge_plans if not (e["kind"] == 1 and e["plan"][2] == 5)])
+        base = t_us(fn)
+        best = (base, None)
+        for v in PP_VARIANTS:
+            if cout % (((v >> 2) & 3) * 128):
+                continue
+            lib.creid_tune_set(1, *key, v, 0, 5)
+            sc = t_us(fn)
+            if sc < best[0]:
+                best = (sc, (v, 0, 5))
+        lib.creid_tune_clear()
+        tuned_keys.add((1, tuple(key)))
+        if best[1] is not None and best[0] < 0.97 * base:
+            plans.append({"kind": 1, "key": list(key), "plan": list(best[1]), "us": round(best[0], 2), "rule_us": round(base, 2),
+                          "layer": f"{'fwd-eval' if args.fwd_only else 'fwd'} {name} B={B} (kind 5 = conv_pipe.hip, variant {hex(best[1][0])})"})
+        log.append(f"pp {name:28s} x{cnt} plan/rule {base:6.1f}  best {best[0]:6.1f} {best[1] and hex(best[1][0])}")
+        print(log[-1], flush=True)
+        continue
 
     if args.fwd_only:
         ss = torch.stack([torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.1]).contiguous()
@@ -208,10 +252,15 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
 if args.merge and os.path.exists(args.merge):
     old = json.load(open(args.merge)).get("plans", [])
     # entries of shapes measured in this run are replaced (or dropped, when the built-in rule now wins); others are kept
-    plans = [e for e in old if (e["kind"], tuple(e["key"])) not in tuned_keys] + plans
+    if args.pp_only:
+        # only kind-5 entries are owned by this mode: an older plan of the same key stays unless a kind-5 plan now beats it
+        newkeys = {(e["kind"], tuple(e["key"])) for e in plans}
+        plans = [e for e in old if (e["kind"], tuple(e["key"])) not in newkeys and not (e["plan"][2] == 5 and (e["kind"], tuple(e["key"])) in tuned_keys)] + plans
+    else:
+        plans = [e for e in old if (e["kind"], tuple(e["key"])) not in tuned_keys] + plans
 out = {"_comment": "measured launch plans (tools/tune_plans.py) for the ResNet50 layer mix on one MI355X (B=64 256x128 = BASELINE "
                    "configs[1]; B=56 320x320 = configs[3] training; B=128 256x128 and B=256 320x320 forward = the eval-mode embedding batches); kind 0 = weight gradient (M, out_c, K) -> (tile rows, tile cols, splits), "
-                   "kind 1 = forward / data gradient (M, N, K, transposed) -> (N tile, ring depth, kernel: 0 producer/consumer, 1 four-wave DMA, 2 persistent 1x1, 3 256-row tiles, 4 persistent 1x1 second form with the ring-depth slot as column-slab cap).  Shapes without an entry use the "
+                   "kind 1 = forward / data gradient (M, N, K, transposed) -> (N tile, ring depth, kernel: 0 producer/consumer, 1 four-wave DMA, 2 persistent 1x1, 3 256-row tiles, 4 persistent 1x1 second form with the ring-depth slot as column-slab cap, 5 all-waves-multiply persistent kernel of conv_pipe.hip with plan[0] = its variant word; key[3] bit 3 = measured with the folded eval-mode epilogue).  Shapes without an entry use the "
                    "built-in rules.",
        "device": torch.cuda.get_device_name(0), "plans": plans}
 json.dump(out, open(args.out, "w"), indent=1)
