@@ -278,7 +278,10 @@ class BackboneEngine:
         self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
         # eval-mode forward: BatchNorm (running statistics = constants) folded into the producing convolution's epilogue --
         # one launch per conv instead of conv -> finalize -> apply (CREID_EVAL_FOLD=0: the three-launch schedule)
-        self.eval_fold = os.environ.get("CREID_EVAL_FOLD", "1") == "1"
+        # (the folded epilogue of the 16-bit types lives in the LDS-DMA kernels only: with CREID_IGEMM_DMA=0 those forwards take
+        # the three-launch schedule instead of failing)
+        self.eval_fold = os.environ.get("CREID_EVAL_FOLD", "1") == "1" and \
+            (dtype == torch.float32 or os.environ.get("CREID_IGEMM_DMA", "1") == "1")
         self._fold_key = None
         # TIMING-ONLY ablation (results are WRONG): bit 0 skips the forward BatchNorm apply launches of bn1 / bn2 (no residual),
         # bit 1 their backward apply launches -- the upper bound of what fusing those passes into the consuming / producing
@@ -567,6 +570,10 @@ class BackboneEngine:
         B, _, H, W = x_nchw.shape
         if not training and self.eval_fold:
             return self._forward_eval_folded(x_nchw, want_base_out)
+        if training and self.dtype == torch.float16:
+            # f16 (the reference's precision=16, utils/misc.py:111) is an eval / inference compute type here: the weight-gradient
+            # kernels and the loss scaling its training would need are not built -- train in bf16 or fp32
+            raise NotImplementedError("compute dtype float16 covers the eval-mode / inference forward only; train in bfloat16 or float32")
         sv = {"B": B, "H": H, "W": W, "training": training}
         if training:      # one counter kernel per step instead of 53 per-layer `num_batches_tracked += 1`
             if self._pending_steps is None:

@@ -217,15 +217,15 @@ class EmbedBench:
         return (time.perf_counter() - t0) / steps
 
 
-def run_embed(arch="resnet50", B=128, H=256, W=128, steps=20, warmup=3, insitu=None, label=None):
+def run_embed(arch="resnet50", B=128, H=256, W=128, steps=20, warmup=3, insitu=None, label=None, dtype=torch.bfloat16):
     """The `embed` object of the bench line: images/s of the eval-mode embedding forward (BatchNorm folded into the
-    convolution epilogues), its roofline against the bf16 MFMA peak."""
-    eb = EmbedBench(arch, B, H, W)
+    convolution epilogues), its roofline against the bf16 / f16 MFMA peak (the same 2.5 PF)."""
+    eb = EmbedBench(arch, B, H, W, dtype=dtype)
     dt = eb.run(steps, warmup)
     assert bool(torch.isfinite(eb.emb).all()), "non-finite embeddings in the benchmark"
     fl = forward_flops(B, H, W)                                # convolution FLOPs are the same for both backbones
     res = {"metric": "embed_images_per_sec", "value": B / dt, "unit": "images/s", "ms_per_step": dt * 1e3, "steps": steps,
-           "dtype": "bf16", "hip_graph": True,
+           "dtype": "f16" if dtype == torch.float16 else "bf16", "hip_graph": True,
            "config": {"workload": label or f"{arch} {H}x{W} eval-mode embedding forward (validation_step: backbone + GAP + BNNeck), "
                                            f"batch {B}, BatchNorm folded into the conv epilogues", "batch": B},
            "roofline": {"kernel": "igemm_bf16_{ws,dma}_kernel (53 conv launches per forward, folded BN epilogue)", "bound": "mfma",
@@ -370,7 +370,7 @@ def map_delta_bf16(n_id=96, n_query=2, n_gallery=6, H=256, W=128, noise=0.6, see
     sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
     del ref
     embs = {}
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
         model = make_model(dtype=dt)
         model.load_state_dict(sd)                                          # identical weights AND statistics
         model.eval()
@@ -382,13 +382,17 @@ def map_delta_bf16(n_id=96, n_query=2, n_gallery=6, H=256, W=128, noise=0.6, see
         embs[dt] = torch.cat(out)[torch.as_tensor(order, device="cuda")].contiguous()
         del model
     res = {}
-    for dt, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+    for dt, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16"), (torch.float16, "f16")):
         cmc, mAP, _ = rm.R1_mAP(num_query=len(q_rows), streamed=True).compute(embs[dt], pids, cams)
         res[name] = (mAP, float(cmc[0]))
-    a, b = embs[torch.float32], embs[torch.bfloat16]
+    a, b, h = embs[torch.float32], embs[torch.bfloat16], embs[torch.float16]
     cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
+    cos_h = torch.nn.functional.cosine_similarity(a, h, dim=1)
     return {"mAP_f32": res["f32"][0], "mAP_bf16": res["bf16"][0], "mAP_bf16_minus_f32": res["bf16"][0] - res["f32"][0],
             "rank1_f32": res["f32"][1], "rank1_bf16": res["bf16"][1], "min_cosine": float(cos.min().item()),
+            # the reference's own mixed precision (utils/misc.py:111, precision=16) as the compute type of the eval forward
+            "mAP_f16": res["f16"][0], "mAP_f16_minus_f32": res["f16"][0] - res["f32"][0], "rank1_f16": res["f16"][1],
+            "min_cosine_f16": float(cos_h.min().item()),
             "images": int(len(x)), "identities": n_id, "noise": noise}
 
 
@@ -715,8 +719,16 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
             torch.cuda.empty_cache()
             res["fp32_mode"] = fp32_mode_step(P, K, H, W)
             res["map_delta_bf16"] = map_delta_bf16()             # BASELINE metric (iii) on clustered synthetic identities
+            md = res["map_delta_bf16"]
+            res["map_delta_f16"] = {"mAP_f32": md["mAP_f32"], "mAP_f16": md["mAP_f16"], "mAP_f16_minus_f32": md["mAP_f16_minus_f32"],
+                                    "rank1_f32": md["rank1_f32"], "rank1_f16": md["rank1_f16"], "min_cosine": md["min_cosine_f16"],
+                                    "note": "same recipe as map_delta_bf16; f16 = compute type of the eval-mode forward (conv MFMA inputs "
+                                            "and activations), fp32 accumulate"}
             # embeddings/s: the eval-mode forward validation_step / inference run (north_star's multi-GPU target is in it)
             res["embed"] = run_embed("resnet50", 128, 256, 128, steps=20, warmup=3, insitu=insitu)
+            ef = run_embed("resnet50", 128, 256, 128, steps=20, warmup=3, dtype=torch.float16)
+            res["embed"]["f16"] = {"value": ef["value"], "unit": ef["unit"], "ms_per_step": ef["ms_per_step"], "dtype": "f16",
+                                   "vs_bf16": ef["value"] / res["embed"]["value"], "roofline_frac_whole_forward": ef["roofline"]["frac"]}
             res["embed"]["configs3_embedding_half"] = run_embed(
                 "resnet50_ibn_a", 256, 320, 320, steps=5, warmup=2,
                 label="ResNet50-IBN-a 320x320 eval-mode embedding forward, batch 256 (embedding half of BASELINE configs[3], "

@@ -68,6 +68,12 @@ template <> struct Px4<unsigned short> {
   }
 };
 
+template <> struct Px4<_Float16> {
+  static __device__ __forceinline__ void st(_Float16* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(F16T::pack2(v[0], v[1]), F16T::pack2(v[2], v[3]));
+  }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void augment_stem_kernel(AugGeom g, const unsigned char* __restrict__ src,
                                                            const int* __restrict__ prm, T* __restrict__ out) {
@@ -110,6 +116,8 @@ extern "C" int creid_augment_u8(const uint8_t* src_hwc, const int32_t* params, i
   } else if (dtype == CREID_BF16) {
     hipLaunchKernelGGL(augment_stem_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, g, src_hwc, params,
                        (unsigned short*)out);
+  } else if (dtype == CREID_F16) {
+    hipLaunchKernelGGL(augment_stem_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, g, src_hwc, params, (_Float16*)out);
   } else {
     return CREID_E_DTYPE;
   }

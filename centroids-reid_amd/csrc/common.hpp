@@ -75,3 +75,32 @@ __device__ __forceinline__ unsigned f32x2_to_bf16x2_bits(float lo, float hi) {
   const cvt_f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cvt_bf16x2));
 }
+
+// 16-bit element types of the MFMA convolution path (storage = 2 bytes per element; a "word" holds two elements, the lower
+// column in bits 0..15).  bf16: the throughput mode of configs[1]; f16: the reference's own mixed precision
+// (utils/misc.py:111 `precision=16`), same MFMA rate, three more mantissa bits.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+struct Bf16T {
+  static constexpr int DT = CREID_BF16;
+  static constexpr unsigned ONE2 = 0x3f803f80u;                        // (1.0, 1.0)
+  static __device__ __forceinline__ unsigned pack2(float lo, float hi) { return f32x2_to_bf16x2_bits(lo, hi); }
+  static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+struct F16T {
+  static constexpr int DT = CREID_F16;
+  static constexpr unsigned ONE2 = 0x3c003c00u;
+  static __device__ __forceinline__ unsigned pack2(float lo, float hi) {   // round to nearest even (v_cvt_f16_f32 x2 + v_pack_b32_f16)
+    const h16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned, v);
+  }
+  static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(h16x2, w)[0]; }
+  static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(h16x2, w)[1]; }
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+};
+static inline bool creid_is16(int dtype) { return dtype == CREID_BF16 || dtype == CREID_F16; }

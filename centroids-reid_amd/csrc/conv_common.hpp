@@ -115,6 +115,11 @@ template <> struct ElemIO<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
 };
+template <> struct ElemIO<_Float16> {
+  static constexpr int DT = CREID_F16;
+  static __device__ __forceinline__ float ld(const _Float16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(_Float16* p, float v) { *p = (_Float16)v; }
+};
 template <> struct ElemIO<unsigned short> {   // bf16 bits
   static constexpr int DT = CREID_BF16;
   static __device__ __forceinline__ float ld(const unsigned short* p) { return bf16_bits_to_f32(*p); }

@@ -30,7 +30,7 @@ int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* 
                    const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, hipStream_t s);
 // defined in conv_pipe.hip
 int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src, float* bn_part,
-                    int variant, hipStream_t s);
+                    int variant, int dtype, hipStream_t s);
 
 // Out-of-image taps read this 128-byte page of zeros instead of selecting zeros per dword (saves 3 VALU
 // per load in the gather path).
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IGemmGeom g, const u
 // layer -- the loop is not DMA-latency bound, and 3+ stages cost a workgroup per CU.
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN, int NS>
+template <int BN, int NS, typename ET = Bf16T>
 __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) void igemm_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
                                                                  const unsigned short* __restrict__ wgt,
                                                                  unsigned short* __restrict__ out,
@@ -428,8 +428,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < TNW; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kk][i]),
-                                                              __builtin_bit_cast(bf16x8, b[kk][j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = ET::mfma(a[kk][i], b[kk][j], acc[i][j]);
   }
   __syncthreads();
 
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
       unit_of(i, rl, ch);
       const int rr = row0 + rl;
       pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
-      pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      pre_a[i] = make_uint4(ET::ONE2, ET::ONE2, ET::ONE2, ET::ONE2);
       pre_m[i] = 0xffu;
       if (rr < g.M) {
         const int64_t off = (int64_t)rr * g.N + col0 + ch * 8;
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
           float v0 = fmaf(acc[i][j][4 * q], sc, sh), v1 = fmaf(acc[i][j][4 * q + 1], sc, sh);
           float v2 = fmaf(acc[i][j][4 * q + 2], sc, sh), v3 = fmaf(acc[i][j][4 * q + 3], sc, sh);
           if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(ET::pack2(v0, v1), ET::pack2(v2, v3));
         }
       }
       s1v[j] = 0.f; s2v[j] = 0.f;
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
         s1 += v1; s2 = fmaf(v1, v1, s2);
         s1 += v2; s2 = fmaf(v2, v2, s2);
         s1 += v3; s2 = fmaf(v3, v3, s2);
-        *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+        *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(ET::pack2(v0, v1), ET::pack2(v2, v3));
       }
     }
     s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -567,12 +566,12 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
           unsigned* vw = &v.x; const unsigned* aw = &a.x;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float alo = ((am >> (2 * q)) & 1u) ? __uint_as_float(aw[q] << 16) : 0.f;
-            const float ahi = ((am >> (2 * q + 1)) & 1u) ? __uint_as_float(aw[q] & 0xffff0000u) : 0.f;
-            float lo = __uint_as_float(vw[q] << 16) + alo;
-            float hi = __uint_as_float(vw[q] & 0xffff0000u) + ahi;
+            const float alo = ((am >> (2 * q)) & 1u) ? ET::lo(aw[q]) : 0.f;
+            const float ahi = ((am >> (2 * q + 1)) & 1u) ? ET::hi(aw[q]) : 0.f;
+            float lo = ET::lo(vw[q]) + alo;
+            float hi = ET::hi(vw[q]) + ahi;
             if (g.epi_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }     // folded BatchNorm + residual: ReLU after the add
-            vw[q] = f32x2_to_bf16x2_bits(lo, hi);
+            vw[q] = ET::pack2(lo, hi);
           }
         }
       }
@@ -582,16 +581,16 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
         unsigned mb = pre_m[i];
         if (!bnred.prefetch) {
           xv = *reinterpret_cast<const uint4*>(bx + off);
-          av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+          av = make_uint4(ET::ONE2, ET::ONE2, ET::ONE2, ET::ONE2);
           if (bnred.mask) mb = bnred.mask[off >> 3];
           else if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
         }
         const unsigned* vw = &v.x; const unsigned* xw = &xv.x; const unsigned* aw = &av.x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float g0 = __uint_as_float(vw[q] << 16), g1 = __uint_as_float(vw[q] & 0xffff0000u);
-          const float a0 = __uint_as_float(aw[q] << 16), a1 = __uint_as_float(aw[q] & 0xffff0000u);
-          const float x0 = __uint_as_float(xw[q] << 16), x1 = __uint_as_float(xw[q] & 0xffff0000u);
+          float g0 = ET::lo(vw[q]), g1 = ET::hi(vw[q]);
+          const float a0 = ET::lo(aw[q]), a1 = ET::hi(aw[q]);
+          const float x0 = ET::lo(xw[q]), x1 = ET::hi(xw[q]);
           g0 = (a0 > 0.f && ((mb >> (2 * q)) & 1u)) ? g0 : 0.f; g1 = (a1 > 0.f && ((mb >> (2 * q + 1)) & 1u)) ? g1 : 0.f;
           rs1[2 * q] += g0; rs1[2 * q + 1] += g1;
           rs2[2 * q] = fmaf(g0, (x0 - rmu[2 * q]) * ris[2 * q], rs2[2 * q]);
@@ -647,7 +646,7 @@ __global__ __launch_bounds__(256, (NS * (128 + BN) * 128 <= 80 * 1024) ? 2 : 1) 
 // -0.06 ms per step on the rule-selected schedule, round 3).  BM = 256: 128 x BN/2
 // sub-tiles -- 0.75 instead of 1 fragment read per MFMA and 1.125 instead of 1.5 KB of LDS traffic per MFMA; one workgroup
 // per CU (the ring is 48 KB per stage), so only for grids that still fill the chip with 256-row tiles.
-template <int BN, int NS, int BM = 128>
+template <int BN, int NS, int BM = 128, typename ET = Bf16T>
 __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1)) void igemm_bf16_ws_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
                                                                 const unsigned short* __restrict__ wgt,
                                                                 unsigned short* __restrict__ out,
@@ -815,8 +814,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < TNW; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[sl][i]),
-                                                                __builtin_bit_cast(bf16x8, b[sl][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = ET::mfma(a[sl][i], b[sl][j], acc[i][j]);
       };
       if (CREID_ABL_ON(g.abl, 4)) continue;
       load_frags(0, 0);
@@ -855,7 +853,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
       unit_of(i, rl, ch);
       const int rr = row0 + rl;
       pre_x[i] = make_uint4(0u, 0u, 0u, 0u);
-      pre_a[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      pre_a[i] = make_uint4(ET::ONE2, ET::ONE2, ET::ONE2, ET::ONE2);
       pre_m[i] = 0xffu;
       if (rr < g.M) {
         const int64_t off = (int64_t)pixel_of(rr) * g.N + col0 + ch * 8;
@@ -885,7 +883,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
           float v0 = fmaf(acc[i][j][4 * q], sc, sh), v1 = fmaf(acc[i][j][4 * q + 1], sc, sh);
           float v2 = fmaf(acc[i][j][4 * q + 2], sc, sh), v3 = fmaf(acc[i][j][4 * q + 3], sc, sh);
           if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(ET::pack2(v0, v1), ET::pack2(v2, v3));
         }
       }
       s1v[j] = 0.f; s2v[j] = 0.f;
@@ -905,7 +903,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
           s1 += v1; s2 = fmaf(v1, v1, s2);
           s1 += v2; s2 = fmaf(v2, v2, s2);
           s1 += v3; s2 = fmaf(v3, v3, s2);
-          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+          *reinterpret_cast<uint2*>(&smem[cl * CPT + rl]) = make_uint2(ET::pack2(v0, v1), ET::pack2(v2, v3));
         }
       }
       s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -973,12 +971,12 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
           unsigned* vw = &v.x; const unsigned* aw = &a.x;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float alo = ((am >> (2 * q)) & 1u) ? __uint_as_float(aw[q] << 16) : 0.f;
-            const float ahi = ((am >> (2 * q + 1)) & 1u) ? __uint_as_float(aw[q] & 0xffff0000u) : 0.f;
-            float lo = __uint_as_float(vw[q] << 16) + alo;
-            float hi = __uint_as_float(vw[q] & 0xffff0000u) + ahi;
+            const float alo = ((am >> (2 * q)) & 1u) ? ET::lo(aw[q]) : 0.f;
+            const float ahi = ((am >> (2 * q + 1)) & 1u) ? ET::hi(aw[q]) : 0.f;
+            float lo = ET::lo(vw[q]) + alo;
+            float hi = ET::hi(vw[q]) + ahi;
             if (g.epi_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }     // folded BatchNorm + residual: ReLU after the add
-            vw[q] = f32x2_to_bf16x2_bits(lo, hi);
+            vw[q] = ET::pack2(lo, hi);
           }
         }
       }
@@ -988,16 +986,16 @@ __global__ __launch_bounds__(512, (BN == 64 && NS == 2 && BM == 128) ? 6 : ((NS 
         unsigned mb = pre_m[i % NPRE];
         if (!bnred.prefetch) {
           xv = *reinterpret_cast<const uint4*>(bx + off);
-          av = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+          av = make_uint4(ET::ONE2, ET::ONE2, ET::ONE2, ET::ONE2);
           if (bnred.mask) mb = bnred.mask[off >> 3];
           else if (bact) av = *reinterpret_cast<const uint4*>(bact + off);
         }
         const unsigned* vw = &v.x; const unsigned* xw = &xv.x; const unsigned* aw = &av.x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float g0 = __uint_as_float(vw[q] << 16), g1 = __uint_as_float(vw[q] & 0xffff0000u);
-          const float a0 = __uint_as_float(aw[q] << 16), a1 = __uint_as_float(aw[q] & 0xffff0000u);
-          const float x0 = __uint_as_float(xw[q] << 16), x1 = __uint_as_float(xw[q] & 0xffff0000u);
+          float g0 = ET::lo(vw[q]), g1 = ET::hi(vw[q]);
+          const float a0 = ET::lo(aw[q]), a1 = ET::hi(aw[q]);
+          const float x0 = ET::lo(xw[q]), x1 = ET::hi(xw[q]);
           g0 = (a0 > 0.f && ((mb >> (2 * q)) & 1u)) ? g0 : 0.f; g1 = (a1 > 0.f && ((mb >> (2 * q + 1)) & 1u)) ? g1 : 0.f;
           rs1[2 * q] += g0; rs1[2 * q + 1] += g1;
           rs2[2 * q] = fmaf(g0, (x0 - rmu[2 * q]) * ris[2 * q], rs2[2 * q]);
@@ -1211,9 +1209,11 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   // (folded eval-mode launches -- epi_scale set -- look for a plan measured with THAT epilogue first: key bit 3; plans recorded
   // before the bit existed carry no mode and serve both)
   const int plan_d = g.transposed | (g.stride << 1);
-  const bool have_plan = dtype == CREID_BF16 && ((g.epi_scale && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, plan_d | 8, tp)) ||
+  const bool have_plan = creid_is16(dtype) && ((g.epi_scale && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, plan_d | 8, tp)) ||
                                                   creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, plan_d, tp));
-  if (have_plan && tp.p2 == 5) {
+  if (have_plan && dtype == CREID_F16 && (tp.p2 == 2 || tp.p2 == 4)) {
+    // (the persistent 1x1 kernels of conv_stream.hip are bf16 only: f16 launches of those shapes take the built-in rule)
+  } else if (have_plan && tp.p2 == 5) {
     tuned_pp = tp.p0;                                              // plan kind 5: all-waves-multiply persistent kernel, p0 = its variant word
   } else if (have_plan && (tp.p0 == 64 || tp.p0 == 128) && g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
     bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2; tuned_bm256 = tp.p2 == 3; tuned_stream2 = tp.p2 == 4;
@@ -1222,8 +1222,8 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   {
     const char* pe = getenv("CREID_IGEMM_PP");                     // read per call: tests and the tuner toggle it
     const int force_pp = pe ? (int)strtol(pe, nullptr, 0) : 0;
-    if (dtype == CREID_BF16 && !bnred.x && !wred.ws && g.log2span >= 6 && (force_pp || tuned_pp >= 0)) {
-      const int rc = launch_igemm_pp(g, src, wgt, out, add_src, bn_part, force_pp ? (force_pp & 0xfff) : tuned_pp, s);
+    if (creid_is16(dtype) && !bnred.x && !wred.ws && g.log2span >= 6 && (force_pp || tuned_pp >= 0)) {
+      const int rc = launch_igemm_pp(g, src, wgt, out, add_src, bn_part, force_pp ? (force_pp & 0xfff) : tuned_pp, dtype, s);
       if (rc != CREID_E_SHAPE) return rc;
     }
   }
@@ -1257,7 +1257,7 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
   const bool stem_geom = g.log2span == 5 && !g.transposed && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0;
   static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
-  if (dtype == CREID_BF16 && use_dma && (g.log2span >= 6 || (stem_geom && stem_dma))) {
+  if (creid_is16(dtype) && use_dma && (g.log2span >= 6 || (stem_geom && stem_dma))) {
     if (g.K % 64 != 0) return CREID_E_SHAPE;
     static const int use_ws = [] { const char* e = getenv("CREID_IGEMM_WS"); return e ? atoi(e) : 1; }();
 
@@ -1287,25 +1287,27 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
           const int st256 = (ws_stages >= 3 || g.K >= 256) ? 3 : 2;
           const dim3 grid256((unsigned)(wgs256 + (wred.ws ? wred.nblocks : 0)));
           const int tn256 = g.N / 128;
-          if (st256 == 3)
-            hipLaunchKernelGGL((igemm_bf16_ws_kernel<128, 3, 256>), grid256, block_ws, 0, s, gp, (const unsigned short*)src,
-                               (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tn256, bnred, wred);
-          else
-            hipLaunchKernelGGL((igemm_bf16_ws_kernel<128, 2, 256>), grid256, block_ws, 0, s, gp, (const unsigned short*)src,
-                               (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tn256, bnred, wred);
+#define CREID_WS256_LAUNCH(NS_, ET_)                                                                                  \
+  hipLaunchKernelGGL((igemm_bf16_ws_kernel<128, NS_, 256, ET_>), grid256, block_ws, 0, s, gp, (const unsigned short*)src, \
+                     (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tn256, bnred, wred)
+          if (dtype == CREID_F16) { if (st256 == 3) CREID_WS256_LAUNCH(3, F16T); else CREID_WS256_LAUNCH(2, F16T); }
+          else { if (st256 == 3) CREID_WS256_LAUNCH(3, Bf16T); else CREID_WS256_LAUNCH(2, Bf16T); }
+#undef CREID_WS256_LAUNCH
           return (int)hipGetLastError();
         }
       }
       // 4 x 32 KB at BN = 128 is one workgroup per CU (the C staging reuses the ring): only on request of a measured plan
       if (ws_stages == 4 && bn == 128 && !(tuned_stages == 4 && use_ws != 2)) ws_stages = 3;
       const dim3 grid_ws((unsigned)(tiles_m * tiles_n + (wred.ws ? wred.nblocks : 0)));
-#define CREID_WS_LAUNCH(BN_, NS_)                                                                                     \
-  hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_>), grid_ws, block_ws, 0, s, gp, (const unsigned short*)src,       \
+#define CREID_WS_LAUNCH1(BN_, NS_, ET_)                                                                               \
+  hipLaunchKernelGGL((igemm_bf16_ws_kernel<BN_, NS_, 128, ET_>), grid_ws, block_ws, 0, s, gp, (const unsigned short*)src, \
                      (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n, \
                      bnred, wred)
+#define CREID_WS_LAUNCH(BN_, NS_) do { if (dtype == CREID_F16) CREID_WS_LAUNCH1(BN_, NS_, F16T); else CREID_WS_LAUNCH1(BN_, NS_, Bf16T); } while (0)
       if (bn == 128) { if (ws_stages == 4) CREID_WS_LAUNCH(128, 4); else if (ws_stages == 2) CREID_WS_LAUNCH(128, 2); else CREID_WS_LAUNCH(128, 3); }
       else { if (ws_stages == 4) CREID_WS_LAUNCH(64, 4); else if (ws_stages == 2) CREID_WS_LAUNCH(64, 2); else CREID_WS_LAUNCH(64, 3); }
 #undef CREID_WS_LAUNCH
+#undef CREID_WS_LAUNCH1
       return (int)hipGetLastError();
     }
     if (wred.ws) { const int rc = wgrad_reduce_job_launch(wred, s); if (rc) return rc; wred.ws = nullptr; }
@@ -1313,10 +1315,11 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
     // by the LDS->MFMA chain and by workgroups/CU, not by DMA latency; 3+ stages cost occupancy)
     static const int stages_env = [] { const char* e = getenv("CREID_IGEMM_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 5) ? v : 2; }();
     const int stages = (tuned_dma && tuned_stages) ? tuned_stages : stages_env;
-#define CREID_DMA_LAUNCH(BN_, NS_)                                                                                     \
-  hipLaunchKernelGGL((igemm_bf16_dma_kernel<BN_, NS_>), grid, block, 0, s, g, (const unsigned short*)src,              \
+#define CREID_DMA_LAUNCH1(BN_, NS_, ET_)                                                                               \
+  hipLaunchKernelGGL((igemm_bf16_dma_kernel<BN_, NS_, ET_>), grid, block, 0, s, g, (const unsigned short*)src,         \
                      (const unsigned short*)wgt, (unsigned short*)out, (const unsigned short*)add_src, bn_part, tiles_n, \
                      bnred)
+#define CREID_DMA_LAUNCH(BN_, NS_) do { if (dtype == CREID_F16) CREID_DMA_LAUNCH1(BN_, NS_, F16T); else CREID_DMA_LAUNCH1(BN_, NS_, Bf16T); } while (0)
     if (bn == 128) {
       switch (stages) { case 2: CREID_DMA_LAUNCH(128, 2); break; case 3: CREID_DMA_LAUNCH(128, 3); break;
                         case 4: case 5: CREID_DMA_LAUNCH(128, 4); break;   // 5 x 32 KB would not fit
@@ -1327,8 +1330,9 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
                         default: CREID_DMA_LAUNCH(64, 2); break; }
     }
 #undef CREID_DMA_LAUNCH
-  } else if (bnred.x || g.add_mask || (g.epi_scale && dtype == CREID_BF16)) {
-    return CREID_E_DTYPE;          // the fused reduction / masked add / folded BatchNorm exist only in the bf16 LDS-DMA kernels
+#undef CREID_DMA_LAUNCH1
+  } else if (bnred.x || g.add_mask || (g.epi_scale && creid_is16(dtype)) || dtype == CREID_F16) {
+    return CREID_E_DTYPE;          // the fused reduction / masked add / folded BatchNorm (and f16) exist only in the 16-bit LDS-DMA kernels
   } else if (wred.ws && wgrad_reduce_job_launch(wred, s) != 0) {
     return (int)hipGetLastError();
   } else if (dtype == CREID_BF16) {
@@ -1427,7 +1431,7 @@ int creid_conv2d_dgrad_bnred_nhwc(const creid_conv_desc* d, const void* dy, cons
   if (add_src_stride != 1 && add_src_stride != 2) return CREID_E_ARG;
   if (add_src_stride == 2 && (!add_src || d->in_h % 2 || d->in_w % 2)) return CREID_E_SHAPE;
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
-  if (dtype != CREID_BF16 || !use_dma) return CREID_E_DTYPE;
+  if (!creid_is16(dtype) || !use_dma) return CREID_E_DTYPE;
   IGemmGeom g;
   g.M = (int)(d->batch * d->in_h * d->in_w); g.OH = (int)d->in_h; g.OW = (int)d->in_w;
   g.SH = (int)d->out_h; g.SW = (int)d->out_w; g.pitch = (int)d->out_c; g.log2span = ilog2_exact(d->out_c);
@@ -1459,8 +1463,8 @@ int creid_conv2d_dgrad_fused_nhwc(const creid_conv_desc* d, const void* dy, cons
   if (add_src_stride != 1 && add_src_stride != 2) return CREID_E_ARG;
   if (add_src_stride == 2 && (!add_src || d->in_h % 2 || d->in_w % 2)) return CREID_E_SHAPE;
   static const int use_dma = [] { const char* e = getenv("CREID_IGEMM_DMA"); return e ? atoi(e) : 1; }();
-  if (bn_x && (dtype != CREID_BF16 || !use_dma)) return CREID_E_DTYPE;
-  if (add_mask && (!add_src || add_src_stride != 1 || dtype != CREID_BF16 || !use_dma)) return CREID_E_ARG;
+  if (bn_x && (!creid_is16(dtype) || !use_dma)) return CREID_E_DTYPE;
+  if (add_mask && (!add_src || add_src_stride != 1 || !creid_is16(dtype) || !use_dma)) return CREID_E_ARG;
   WRedJob job{};
   bool have_job = false;
   if (wred_desc) {

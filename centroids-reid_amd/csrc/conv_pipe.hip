@@ -86,7 +86,7 @@ struct PipeArgs {
 // EPI: 0 plain store (+ add_src), 1 BatchNorm statistics of the fp32 accumulators, 2 folded affine (+ residual) (+ ReLU) --
 // compile-time, because the per-element work of the copy-out is VALU-bound (a runtime choice made the compiler evaluate
 // every variant and select: ~450 instructions per 32-row piece, 3100 cycles of the 3300 a whole k-tile takes).
-template <int BM, int BN, int WN, int KPH, int GLM, int EPI>
+template <int BM, int BN, int WN, int KPH, int GLM, int EPI, typename ET>
 __global__ __launch_bounds__(512, 2) void igemm_bf16_pp_kernel(IGemmGeom g, PipeArgs pa) {
   constexpr int NT = 512, BK = 64, WM = 8 / WN;
   constexpr int MI = BM / WM / 32, NJ = BN / WN / 32;            // 32 x 32 accumulator blocks per wave
@@ -240,8 +240,7 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_pp_kernel(IGemmGeom g, Pipe
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
-                                                                acc[i][j], 0, 0, 0);
+            acc[i][j] = ET::mfma(a[i], b[j], acc[i][j]);
       };
       // (top of the tile: the whole of k-tile 1 was requested behind k-tile 0, see below)
       rd(0, 0, a0, b0);
@@ -323,8 +322,7 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_pp_kernel(IGemmGeom g, Pipe
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kq][i]),
-                                                                  __builtin_bit_cast(bf16x8, b[kq][j]), acc[i][j], 0, 0, 0);
+              acc[i][j] = ET::mfma(a[kq][i], b[kq][j], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
         if (ph == NPH - 1 && grp == 0 && more) pp_wait_vm<0>();   // group 0's pieces of k-tile t + 1
         pp_barrier();
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_pp_kernel(IGemmGeom g, Pipe
             s1 += v2; s2 = fmaf(v2, v2, s2);
             s1 += v3; s2 = fmaf(v3, v3, s2);
           }
-          *reinterpret_cast<uint2*>(&sb[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+          *reinterpret_cast<uint2*>(&sb[cl * CPT + rl]) = make_uint2(ET::pack2(v0, v1), ET::pack2(v2, v3));
         }
         s1r[j] = s1; s2r[j] = s2;
         if constexpr (EPI == 1) {
@@ -412,10 +410,10 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_pp_kernel(IGemmGeom g, Pipe
             unsigned* vw = &v.x; const unsigned* aw = &av.x;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
-              float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+              float lo = ET::lo(vw[q]) + ET::lo(aw[q]);
+              float hi = ET::hi(vw[q]) + ET::hi(aw[q]);
               if (affine && g.epi_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-              vw[q] = f32x2_to_bf16x2_bits(lo, hi);
+              vw[q] = ET::pack2(lo, hi);
             }
           }
           if (!CREID_ABL_ON(g.abl, 8)) *reinterpret_cast<uint4*>(pa.out + off) = v;
@@ -450,7 +448,8 @@ extern "C" int creid_dbg_pp_trace(void* buf) { g_pp_trace_buf = (unsigned long l
 #endif
 
 int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src, float* bn_part,
-                    int variant, hipStream_t s) {
+                    int variant, int dtype, hipStream_t s) {
+  if (!creid_is16(dtype)) return CREID_E_SHAPE;
   if (g.log2span < 6 || g.K % 64 != 0 || g.parity || g.add_compact || g.add_mask) return CREID_E_SHAPE;
   if (bn_part && (g.epi_scale || add_src)) return CREID_E_SHAPE;
   int bm = (variant & 3) * 128, bn = ((variant >> 2) & 3) * 128, kph = (variant >> 4) & 7, glm = (variant >> 8) & 3;
@@ -468,9 +467,15 @@ int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* 
   const int epi = g.epi_scale ? 2 : (bn_part ? 1 : 0);
 #define CREID_PP_LAUNCH(BM_, BN_, WN_, KPH_, GLM_)                                                          \
   do {                                                                                                      \
-    if (epi == 2) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 2>), grid, block, 0, s, g, pa);      \
-    else if (epi == 1) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 1>), grid, block, 0, s, g, pa); \
-    else hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 0>), grid, block, 0, s, g, pa);               \
+    if (dtype == CREID_F16) {                                                                               \
+      /* f16: the eval-mode forward (folded affine) and the plain forward; statistics / gradients run the tile kernels */ \
+      if (epi == 2) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 2, F16T>), grid, block, 0, s, g, pa); \
+      else if (epi == 0) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 0, F16T>), grid, block, 0, s, g, pa); \
+      else return CREID_E_SHAPE;                                                                            \
+    }                                                                                                       \
+    else if (epi == 2) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 2, Bf16T>), grid, block, 0, s, g, pa); \
+    else if (epi == 1) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 1, Bf16T>), grid, block, 0, s, g, pa); \
+    else hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 0, Bf16T>), grid, block, 0, s, g, pa);        \
   } while (0)
 #define CREID_PP_KPH(BM_, BN_, WN_)                                                                        \
   do {                                                                                                     \

@@ -33,6 +33,23 @@ template <> struct Vec16<unsigned short> {
   static __device__ __forceinline__ float rnd(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }   // value as stored
 };
 
+template <> struct Vec16<_Float16> {                            // f16 storage (the reference's own mixed precision)
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const _Float16* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = F16T::lo(w[i]); v[2 * i + 1] = F16T::hi(w[i]); }
+  }
+  static __device__ __forceinline__ void store(_Float16* p, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = F16T::pack2(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
+};
+
 // ------------------------------------------------------------------ BN statistics finalize
 // partial: [rows][2][C] (sum, sumsq per 128-row conv tile).  training: mean/invstd from the batch and
 // running-stat update (momentum, unbiased variance); eval: mean = running_mean, invstd = rsqrt(rv+eps).
@@ -761,10 +778,11 @@ static inline unsigned ew_blocks(int64_t total_threads_needed, int64_t mult) {
   return (unsigned)b;
 }
 
-#define DISPATCH_T(dtype, EXPR_F32, EXPR_BF16)          \
+#define DISPATCH_T(dtype, EXPR_F32, EXPR_BF16, EXPR_F16) \
   do {                                                  \
     if ((dtype) == CREID_F32) { EXPR_F32; }             \
     else if ((dtype) == CREID_BF16) { EXPR_BF16; }      \
+    else if ((dtype) == CREID_F16) { EXPR_F16; }        \
     else return CREID_E_DTYPE;                          \
   } while (0)
 
@@ -805,7 +823,9 @@ int creid_col_stats(const void* x, int64_t M, int64_t C, int dtype, float* parti
              hipLaunchKernelGGL(col_stats_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rows), dim3(256), 0, s,
                                 (const float*)x, M, (int)C, 128, partial),
              hipLaunchKernelGGL(col_stats_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256), 0,
-                                s, (const unsigned short*)x, M, (int)C, 128, partial));
+                                s, (const unsigned short*)x, M, (int)C, 128, partial),
+             hipLaunchKernelGGL(col_stats_kernel<_Float16>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256), 0,
+                                s, (const _Float16*)x, M, (int)C, 128, partial));
   CREID_LAUNCH_RET();
 }
 
@@ -820,7 +840,10 @@ int creid_bn2d_apply_mask(const void* x, const float* scale_shift, const void* r
                                 (uint8_t*)nullptr, (const float*)nullptr),
              hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, (const unsigned short*)residual, relu, M,
-                                (int)C, (unsigned short*)y, mask_out, (const float*)nullptr));
+                                (int)C, (unsigned short*)y, mask_out, (const float*)nullptr),
+             hipLaunchKernelGGL(bn2d_apply_kernel<_Float16>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+                                (const _Float16*)x, scale_shift, (const _Float16*)residual, relu, M,
+                                (int)C, (_Float16*)y, mask_out, (const float*)nullptr));
   CREID_LAUNCH_RET();
 }
 
@@ -835,7 +858,10 @@ int creid_bn2d_apply_dual_mask(const void* x, const float* scale_shift, const vo
                                 (uint8_t*)nullptr, scale_shift_res),
              hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, (const unsigned short*)x_res, relu, M,
-                                (int)C, (unsigned short*)y, mask_out, scale_shift_res));
+                                (int)C, (unsigned short*)y, mask_out, scale_shift_res),
+             hipLaunchKernelGGL(bn2d_apply_kernel<_Float16>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+                                (const _Float16*)x, scale_shift, (const _Float16*)x_res, relu, M,
+                                (int)C, (_Float16*)y, mask_out, scale_shift_res));
   CREID_LAUNCH_RET();
 }
 
@@ -863,6 +889,9 @@ static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const ui
                                 (const uint8_t*)nullptr, pg),
              hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
                                 0, s, (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, mean,
+                                invstd, M, (int)C, 128, partial, mask, pg),
+             hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<_Float16>, dim3((unsigned)((C / 8 + 31) / 32), rows), dim3(256),
+                                0, s, (const _Float16*)x, (const _Float16*)g, (const _Float16*)act, mean,
                                 invstd, M, (int)C, 128, partial, mask, pg));
   if (partial_ready != 2 && !fin_dry(2)) {
     if (C <= 256 && rows >= 512)
@@ -878,7 +907,10 @@ static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const ui
                                 (float*)dx, (float*)gm_out, (const uint8_t*)nullptr, pg),
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, sums, M,
-                                (int)C, (unsigned short*)dx, (unsigned short*)gm_out, mask, pg));
+                                (int)C, (unsigned short*)dx, (unsigned short*)gm_out, mask, pg),
+             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<_Float16>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+                                (const _Float16*)x, (const _Float16*)g, (const _Float16*)act, sums, M,
+                                (int)C, (_Float16*)dx, (_Float16*)gm_out, mask, pg));
   CREID_LAUNCH_RET();
 }
 
@@ -908,6 +940,9 @@ int creid_bn2d_apply_maxpool3x3s2(const void* x, const float* scale_shift, int r
                                 (const float*)x, scale_shift, relu, (int)B, (int)H, (int)W, (int)C, (float*)y, idx),
              hipLaunchKernelGGL(bn_apply_maxpool_kernel<unsigned short>, dim3(ew_blocks(B * H * W * C / 32, 1)), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, relu, (int)B, (int)H, (int)W, (int)C, (unsigned short*)y,
+                                idx),
+             hipLaunchKernelGGL(bn_apply_maxpool_kernel<_Float16>, dim3(ew_blocks(B * H * W * C / 32, 1)), dim3(256), 0, s,
+                                (const _Float16*)x, scale_shift, relu, (int)B, (int)H, (int)W, (int)C, (_Float16*)y,
                                 idx));
   CREID_LAUNCH_RET();
 }
@@ -927,7 +962,9 @@ int creid_maxpool3x3s2_fwd(const void* x, int64_t B, int64_t H, int64_t W, int64
              hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(B * H * W * C / 16, 1)), dim3(256), 0, s,
                                 (const float*)x, (int)B, (int)H, (int)W, (int)C, (float*)y, idx),
              hipLaunchKernelGGL(maxpool_fwd_kernel<unsigned short>, dim3(ew_blocks(B * H * W * C / 32, 1)), dim3(256), 0, s,
-                                (const unsigned short*)x, (int)B, (int)H, (int)W, (int)C, (unsigned short*)y, idx));
+                                (const unsigned short*)x, (int)B, (int)H, (int)W, (int)C, (unsigned short*)y, idx),
+             hipLaunchKernelGGL(maxpool_fwd_kernel<_Float16>, dim3(ew_blocks(B * H * W * C / 32, 1)), dim3(256), 0, s,
+                                (const _Float16*)x, (int)B, (int)H, (int)W, (int)C, (_Float16*)y, idx));
   CREID_LAUNCH_RET();
 }
 
@@ -939,7 +976,9 @@ int creid_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, int64_t B, int64_
              hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((unsigned)(B * H)), dim3(256), 0, s,
                                 (const float*)dy, idx, (int)B, (int)H, (int)W, (int)C, (float*)dx),
              hipLaunchKernelGGL(maxpool_bwd_kernel<unsigned short>, dim3((unsigned)(B * H)), dim3(256), 0, s,
-                                (const unsigned short*)dy, idx, (int)B, (int)H, (int)W, (int)C, (unsigned short*)dx));
+                                (const unsigned short*)dy, idx, (int)B, (int)H, (int)W, (int)C, (unsigned short*)dx),
+             hipLaunchKernelGGL(maxpool_bwd_kernel<_Float16>, dim3((unsigned)(B * H)), dim3(256), 0, s,
+                                (const _Float16*)dy, idx, (int)B, (int)H, (int)W, (int)C, (_Float16*)dx));
   CREID_LAUNCH_RET();
 }
 
@@ -950,7 +989,9 @@ int creid_gap_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, fl
              hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), (unsigned)B), dim3(256), 0, s,
                                 (const float*)x, (int)HW, (int)C, feat),
              hipLaunchKernelGGL(gap_fwd_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), (unsigned)B),
-                                dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, feat));
+                                dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, feat),
+             hipLaunchKernelGGL(gap_fwd_kernel<_Float16>, dim3((unsigned)((C / 8 + 31) / 32), (unsigned)B),
+                                dim3(256), 0, s, (const _Float16*)x, (int)HW, (int)C, feat));
   CREID_LAUNCH_RET();
 }
 
@@ -961,7 +1002,9 @@ int creid_gap_bwd(const float* dfeat, int64_t B, int64_t HW, int64_t C, int dtyp
              hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(ew_blocks(B * HW * C / 4, 1)), dim3(256), 0, s, dfeat, (int)HW,
                                 (int)C, B * HW * C / 4, (float*)dx),
              hipLaunchKernelGGL(gap_bwd_kernel<unsigned short>, dim3(ew_blocks(B * HW * C / 8, 1)), dim3(256), 0, s, dfeat,
-                                (int)HW, (int)C, B * HW * C / 8, (unsigned short*)dx));
+                                (int)HW, (int)C, B * HW * C / 8, (unsigned short*)dx),
+             hipLaunchKernelGGL(gap_bwd_kernel<_Float16>, dim3(ew_blocks(B * HW * C / 8, 1)), dim3(256), 0, s, dfeat,
+                                (int)HW, (int)C, B * HW * C / 8, (_Float16*)dx));
   CREID_LAUNCH_RET();
 }
 
@@ -973,7 +1016,9 @@ int creid_image_to_nhwc4_pad(const float* x_nchw, int64_t B, int64_t H, int64_t 
              hipLaunchKernelGGL(image_pad_kernel<float>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, x_nchw, (int)B, (int)H,
                                 (int)W, (float*)xpad),
              hipLaunchKernelGGL(image_pad_kernel<unsigned short>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, x_nchw, (int)B,
-                                (int)H, (int)W, (unsigned short*)xpad));
+                                (int)H, (int)W, (unsigned short*)xpad),
+             hipLaunchKernelGGL(image_pad_kernel<_Float16>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, x_nchw, (int)B,
+                                (int)H, (int)W, (_Float16*)xpad));
   CREID_LAUNCH_RET();
 }
 
@@ -986,7 +1031,9 @@ int creid_weight_prep(const float* w_oihw, int64_t O, int64_t I, int64_t kh, int
              hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, w_oihw, (int)O, (int)I,
                                 (int)kh, (int)kw, (float*)w_krsc, (float*)w_crsk),
              hipLaunchKernelGGL(weight_prep_kernel<unsigned short>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, w_oihw,
-                                (int)O, (int)I, (int)kh, (int)kw, (unsigned short*)w_krsc, (unsigned short*)w_crsk));
+                                (int)O, (int)I, (int)kh, (int)kw, (unsigned short*)w_krsc, (unsigned short*)w_crsk),
+             hipLaunchKernelGGL(weight_prep_kernel<_Float16>, dim3(ew_blocks(total, 1)), dim3(256), 0, s, w_oihw,
+                                (int)O, (int)I, (int)kh, (int)kw, (_Float16*)w_krsc, (_Float16*)w_crsk));
   CREID_LAUNCH_RET();
 }
 
@@ -1000,6 +1047,8 @@ int creid_weight_prep_multi(const void* table_dev, const int32_t* tile_start_dev
              hipLaunchKernelGGL(weight_prep_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, s,
                                 (const WPrepEntry*)table_dev, (int)n_entries, tile_start_dev),
              hipLaunchKernelGGL(weight_prep_multi_kernel<unsigned short>, dim3((unsigned)total_tiles), dim3(256), 0, s,
+                                (const WPrepEntry*)table_dev, (int)n_entries, tile_start_dev),
+             hipLaunchKernelGGL(weight_prep_multi_kernel<_Float16>, dim3((unsigned)total_tiles), dim3(256), 0, s,
                                 (const WPrepEntry*)table_dev, (int)n_entries, tile_start_dev));
   CREID_LAUNCH_RET();
 }
@@ -1019,7 +1068,9 @@ int creid_stem_weight_prep(const float* w_oihw, int dtype, void* w_stem, void* s
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(stem_weight_prep_kernel<float>, dim3(64), dim3(256), 0, s, w_oihw, (float*)w_stem),
              hipLaunchKernelGGL(stem_weight_prep_kernel<unsigned short>, dim3(64), dim3(256), 0, s, w_oihw,
-                                (unsigned short*)w_stem));
+                                (unsigned short*)w_stem),
+             hipLaunchKernelGGL(stem_weight_prep_kernel<_Float16>, dim3(64), dim3(256), 0, s, w_oihw,
+                                (_Float16*)w_stem));
   CREID_LAUNCH_RET();
 }
 
@@ -1030,7 +1081,9 @@ int creid_nhwc_to_nchw_f32(const void* x, int64_t B, int64_t HW, int64_t C, int 
              hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_blocks(B * HW * C, 1)), dim3(256), 0, s, (const float*)x,
                                 (int)B, (int)HW, (int)C, y),
              hipLaunchKernelGGL(nhwc_to_nchw_kernel<unsigned short>, dim3(ew_blocks(B * HW * C, 1)), dim3(256), 0, s,
-                                (const unsigned short*)x, (int)B, (int)HW, (int)C, y));
+                                (const unsigned short*)x, (int)B, (int)HW, (int)C, y),
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, dim3(ew_blocks(B * HW * C, 1)), dim3(256), 0, s,
+                                (const _Float16*)x, (int)B, (int)HW, (int)C, y));
   CREID_LAUNCH_RET();
 }
 
@@ -1363,7 +1416,9 @@ int creid_ibn_fwd_mask(const void* x, int64_t B, int64_t HW, int64_t C, int64_t 
              hipLaunchKernelGGL(ibn_col_stats_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), rpi, (unsigned)B), dim3(256),
                                 0, s, (const float*)x, (int)HW, (int)C, 128, rpi, partial),
              hipLaunchKernelGGL(ibn_col_stats_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
-                                dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, 128, rpi, partial));
+                                dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, 128, rpi, partial),
+             hipLaunchKernelGGL(ibn_col_stats_kernel<_Float16>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
+                                dim3(256), 0, s, (const _Float16*)x, (int)HW, (int)C, 128, rpi, partial));
   hipLaunchKernelGGL(ibn_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, (int)B,
                      rpi, (int)HW, (int)C, (int)c_in, in_w, in_b, bn_w, bn_b, running_mean, running_var, training, momentum,
                      eps, mean_out, invstd_out, scale_shift);
@@ -1371,7 +1426,9 @@ int creid_ibn_fwd_mask(const void* x, int64_t B, int64_t HW, int64_t C, int64_t 
              hipLaunchKernelGGL(ibn_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4), (unsigned)B), dim3(256), 0, s, (const float*)x,
                                 scale_shift, relu, B * HW, (int)HW, (int)C, (float*)y, (uint8_t*)nullptr),
              hipLaunchKernelGGL(ibn_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
-                                (const unsigned short*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (unsigned short*)y, mask_out));
+                                (const unsigned short*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (unsigned short*)y, mask_out),
+             hipLaunchKernelGGL(ibn_apply_kernel<_Float16>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
+                                (const _Float16*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (_Float16*)y, mask_out));
   CREID_LAUNCH_RET();
 }
 
@@ -1400,7 +1457,10 @@ int creid_ibn_bwd_mask(const void* x, const void* g, const void* act, const uint
                                 rpi, partial, (const uint8_t*)nullptr),
              hipLaunchKernelGGL(ibn_bwd_reduce_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
                                 dim3(256), 0, s, (const unsigned short*)x, (const unsigned short*)g,
-                                (const unsigned short*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial, mask));
+                                (const unsigned short*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial, mask),
+             hipLaunchKernelGGL(ibn_bwd_reduce_kernel<_Float16>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
+                                dim3(256), 0, s, (const _Float16*)x, (const _Float16*)g,
+                                (const _Float16*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial, mask));
   hipLaunchKernelGGL(ibn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial,
                      (int)B, rpi, (int)HW, (int)C, (int)c_in, mean, invstd, in_w, bn_w, coef, per_img, d_bn_w, d_bn_b);
   hipLaunchKernelGGL(ibn_in_grad_kernel, dim3((unsigned)((c_in + 255) / 256)), dim3(256), 0, s, per_img, (int)B, (int)c_in,
@@ -1410,7 +1470,10 @@ int creid_ibn_bwd_mask(const void* x, const void* g, const void* act, const uint
                                 (const float*)x, (const float*)g, (const float*)act, coef, B * HW, (int)HW, (int)C, (float*)dx, (const uint8_t*)nullptr),
              hipLaunchKernelGGL(ibn_bwd_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
                                 (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, coef, B * HW,
-                                (int)HW, (int)C, (unsigned short*)dx, mask));
+                                (int)HW, (int)C, (unsigned short*)dx, mask),
+             hipLaunchKernelGGL(ibn_bwd_apply_kernel<_Float16>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
+                                (const _Float16*)x, (const _Float16*)g, (const _Float16*)act, coef, B * HW,
+                                (int)HW, (int)C, (_Float16*)dx, mask));
   CREID_LAUNCH_RET();
 }
 

@@ -25,7 +25,7 @@ CASES = [  # B, H, W, cin, cout, k, stride, residual, relu
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_affine_layer(case, dtype):
     from centroids_reid_amd import layers as ly
@@ -54,7 +54,7 @@ def test_conv_affine_layer(case, dtype):
     xg = x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
     rg = res.permute(0, 2, 3, 1).contiguous().cuda() if res is not None else None
     yg = ly.conv2d_fwd_affine(xg, krsc, stride, pad, ss, rg, relu)
-    rt, at = (3e-2, 3e-2) if dtype == torch.bfloat16 else (1e-4, 1e-4)
+    rt, at = {torch.bfloat16: (3e-2, 3e-2), torch.float16: (4e-3, 4e-3), torch.float32: (1e-4, 1e-4)}[dtype]
     np.testing.assert_allclose(yg.float().cpu().permute(0, 3, 1, 2).numpy(), y.float().numpy(), rtol=rt, atol=at)
     if relu:
         assert float(yg.float().min()) >= 0.0
@@ -104,6 +104,36 @@ def test_folded_eval_forward_bf16_close_to_fp32(arch, H, W):
     assert float(cos.min()) > 0.995, cos
     # one rounding per layer instead of two: the folded bf16 forward is no further from fp32 than the unfolded one (+ slack)
     assert float((1 - cos).max()) <= 1.5 * float((1 - cos_u).max()) + 1e-4
+
+
+@pytest.mark.parametrize("arch,H,W", [("resnet50", 256, 128), ("resnet50_ibn_a", 64, 64)])
+def test_folded_eval_forward_f16_closer_to_fp32_than_bf16(arch, H, W):
+    """f16 as the compute type of the eval-mode forward (the reference's mixed precision is fp16 autocast, utils/misc.py:111):
+    10 explicit mantissa bits against bf16's 7 -- the embeddings must sit several times closer to the fp32 ones, finite, and the
+    folded forward must equal the three-launch schedule's arithmetic up to one rounding per layer."""
+    from oracle import backbone_oracle as bo
+    sd = {k: v.cuda() for k, v in bo.make_state_dict(arch, 1, seed=12).items()}
+    x = bo.synthetic_images(4, H, W, seed=3).cuda()
+    _, f32, _ = _eval_feat(arch, torch.float32, True, x, sd)
+    _, fbf, _ = _eval_feat(arch, torch.bfloat16, True, x, sd)
+    _, fh, _ = _eval_feat(arch, torch.float16, True, x, sd)
+    assert bool(torch.isfinite(fh).all())
+    cos_b = F.cosine_similarity(f32, fbf, dim=1)
+    cos_h = F.cosine_similarity(f32, fh, dim=1)
+    assert float(cos_h.min()) > 0.9999, cos_h
+    assert float((1 - cos_h).max()) < 0.25 * float((1 - cos_b).max()), (cos_h, cos_b)
+    rel = float(((fh - f32).norm(dim=1) / f32.norm(dim=1)).max())
+    assert rel < 1e-2, rel
+
+
+def test_f16_training_forward_is_refused():
+    from oracle import backbone_oracle as bo
+    from centroids_reid_amd import backbone as bb
+    net = bb.ResNet(last_stride=1).cuda()
+    eng = bb.BackboneEngine(net, torch.float16)
+    x = bo.synthetic_images(2, 64, 32, seed=4).cuda()
+    with pytest.raises(NotImplementedError):
+        eng.forward(x, True)
 
 
 def test_eval_forward_after_training_step_uses_fresh_statistics():
