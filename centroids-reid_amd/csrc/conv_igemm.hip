@@ -27,7 +27,7 @@ int wgrad_reduce_job_launch(const WRedJob& j, hipStream_t s);
 // defined in conv_stream.hip
 int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, hipStream_t s);
 int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, const void* add_src,
-                   const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, hipStream_t s);
+                   const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, int dtype, hipStream_t s);
 // defined in conv_pipe.hip
 int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src, float* bn_part,
                     int variant, int dtype, hipStream_t s);
@@ -1211,8 +1211,8 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   const int plan_d = g.transposed | (g.stride << 1);
   const bool have_plan = creid_is16(dtype) && ((g.epi_scale && creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, plan_d | 8, tp)) ||
                                                   creid_tune_lookup(CREID_TUNE_IGEMM, g.M, g.N, g.K, plan_d, tp));
-  if (have_plan && dtype == CREID_F16 && (tp.p2 == 2 || tp.p2 == 4)) {
-    // (the persistent 1x1 kernels of conv_stream.hip are bf16 only: f16 launches of those shapes take the built-in rule)
+  if (have_plan && dtype == CREID_F16 && tp.p2 == 2) {
+    // (the first persistent 1x1 kernel of conv_stream.hip is bf16 only: f16 launches of those shapes take the built-in rule)
   } else if (have_plan && tp.p2 == 5) {
     tuned_pp = tp.p0;                                              // plan kind 5: all-waves-multiply persistent kernel, p0 = its variant word
   } else if (have_plan && (tp.p0 == 64 || tp.p0 == 128) && g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
@@ -1241,13 +1241,13 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
     // second form (plan kind 4 / CREID_STREAM2=1): also the folded eval-mode epilogue with the block's residual
     const char* f2 = getenv("CREID_STREAM2");
     const int force2 = f2 ? atoi(f2) : 0;
-    const bool fwd_1x1 = dtype == CREID_BF16 && !g.transposed && g.K == (1 << g.log2span) && g.stride == 1 && g.pad == 0 &&
+    const bool fwd_1x1 = creid_is16(dtype) && !g.transposed && g.K == (1 << g.log2span) && g.stride == 1 && g.pad == 0 &&
                          g.kw == 1 && g.check_bounds && !bnred.x && !wred.ws && g.pitch == g.K && !g.add_compact && !g.add_mask &&
                          !(bn_part && (g.epi_scale || add_src));
     if (fwd_1x1 && (force2 || tuned_stream2)) {
       // (plan: p1 = 2 -> widest column slab the LDS allows, 3 -> at most 128 columns, 4 -> 64)
       const int cap = tuned_stream2 ? (tuned_stages == 3 ? 128 : (tuned_stages == 4 ? 64 : 0)) : 0;
-      const int rc = launch_stream2(g.M, g.K, g.N, src, wgt, out, bn_part, add_src, g.epi_scale, g.epi_shift, g.epi_relu, cap, s);
+      const int rc = launch_stream2(g.M, g.K, g.N, src, wgt, out, bn_part, add_src, g.epi_scale, g.epi_shift, g.epi_relu, cap, dtype, s);
       if (rc != CREID_E_SHAPE) return rc;
     }
   }

@@ -257,7 +257,7 @@ int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void
 //     with the block's residual added in the copy-out (the arithmetic of igemm_bf16_ws_kernel: identical bits).
 // K = 64 / 128 / 256 (KCH = 1, 2, 4); BN = 64 / 128 / 256 columns per workgroup; RT = 2 ring slots, or 1 where LDS allows no more
 // (K = 256 with 64-column slabs, K = 128 with 256-column slabs): the tile is then written into the slot between two barriers.
-template <int BN, int KCH, int RT>
+template <int BN, int KCH, int RT, typename ET = Bf16T>
 __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned short* __restrict__ src, int M, int K, int N,
                                                                    const unsigned short* __restrict__ wgt,
                                                                    unsigned short* __restrict__ out, float* __restrict__ bn_part,
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
         }
 #pragma unroll
         for (int j = 0; j < TW; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[j]), acc[j], 0, 0, 0);
+          acc[j] = ET::mfma(a, b[j], acc[j]);
       }
     }
     if (bn_part) {                                                // column sums of the fp32 accumulators (rows >= M are zero)
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
             v0 = fmaf(v0, sc[j], sh[j]); v1 = fmaf(v1, sc[j], sh[j]); v2 = fmaf(v2, sc[j], sh[j]); v3 = fmaf(v3, sc[j], sh[j]);
             if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
           }
-          *reinterpret_cast<uint2*>(&stage[cl * CPT + rl]) = make_uint2(f32x2_to_bf16x2_bits(v0, v1), f32x2_to_bf16x2_bits(v2, v3));
+          *reinterpret_cast<uint2*>(&stage[cl * CPT + rl]) = make_uint2(ET::pack2(v0, v1), ET::pack2(v2, v3));
         }
       }
       __syncthreads();                                            // the half is staged (and `red` is complete)
@@ -488,10 +488,10 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
           unsigned* vw = &v.x; const unsigned* aw = &a.x;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
-            float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+            float lo = ET::lo(vw[q]) + ET::lo(aw[q]);
+            float hi = ET::hi(vw[q]) + ET::hi(aw[q]);
             if (epi_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-            vw[q] = f32x2_to_bf16x2_bits(lo, hi);
+            vw[q] = ET::pack2(lo, hi);
           }
         }
         outv[h][i] = v;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
 
 // Returns CREID_E_SHAPE when the GEMM is outside the kernel's scope (the caller then uses conv_igemm.hip's kernels).
 int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, const void* add_src,
-                   const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, hipStream_t s) {
+                   const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, int dtype, hipStream_t s) {
   if (K != 64 && K != 128 && K != 256) return CREID_E_SHAPE;
   int bn = N >= 256 ? 256 : N;
   if (K == 256 && bn > 64) bn = 64;                    // LDS: weight slab + one 64 KB tile slot + staging
@@ -523,10 +523,12 @@ int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* 
 #else
   const int abl = 0;
 #endif
-#define CREID_ST2_LAUNCH(BN_, KCH_, RT_)                                                                                \
-  hipLaunchKernelGGL((igemm1x1_stream2_kernel<BN_, KCH_, RT_>), grid, block, 0, s, (const unsigned short*)src, M, K, N, \
+#define CREID_ST2_LAUNCH1(BN_, KCH_, RT_, ET_)                                                                          \
+  hipLaunchKernelGGL((igemm1x1_stream2_kernel<BN_, KCH_, RT_, ET_>), grid, block, 0, s, (const unsigned short*)src, M, K, N, \
                      (const unsigned short*)wgt, (unsigned short*)out, bn_part, (const unsigned short*)add_src, epi_scale, \
                      epi_shift, epi_relu, tiles_m, tiles_n, abl)
+#define CREID_ST2_LAUNCH(BN_, KCH_, RT_) \
+  do { if (dtype == CREID_F16) CREID_ST2_LAUNCH1(BN_, KCH_, RT_, F16T); else CREID_ST2_LAUNCH1(BN_, KCH_, RT_, Bf16T); } while (0)
   if (K == 64) {
     if (bn == 256) CREID_ST2_LAUNCH(256, 1, 2); else if (bn == 128) CREID_ST2_LAUNCH(128, 1, 2); else CREID_ST2_LAUNCH(64, 1, 2);
   } else if (K == 128) {
@@ -535,5 +537,6 @@ int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* 
     CREID_ST2_LAUNCH(64, 4, 1);
   }
 #undef CREID_ST2_LAUNCH
+#undef CREID_ST2_LAUNCH1
   return (int)hipGetLastError();
 }

@@ -39,12 +39,16 @@ def make_grad_sync(world):
     """grad_sync hook for CTLModel: all-reduce the flat Adam gradient buffer and the centers' gradient;
     the 1/world of the big buffer is folded into the Adam kernel (grad_scale) instead of a separate pass."""
     def sync(model):
-        opt, _ = model.optimizers()
-        dist.all_reduce(opt.gflat, op=dist.ReduceOp.SUM)
+        opt, opt_c = model.optimizers()
+        opt, opt_c = getattr(opt, "_optimizer", opt), getattr(opt_c, "_optimizer", opt_c)
+        dist.all_reduce(opt.gflat, op=dist.ReduceOp.SUM)          # (the centers' gradient rides in its tail: solver.build_optimizer)
         opt.grad_scale = 1.0 / world
-        cg = model.center_loss.centers.grad
-        dist.all_reduce(cg, op=dist.ReduceOp.SUM)
-        cg.mul_(1.0 / world)
+        if getattr(opt_c, "grad_in_adam_tail", False):
+            opt_c.grad_scale = 1.0 / world
+        else:
+            cg = model.center_loss.centers.grad
+            dist.all_reduce(cg, op=dist.ReduceOp.SUM)
+            cg.mul_(1.0 / world)
     return sync
 
 
@@ -99,16 +103,29 @@ def _layer_number(group_name: str) -> int:
     return int(m.group(1))
 
 
-def make_overlapped_grad_sync(model, world, groups=("layer4.", "layer3.")):
+def _default_groups():
+    """Layer groups whose gradient buckets are all-reduced as they become final.  Default: layer4 (+ heads + the centers'
+    gradient in the buffer's tail) | layer3 | the rest = 3 collectives per step; CREID_DDP_GROUPS="layer4." makes it 2
+    (the last one then carries 34 MB instead of 6 MB with nothing left to hide it behind)."""
+    import os
+    e = os.environ.get("CREID_DDP_GROUPS")
+    return tuple(g for g in e.split(",") if g) if e else ("layer4.", "layer3.")
+
+
+def make_overlapped_grad_sync(model, world, groups=None):
     """Returns (buckets, on_group_done, finish): `on_group_done(k)` is the backbone engine's backward hook (k = 4, 3,
     2, 1 after layer k's last kernel has been enqueued): it all-reduces the bucket that just became final on a side
     stream; `finish()` reduces what is left (first bucket, centers) and makes the main stream wait for the side
     stream before the optimiser kernels.  Works with eager steps and with the step captured as per-bucket graph
     segments (bench_train.DDPStepper)."""
-    opt, _ = model.optimizers()
-    opt = getattr(opt, "_optimizer", opt)
-    buckets = GradBuckets.for_optimizer(opt, groups)
+    groups = _default_groups() if groups is None else groups
+    opt, opt_c = model.optimizers()
+    opt, opt_c = getattr(opt, "_optimizer", opt), getattr(opt_c, "_optimizer", opt_c)
+    buckets = GradBuckets.for_optimizer(opt, groups)              # (the first bucket ends at the buffer's end: tail included)
     opt.grad_scale = 1.0 / world
+    tail = getattr(opt_c, "grad_in_adam_tail", False)
+    if tail:
+        opt_c.grad_scale = 1.0 / world
     side = torch.cuda.Stream()
     layer_to_bucket = {}
     for i, g in enumerate(groups):
@@ -130,11 +147,12 @@ def make_overlapped_grad_sync(model, world, groups=("layer4.", "layer3.")):
     def finish():
         while state["next"] < len(buckets):
             _launch(state["next"]); state["next"] += 1
-        cg = model.center_loss.centers.grad
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            dist.all_reduce(cg, op=dist.ReduceOp.SUM)
-            cg.mul_(1.0 / world)
+        if not tail:
+            cg = model.center_loss.centers.grad
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dist.all_reduce(cg, op=dist.ReduceOp.SUM)
+                cg.mul_(1.0 / world)
         torch.cuda.current_stream().wait_stream(side)
         state["next"] = 0
 

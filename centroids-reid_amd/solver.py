@@ -22,11 +22,13 @@ def flat_offsets(params):
     return offs, off
 
 
-def flatten_(params, device):
-    """Re-home `params` (list of nn.Parameter) as views of one flat fp32 buffer; returns (flat, gflat)."""
+def flatten_(params, device, grad_tail=0):
+    """Re-home `params` (list of nn.Parameter) as views of one flat fp32 buffer; returns (flat, gflat).  `grad_tail` extra
+    elements behind the gradients: room for the gradient of parameters another optimiser owns (the centers), so that ONE
+    collective carries both."""
     offs, n_pad = flat_offsets(params)
     flat = torch.zeros(n_pad, dtype=torch.float32, device=device)
-    gflat = torch.zeros(n_pad, dtype=torch.float32, device=device)
+    gflat = torch.zeros(n_pad + grad_tail, dtype=torch.float32, device=device)
     for p, off in zip(params, offs):
         k = p.numel()
         flat[off:off + k].copy_(p.data.reshape(-1))
@@ -38,11 +40,12 @@ def flatten_(params, device):
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (L2 weight decay in the gradient) -- one kernel over the flat buffer."""
 
-    def __init__(self, param_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, param_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_tail=0):
         super().__init__(param_groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         params = [p for g in self.param_groups for p in g["params"]]
         assert len(self.param_groups) == 1
-        self.flat, self.gflat = flatten_(params, params[0].device)
+        self.flat, self.gflat = flatten_(params, params[0].device, grad_tail)
+        self.gtail = self.gflat[self.flat.numel():]          # not an Adam gradient: see build_optimizer
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.grad_scale = 1.0
@@ -114,6 +117,20 @@ class CenterSGD(torch.optim.Optimizer):
     def __init__(self, param_groups, lr=0.5):
         super().__init__(param_groups, dict(lr=lr))
         self.grad_mul = 1.0
+        self.grad_scale = 1.0          # data-parallel 1 / world when the gradient was SUM-reduced inside the Adam buffer's tail
+        self.grad_in_adam_tail = False
+
+    def adopt_tail(self, tail):
+        """The parameters' gradients become views of `tail` (the room behind FusedAdam's flat gradient buffer): the
+        data-parallel all-reduce of that buffer then carries them too -- one collective less per step."""
+        off = 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                k = p.numel()
+                assert off + k <= tail.numel()
+                p.grad = tail[off:off + k].view(p.shape)
+                off += (k + 3) // 4 * 4
+        self.grad_in_adam_tail = True
 
     def zero_grad(self, set_to_none: bool = False):
         for g in self.param_groups:
@@ -130,7 +147,7 @@ class CenterSGD(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 L.check(L.lib().creid_sgd_scaled_step(L.ptr(p.data), L.ptr(p.grad), p.numel(), float(g["lr"]),
-                                                      float(self.grad_mul), L.stream()), "creid_sgd_scaled_step")
+                                                      float(self.grad_mul) * float(self.grad_scale), L.stream()), "creid_sgd_scaled_step")
         self.grad_mul = 1.0
 
 
@@ -147,9 +164,14 @@ def build_optimizer(named_parameters, hparams):
             regular.append(parameter); regular_names.append(name)
     if hparams.SOLVER.OPTIMIZER_NAME != "Adam":
         raise NotImplementedError(f"No such optimizer {hparams.SOLVER.OPTIMIZER_NAME}")
+    # the centers' gradient lives behind the Adam group's flat gradient buffer (never seen by the Adam kernel, whose length is
+    # the parameter buffer's): the gradient all-reduce of the last layer group carries it (parallel.py)
+    tail = sum((p.numel() + 3) // 4 * 4 for p in center)
     model_optimizer = FusedAdam([{"params": regular, "names": regular_names}], lr=hparams.SOLVER.BASE_LR,
-                                weight_decay=hparams.SOLVER.WEIGHT_DECAY)
+                                weight_decay=hparams.SOLVER.WEIGHT_DECAY, grad_tail=tail)
     optimizer_center = CenterSGD([{"params": center, "names": center_names}], lr=hparams.SOLVER.CENTER_LR)
+    if tail:
+        optimizer_center.adopt_tail(model_optimizer.gtail)
     return [model_optimizer, optimizer_center]
 
 

@@ -137,11 +137,12 @@ def test_stream_1x1_forward_matches_tile_kernel(B, H, W, cin, cout, wgs, monkeyp
     np.testing.assert_allclose(y1.float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("wgs", [256, 5])
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 8, 64, 256), (2, 16, 16, 128, 512), (5, 32, 16, 64, 64), (1, 10, 10, 64, 256),
                                             (7, 24, 12, 128, 128), (2, 12, 12, 64, 128), (9, 40, 20, 64, 256), (3, 33, 17, 128, 64),
                                             (3, 20, 10, 256, 64), (2, 16, 16, 256, 128), (5, 16, 8, 256, 1024)])
-def test_stream2_forward_matches_tile_kernel(B, H, W, cin, cout, wgs, monkeypatch):
+def test_stream2_forward_matches_tile_kernel(B, H, W, cin, cout, wgs, dtype, monkeypatch):
     """Second form of the persistent 1x1 kernel (igemm1x1_stream2_kernel: eight like waves, copy-out one tile behind) against the
     tile-per-workgroup kernels on the same inputs, all three epilogues: training forward (identical bf16 output, statistics
     partials equal up to the grouping of the fp32 column sums), folded eval-mode affine with and without ReLU, and affine +
@@ -149,11 +150,11 @@ def test_stream2_forward_matches_tile_kernel(B, H, W, cin, cout, wgs, monkeypatc
     residual prefetch one tile ahead, a partial last tile, several column slabs)."""
     from centroids_reid_amd import layers as ly
     rng = np.random.default_rng(B * 1000 + cin + cout)
-    x = torch.from_numpy(rng.standard_normal((B, H, W, cin)).astype(np.float32)).to(torch.bfloat16).cuda()
+    x = torch.from_numpy(rng.standard_normal((B, H, W, cin)).astype(np.float32)).to(dtype).cuda()
     w = torch.from_numpy((rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)).cuda()
-    krsc, _ = ly.weight_prep(w, torch.bfloat16)
+    krsc, _ = ly.weight_prep(w, dtype)
     ss = torch.from_numpy(np.stack([rng.uniform(0.5, 1.5, cout), rng.standard_normal(cout) * 0.3]).astype(np.float32)).cuda()
-    res = torch.from_numpy(rng.standard_normal((B, H, W, cout)).astype(np.float32)).to(torch.bfloat16).cuda()
+    res = torch.from_numpy(rng.standard_normal((B, H, W, cout)).astype(np.float32)).to(dtype).cuda()
 
     def run():
         y, p = ly.conv2d_fwd(x, krsc, 1, 0, with_stats=True)
@@ -170,7 +171,8 @@ def test_stream2_forward_matches_tile_kernel(B, H, W, cin, cout, wgs, monkeypatc
         assert torch.equal(new[k], base[k]), k
     np.testing.assert_allclose(new[1].cpu().numpy(), base[1].cpu().numpy(), rtol=1e-6, atol=1e-5)
     ref = torch.einsum("bhwc,oc->bhwo", x.float(), krsc.view(cout, cin).float())
-    np.testing.assert_allclose(new[0].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(new[0].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 3e-3,
+                               atol=2e-2 if dtype == torch.bfloat16 else 3e-3)
     assert float(new[5].float().min()) >= 0.0
 
 

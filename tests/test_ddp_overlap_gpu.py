@@ -58,3 +58,37 @@ def test_bench_data_parallel_path_over_one_rank_rccl_group_matches_single_proces
     assert losses["single"][0] == losses["rccl1"][0], losses
     # three graph replays + four host-issued collectives per step instead of one replay: a bounded overhead
     assert losses["rccl1"][1] < 1.5 * losses["single"][1] + 1.0, losses
+
+
+def test_bench_gpus_2_contract_two_ranks_one_gpu():
+    """The exact command the scaling driver issues -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`
+    -- on a one-GPU box (both ranks on cuda:0, gloo for the collectives: CREID_DIST_BACKEND=gloo CREID_SINGLE_DEVICE=1): rc 0,
+    exactly ONE stdout line, the N = 2 control flow of every object in it (global batch, dp2, whole-job embeddings/s, the
+    query-sharded evaluation with the gallery all-gather), and the evaluation's mAP equal to the single-process value."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CREID_DIST_BACKEND="gloo", CREID_SINGLE_DEVICE="1",
+               CREID_BENCH_NO_INSITU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 2 * line["config"]["P"] * line["config"]["K"]
+    assert line["value"] > 0 and line["higher_is_better"] is True and line["unit"] == "images/s"
+    emb = line.get("embed_ranks") or line["embed"]
+    assert emb["config"]["parallelism"] == "dp2" and emb["value"] > 0 and emb["scaling"] == "weak"
+    ev = line["eval"]
+    assert ev["config"]["parallelism"] == "query-shard x2, gallery all-gather" and ev["value"] > 0
+    # the sharded evaluation must reproduce the single-process metric on the same seeded features
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "eval", "--steps", "2", "--warmup", "1",
+                             "--no-cpu-baseline"], cwd=ROOT, env={k: v for k, v in env.items() if not k.startswith("CREID_DIST") and k != "CREID_SINGLE_DEVICE"},
+                            capture_output=True, text=True, timeout=900)
+    assert single.returncode == 0, (single.stdout + single.stderr)[-3000:]
+    sline = json.loads([ln for ln in single.stdout.strip().splitlines() if ln.strip()][-1])
+    assert abs(ev["mAP"] - sline["mAP"]) < 1e-12, (ev["mAP"], sline["mAP"])

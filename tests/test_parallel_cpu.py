@@ -52,6 +52,27 @@ def test_grad_sync_mean_gloo():
         np.testing.assert_allclose(b, 1.5)
 
 
+def _grad_sync_tail_case(rank, world):
+    """The centers' gradient as the TAIL of the flat gradient buffer (solver.build_optimizer): one collective carries both,
+    the 1 / world of the centers goes into the SGD kernel's scale."""
+    import types
+    from centroids_reid_amd import parallel as par
+    gflat = torch.arange(16, dtype=torch.float32) * (rank + 1)           # 10 Adam gradients + 6 of the centers
+    cgrad = gflat[10:].view(2, 3)
+    opt = types.SimpleNamespace(gflat=gflat, grad_scale=1.0)
+    opt_c = types.SimpleNamespace(grad_in_adam_tail=True, grad_scale=1.0)
+    model = types.SimpleNamespace(optimizers=lambda: (opt, opt_c),
+                                  center_loss=types.SimpleNamespace(centers=types.SimpleNamespace(grad=cgrad)))
+    par.make_grad_sync(world)(model)
+    return (opt.gflat * opt.grad_scale).numpy(), (cgrad * opt_c.grad_scale).numpy()
+
+
+def test_grad_sync_centers_in_tail_gloo():
+    for g, c in _run(_grad_sync_tail_case):
+        np.testing.assert_allclose(g, np.arange(16) * 1.5)
+        np.testing.assert_allclose(c.reshape(-1), np.arange(10, 16) * 1.5)
+
+
 def _eval_case(rank, world):
     from centroids_reid_amd import parallel as par
     from oracle import reid_oracle as ro
