@@ -29,6 +29,10 @@ def _inference(model, batch, use_cuda=True, normalize_with_bn=True, transform=No
         if data.dtype == torch.uint8:
             if transform is None:
                 raise ValueError("uint8 image batches need `transform` (transforms.ReidTransforms(cfg).build_transforms(False))")
+            if callable(transform) and getattr(transform, "_lazy_cfg", None) is not None:
+                transform = transform()                          # built on the first uint8 batch only (run_inference)
+            # the device-side transform IS a GPU kernel: a uint8 batch goes to the device whatever `use_cuda` says (the flag only
+            # keeps the reference's meaning for float batches, which a CPU-resident model could not run here anyway)
             data = transform(data.cuda(), layout="stem", dtype=model.backbone.engine.dtype)
         else:
             data = data.cuda() if use_cuda else data
@@ -44,8 +48,16 @@ def run_inference(model, val_loader, cfg=None, print_freq=0, use_cuda=True, tran
     [B, H, W, 3] batches is normalised on the device (`transform`, or the test transform built from `cfg`)."""
     embs, paths = [], []
     if transform is None and cfg is not None:
-        from .transforms import ReidTransforms
-        transform = ReidTransforms(cfg).build_transforms(is_train=False)
+        # built lazily: a float loader never touches cfg.INPUT.* (a partial cfg without those keys stays usable)
+        built = {}
+
+        def _lazy():
+            if "t" not in built:
+                from .transforms import ReidTransforms
+                built["t"] = ReidTransforms(cfg).build_transforms(is_train=False)
+            return built["t"]
+        _lazy._lazy_cfg = cfg
+        transform = _lazy
     for batch in val_loader:
         e, p = _inference(model, batch, use_cuda, transform=transform)
         embs.append(e.float())

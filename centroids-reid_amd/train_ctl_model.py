@@ -80,9 +80,15 @@ class CTLModel(ModelBase):
         P = B // K
         dev = x.device
         # hand-scheduled heads (same kernels, no autograd tape).  K <= 16: creid_loo_emb_bwd keeps one register slot per
-        # instance of a pid.  All-real batches take the unmasked schedule; batches with padded samples (isReal = False,
-        # datasets/bases.py:346-406) the masked one, driven by a DEVICE mask: given isReal on the device the step contains
-        # no host synchronisation for any pattern of fakes (hipGraph-capturable, bench.py's "fake_mix" line)
+        # instance of a pid.  isReal on the HOST: all-real batches take the unmasked schedule, batches with padded samples
+        # (isReal = False, datasets/bases.py:346-406) the masked one.  isReal on the DEVICE (what Lightning hands over once it has
+        # moved the batch): ALWAYS the masked schedule, driven by the device mask -- no host synchronisation for any pattern of
+        # fakes (hipGraph-capturable, bench.py's "fake_mix" line).  One divergence from the reference on that path, accepted for
+        # the missing sync: an identity with exactly ONE real instance makes the reference fail in labels.expand
+        # (losses/triplet_loss.py:88; the host path below raises the same way); the device path cannot look at the mask, so the
+        # lonely row simply drops out of its round (`exists = qreal && cnt > 0` in creid_loo_emb_fwd_rows) and training goes on.
+        # The reference's own sampler never produces such a batch (PK batches pad whole instances of an identity that has
+        # at least two real ones, datasets/bases.py:374-395).
         fused_ok = (self.fused_heads and P >= 2 and 2 <= K <= 16 and x.is_cuda and hasattr(self.backbone, "engine")
                     and self.backbone.training and self.contrastive_loss.margin is not None
                     and self.contrastive_loss.dist_name == "euclidean")

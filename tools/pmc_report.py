@@ -1,8 +1,8 @@
-"""Turn the gpurun_out/pmc_*.json passes (tools/pmc_run.sh) into profiles/<round>_pmc_traffic.json + profiles/<round>_pmc_summary.md (CREID_ROUND, default r03)."""
+"""Turn the gpurun_out/pmc_*.json passes (tools/pmc_run.sh) into profiles/<round>_pmc_traffic.json + profiles/<round>_pmc_summary.md (CREID_ROUND, default r04)."""
 import json
 import os
 
-RND = os.environ.get("CREID_ROUND", "r03")
+RND = os.environ.get("CREID_ROUND", "r04")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
@@ -56,7 +56,7 @@ for key, prefix in (("igemm_family", "igemm_bf16_"), ("wgrad_family", "wgrad_bf1
     out[key]["mfma_busy"] = mf / (ga / 8 * NSIMD)          # matrix-pipe busy fraction by counter (all launches of the family)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{RND}_pmc_traffic.json"), "w"), indent=1)
 
-lines = ["# rocprofv3 --pmc passes, round 2 (tools/pmc_run.sh over tools/pmc_kernels.py, one MI355X)", "",
+lines = [f"# rocprofv3 --pmc passes, round {RND.lstrip('r0') or '0'} (tools/pmc_run.sh over tools/pmc_kernels.py, one MI355X)", "",
          "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of SIMD-cycles whose matrix",
          "pipe is occupied, i.e. the MFMA-roofline fraction measured by the hardware rather than derived from time.  `MfmaUtil` /",
          "`VALUBusy` are rocprofv3's derived metrics (gfx94x formulas), averaged over the dispatches.", "",
