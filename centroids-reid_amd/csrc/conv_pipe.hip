@@ -86,8 +86,10 @@ struct PipeArgs {
 // EPI: 0 plain store (+ add_src), 1 BatchNorm statistics of the fp32 accumulators, 2 folded affine (+ residual) (+ ReLU) --
 // compile-time, because the per-element work of the copy-out is VALU-bound (a runtime choice made the compiler evaluate
 // every variant and select: ~450 instructions per 32-row piece, 3100 cycles of the 3300 a whole k-tile takes).
+// (128 x 128: 32 accumulator registers per wave and a 64 KB ring -- two workgroups per CU, i.e. four waves per SIMD and <= 128
+// registers, for the grids of 256 .. 1024 tiles the M = 8192 layers of the training batch give)
 template <int BM, int BN, int WN, int KPH, int GLM, int EPI, typename ET>
-__global__ __launch_bounds__(512, 2) void igemm_bf16_pp_kernel(IGemmGeom g, PipeArgs pa) {
+__global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? 4 : 2) void igemm_bf16_pp_kernel(IGemmGeom g, PipeArgs pa) {
   constexpr int NT = 512, BK = 64, WM = 8 / WN;
   constexpr int MI = BM / WM / 32, NJ = BN / WN / 32;            // 32 x 32 accumulator blocks per wave
   constexpr int NAI = BM / 64, NBI = BN / 64, NP = NAI + NBI;     // DMA pieces (8 rows x 128 B) per wave and k-tile
@@ -461,7 +463,7 @@ int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* 
               (g.M + bm - 1) / bm, g.N / bn};
   const int ntiles = pa.tiles_m * pa.tiles_n;
   static const int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-  int cap = ncu;
+  int cap = (bm * bn <= 128 * 128) ? 2 * ncu : ncu;
   { const char* e = getenv("CREID_PP_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) cap = v; }   // tests: few workgroups walk many tiles
   const dim3 grid((unsigned)(ntiles < cap ? ntiles : cap)), block(512);
   const int epi = g.epi_scale ? 2 : (bn_part ? 1 : 0);
@@ -488,6 +490,7 @@ int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* 
   if (bm == 256 && bn == 256) CREID_PP_KPH(256, 256, 4);
   else if (bm == 128 && bn == 256) CREID_PP_KPH(128, 256, 4);
   else if (bm == 256 && bn == 128) CREID_PP_KPH(256, 128, 2);
+  else if (bm == 128 && bn == 128) CREID_PP_KPH(128, 128, 4);
   else return CREID_E_SHAPE;
 #undef CREID_PP_KPH
 #undef CREID_PP_LAUNCH

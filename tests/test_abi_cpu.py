@@ -110,7 +110,7 @@ def test_tuned_plan_file_is_well_formed_and_registers():
         elif plan[2] == 5:                              # all-waves-multiply persistent kernel (conv_pipe.hip): plan[0] = variant word
             v = plan[0]
             bm, bn, kph, mode = (v & 3) * 128, ((v >> 2) & 3) * 128, (v >> 4) & 7, (v >> 8) & 3
-            assert (bm, bn) in ((256, 256), (128, 256), (256, 128)) and kph in (1, 2) and mode in (0, 2) and plan[1] == 0
+            assert (bm, bn) in ((256, 256), (128, 256), (256, 128), (128, 128)) and kph in (1, 2) and mode in (0, 2) and plan[1] == 0
             assert key[1] % bn == 0 and key[2] % 64 == 0 and (key[3] & ~8) in (2, 4)      # forward only; bit 3 = eval-mode epilogue
         else:                                           # forward / data gradient: (N tile, ring depth, kernel kind)
             assert plan[0] in (64, 128) and plan[1] in (2, 3, 4) and plan[2] in (0, 1, 2, 3, 4)

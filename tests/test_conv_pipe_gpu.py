@@ -17,7 +17,7 @@ def vword(bm, bn, kph, mode):
 
 
 VARIANTS = [vword(256, 256, 1, 0), vword(256, 256, 2, 0), vword(256, 256, 1, 2), vword(128, 256, 2, 0), vword(128, 256, 1, 2),
-            vword(256, 128, 1, 0), vword(256, 128, 1, 2)]
+            vword(256, 128, 1, 0), vword(256, 128, 1, 2), vword(128, 128, 1, 0), vword(128, 128, 2, 0), vword(128, 128, 1, 2)]
 CASES = [  # B, H, W, cin, cout, k, stride
     (4, 16, 8, 512, 2048, 1, 1),        # M = 512: two 256-row tiles, eight column tiles
     (3, 16, 8, 1024, 512, 1, 1),        # M = 384: a partial second row tile

@@ -25,7 +25,7 @@ def vword(bm, bn, kph, glm):
 if "variants" in opts:
     VARIANTS = [int(v, 0) for v in opts["variants"].split(",")]
 else:
-    VARIANTS = [vword(bm, bn, kph, glm) for (bm, bn) in ((256, 256), (128, 256), (256, 128)) for (kph, glm) in ((1, 0), (2, 0), (1, 2))]
+    VARIANTS = [vword(bm, bn, kph, glm) for (bm, bn) in ((256, 256), (128, 256), (256, 128), (128, 128)) for (kph, glm) in ((1, 0), (2, 0), (1, 2))]
 
 
 def vname(v):

@@ -43,7 +43,7 @@ def t_us(fn, reps=2, iters=10):
 
 
 PP_VARIANTS = [(bm // 128) | ((bn // 128) << 2) | (kph << 4) | (mode << 8)
-               for (bm, bn) in ((256, 256), (128, 256), (256, 128)) for (kph, mode) in ((1, 0), (2, 0), (1, 2))]
+               for (bm, bn) in ((256, 256), (128, 256), (256, 128), (128, 128)) for (kph, mode) in ((1, 0), (2, 0), (1, 2))]
 
 
 def register(entries):
