@@ -19,15 +19,24 @@ def fam(db, prefix, counter):
     return tot, n
 
 
+def first_dispatch(db, prefix):
+    """The kernel's first dispatch; the template argument list grew an element type in round 4, so match by prefix."""
+    fd = db["_first_dispatch"]
+    for k in fd:
+        if k.startswith(prefix):
+            return fd[k]
+    raise KeyError(prefix)
+
+
 calib = {}
 for name, kern in (("calib_l2norm_rows", "l2norm_rows_kernel<0>"), ("calib_bn2d_apply", "bn2d_apply_kernel<unsigned short>"),
-                   ("calib_igemm_1x1_stream", "igemm_bf16_ws_kernel<64, 2, 128>")):
-    f = F["_first_dispatch"][kern]["FETCH_SIZE"] * 1024
-    w = W["_first_dispatch"][kern]["WRITE_SIZE"] * 1024
+                   ("calib_igemm_1x1_stream", "igemm_bf16_ws_kernel<64, 2, 128")):
+    f = first_dispatch(F, kern)["FETCH_SIZE"] * 1024
+    w = first_dispatch(W, kern)["WRITE_SIZE"] * 1024
     calib[name] = {"known_read_bytes": meta[name]["read"], "known_write_bytes": meta[name]["write"], "FETCH_SIZE_bytes": f,
                    "WRITE_SIZE_bytes": w, "fetch_ratio": f / meta[name]["read"], "write_ratio": w / meta[name]["write"]}
-cal_f = F["_first_dispatch"]["igemm_bf16_ws_kernel<64, 2, 128>"]["FETCH_SIZE"] * 1024
-cal_w = W["_first_dispatch"]["igemm_bf16_ws_kernel<64, 2, 128>"]["WRITE_SIZE"] * 1024
+cal_f = first_dispatch(F, "igemm_bf16_ws_kernel<64, 2, 128")["FETCH_SIZE"] * 1024
+cal_w = first_dispatch(W, "igemm_bf16_ws_kernel<64, 2, 128")["WRITE_SIZE"] * 1024
 out = {"_comment": "HBM-side traffic from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, unit KiB -> bytes), this round, one "
                    "MI355X, tools/pmc_run.sh.  CALIBRATION on kernels of exactly known traffic: FETCH_SIZE reads 0.500x the bytes of "
                    "16-byte streaming loads, both plain global loads (bn2d_apply, bf16) and LDS-DMA (1x1 convolution), WRITE_SIZE "
