@@ -23,7 +23,8 @@
 #include <type_traits>
 #include <stdlib.h>
 
-namespace {
+namespace creid_pp {   // (a NAMED namespace: rocprofv3 prints `(anonymous namespace)::` in front of kernels of an unnamed one, which the
+                      // profile tooling's name clean-up would cut to nothing)
 
 __device__ __attribute__((aligned(128))) unsigned g_zero_page_pp[32];
 
@@ -439,7 +440,8 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? 4 : 2) void igemm_bf1
   }
 }
 
-}  // namespace
+}  // namespace creid_pp
+using namespace creid_pp;
 
 // Launch plan kind 5 (tune.hpp) / CREID_IGEMM_PP: returns CREID_E_SHAPE when the launch is not covered (the caller falls back to
 // the tile kernels).  variant = BM / 128 | (BN / 128) << 2 | KPH << 4 | MODE << 8 (MODE 2: free-running form; 0: 256 x 256, 2 slices per phase, pieces beside
