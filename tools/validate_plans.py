@@ -22,6 +22,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--configs", default="embed128,embed256,train64,train56")
 ap.add_argument("--plans", default=os.path.join(ROOT, "centroids-reid_amd", "tuned_plans.json"))
 ap.add_argument("--margin", type=float, default=0.0015, help="relative gain of the whole workload that counts as real")
+ap.add_argument("--all-kinds", action="store_true", help="validate EVERY plan of the configuration (weight-gradient and round-3 "
+                                                          "forward / data-gradient plans too), not only kind 5")
+ap.add_argument("--fast", action="store_true", help="one timing per trial instead of the minimum of several")
 args = ap.parse_args()
 
 CONFIGS = {  # name -> (kind, arch, B, H, W)
@@ -35,12 +38,13 @@ plans = doc["plans"]
 
 
 def conv_ms(B, H, W):
-    """(M, N, K) of every forward convolution at this size -> which plans belong to the configuration."""
+    """(M, N, K) of every forward convolution at this size (and of its data gradient) -> which plans belong to the configuration."""
     from centroids_reid_amd.bench_train import conv_shapes
     out = set()
     for cin, cout, k, s, h, w in conv_shapes(B, H, W):
         oh, ow = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
         out.add((B * oh * ow, cout, cin * k * k))
+        out.add((B * h * w, cin, cout * k * k))                  # data gradient
     return out
 
 
@@ -60,7 +64,7 @@ def time_embed(entries, arch, B, H, W, dtype=None):
     L.load_tuned_plans(path)
     os.unlink(path)
     eb = EmbedBench(arch, B, H, W)
-    t = min(eb.run(20, 3) for _ in range(3))
+    t = min(eb.run(20, 3) for _ in range(1 if args.fast else 3))
     del eb
     torch.cuda.empty_cache()
     return t * 1e3
@@ -72,7 +76,7 @@ def time_train(entries, arch, B, H, W):
     if (H, W) != (256, 128):
         env["CREID_BENCH_CONFIG3"] = "1"
     best = None
-    for _ in range(2):
+    for _ in range(1 if args.fast else 2):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--no-cpu-baseline"],
                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
@@ -87,17 +91,22 @@ for name in args.configs.split(","):
     kind, arch, B, H, W = CONFIGS[name]
     mnk = conv_ms(B, H, W)
     bit = 8 if kind == "embed" else 0
-    mine = [e for e in plans if e["kind"] == 1 and e["plan"][2] == 5 and tuple(e["key"][:3]) in mnk and (e["key"][3] & 8) == bit]
+    if args.all_kinds:
+        # every plan a launch of this configuration can hit: eval launches fall back to mode-less keys, training ones never see bit 3
+        mine = [e for e in plans if tuple(e["key"][:3]) in mnk and (kind == "train" or e["kind"] == 1) and
+                (kind == "embed" or (e["key"][3] & 8) == 0)]
+    else:
+        mine = [e for e in plans if e["kind"] == 1 and e["plan"][2] == 5 and tuple(e["key"][:3]) in mnk and (e["key"][3] & 8) == bit]
     timer = (lambda ents: time_embed(ents, arch, B, H, W)) if kind == "embed" else (lambda ents: time_train(ents, arch, B, H, W))
     base = timer(plans)
-    print(f"[{name}] {len(mine)} kind-5 plans, workload with all of them: {base:.4f} ms", flush=True)
+    print(f"[{name}] {len(mine)} plans to validate, workload with all of them: {base:.4f} ms", flush=True)
     log.append(f"## {name}: {arch} {H}x{W} batch {B} ({'eval-mode embedding forward' if kind == 'embed' else 'training step'}); "
                f"all plans {base:.4f} ms\n\n| plan (M, N, K, mode) | variant | tuner: alone us (plan / before) | workload without it ms | verdict |\n|---|---|---|---:|---|")
     for e in mine:
         trial = [p for p in plans if p is not e]
         t = timer(trial)
         drop = t < base * (1.0 - args.margin)
-        log.append(f"| {tuple(e['key'])} | {hex(e['plan'][0])} | {e.get('us')} / {e.get('rule_us')} | {t:.4f} | "
+        log.append(f"| kind {e['kind']} {tuple(e['key'])} | {e['plan']} | {e.get('us')} / {e.get('rule_us')} | {t:.4f} | "
                    f"{'DROPPED (workload %.2f %% faster without)' % (100 * (base - t) / base) if drop else 'kept'} |")
         print(log[-1], flush=True)
         if drop:
@@ -109,5 +118,5 @@ for name in args.configs.split(","):
 doc["plans"] = plans
 doc["_validated"] = "kind-5 plans validated in situ by tools/validate_plans.py (whole captured forward / step with and without each plan)"
 json.dump(doc, open(args.plans, "w"), indent=1)
-open(os.path.join(ROOT, "gpurun_out", "plan_validation.md"), "w").write("\n".join(log) + "\n")
+open(os.path.join(ROOT, "gpurun_out", "plan_validation_all.md" if args.all_kinds else "plan_validation.md"), "w").write("\n".join(log) + "\n")
 print(f"{len(plans)} plans kept in {args.plans}")
