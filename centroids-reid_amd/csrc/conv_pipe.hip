@@ -99,11 +99,16 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? 4 : 2) void igemm_bf1
   constexpr int PR = WM * 32;                                     // rows of one staged piece (one 32-row block of every wave row)
   constexpr int CPT = PR + 4;                                     // staging pitch (elements): 2 banks between columns
   constexpr int STG = BN * CPT;                                   // one staging buffer
-  constexpr int RING = 2 * STAGE;
+  // ring depth: three slots in the free-running form where 160 KB allow it (128 x 256, 256 x 128: 3 x 48 KB) -- inside a captured
+  // forward the operands come from HBM / the Infinity Cache, not from an L2 the previous launch of the same layer warmed, and
+  // with two slots the once-per-k-tile wait saw less than one k-tile of prefetch distance (profiles/r04_plan_validation.md:
+  // the long-K plans that won alone lost in situ)
+  constexpr int NS = (GLM == 2 && BM * BN > 128 * 128 && 3 * STAGE * 2 + 12 * 1024 <= 160 * 1024) ? 3 : 2;
+  constexpr int RING = NS * STAGE;
   constexpr int RED = 2 * (BM / 64) * 2 * BN;                     // fp32 column-sum scratch in 2-byte units
   // the staging area starts at ring slot 1: while a tile is copied out only slot 0 is in use (the next tile's first k-tile);
   // the column-sum scratch has its own 8 KB behind everything (written piece by piece: no registers held across the copy-out)
-  constexpr int LDS_MAIN = (STAGE + 2 * STG > RING) ? STAGE + 2 * STG : RING;
+  constexpr int LDS_MAIN = (STAGE + 2 * STG > RING) ? STAGE + 2 * STG : RING;   // (staging: slots 1 .. while a tile is copied out)
   constexpr int LDS_ELEMS = LDS_MAIN + (EPI == 1 ? RED : 0);
   static_assert(LDS_ELEMS * 2 <= 160 * 1024, "LDS budget");
   static_assert(MI >= 2 && MI % 2 == 0 && NJ >= 1 && (KPH == 1 || KPH == 2), "shape");
@@ -204,7 +209,9 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? 4 : 2) void igemm_bf1
       // free-running modes: the whole of k-tile 1 goes out NOW (ring slot 1 doubled as the copy-out staging area until the
       // barrier that ended the previous tile).  vmcnt(NP) then means "k-tile 0 has landed" whatever the previous tile's stores
       // do: loads return in order among themselves, so as long as one k-tile-0 piece is pending so are the NP younger ones.
-      if (nk > 1) { issue(1, 1, 0, NP); pp_wait_vm<NP>(); } else pp_wait_vm<0>();
+      if (NS == 3 && nk > 2) { issue(1, 1, 0, NP); issue(2, 2, 0, NP); pp_wait_vm<2 * NP>(); }
+      else if (nk > 1) { issue(1, 1, 0, NP); pp_wait_vm<NP>(); }
+      else pp_wait_vm<0>();
     } else {
       pp_wait_vm<0>();                                           // k-tile 0 of this tile (and the previous tile's stores)
     }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? 4 : 2) void igemm_bf1
       constexpr int P0 = (NP * 3 + 7) / 8, P1 = (NP * 6 + 7) / 8;
       s16x8 a0[MI], b0[NJ], a1[MI], b1[NJ];
       auto rd = [&](int t, int sl, s16x8 (&a)[MI], s16x8 (&b)[NJ]) {
-        const unsigned short* As = smem + (t & 1) * STAGE;
+        const unsigned short* As = smem + (t % NS) * STAGE;
         const unsigned short* Bs = As + TILE_A;
         const int ch = 2 * sl + kh;
 #pragma unroll
@@ -247,28 +254,34 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? 4 : 2) void igemm_bf1
       };
       // (top of the tile: the whole of k-tile 1 was requested behind k-tile 0, see below)
       rd(0, 0, a0, b0);
+      // NS slots: k-tile u lives in slot u % NS; its pieces [0, P0) go out in slice 3 of k-tile u - NS (right behind the barrier
+      // that frees the slot), [P0, NP) in slices 0, 1 of k-tile u - NS + 1; k-tiles 1 .. NS - 1 went out whole at the top
       for (int t = 0; t < nk; ++t) {
-        const bool more = t + 1 < nk, more2 = t + 2 < nk;
-        const bool iss = more && t > 0;                           // k-tile 1 is already on its way
+        const bool more = t + 1 < nk;
+        const int tq = t + NS - 1;
+        const bool iss = t > 0 && tq < nk;
         rd(t, 1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        mm(a0, b0, iss, t + 1, (t + 1) & 1, P0, P1);
+        mm(a0, b0, iss, tq, tq % NS, P0, P1);
         __builtin_amdgcn_sched_barrier(0);
         rd(t, 2, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        mm(a1, b1, iss, t + 1, (t + 1) & 1, P1, NP);
+        mm(a1, b1, iss, tq, tq % NS, P1, NP);
         __builtin_amdgcn_sched_barrier(0);
         rd(t, 3, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         mm(a0, b0, false, 0, 0, 0, 0);
         if (more) {
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          // k-tile t + 1 must have landed; with three slots the NP pieces of k-tile t + 2 may still be on their way (loads only
+          // in this loop: they return in order)
+          if (NS == 3 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           pp_barrier();
           PP_STAMP();
           rd(t + 1, 0, a0, b0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mm(a1, b1, more2, t + 2, t & 1, 0, P0);
+        mm(a1, b1, more && t + NS < nk, t + NS, t % NS, 0, P0);
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
