@@ -28,6 +28,8 @@ int wgrad_reduce_job_launch(const WRedJob& j, hipStream_t s);
 int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, hipStream_t s);
 int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, const void* add_src,
                    const float* epi_scale, const float* epi_shift, int epi_relu, int bn_cap, int dtype, hipStream_t s);
+int launch_conv3x3_c64(int M, int H, int Wd, const void* src, const void* wgt, void* out, float* bn_part, const float* epi_scale,
+                       const float* epi_shift, int epi_relu, int dtype, hipStream_t s);
 // defined in conv_pipe.hip
 int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* out, const void* add_src, float* bn_part,
                     int variant, int dtype, hipStream_t s);
@@ -1217,6 +1219,18 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
     tuned_pp = tp.p0;                                              // plan kind 5: all-waves-multiply persistent kernel, p0 = its variant word
   } else if (have_plan && (tp.p0 == 64 || tp.p0 == 128) && g.N % tp.p0 == 0 && (tp.p1 == 2 || tp.p1 == 3 || tp.p1 == 4)) {
     bn = tp.p0; tuned_stages = tp.p1; tuned_dma = tp.p2 == 1; tuned_stream = tp.p2 == 2; tuned_bm256 = tp.p2 == 3; tuned_stream2 = tp.p2 == 4;
+  }
+  // layer1's 3 x 3, 64 -> 64 forward: halo tile in LDS, weights in registers (conv_stream.hip conv3x3_c64_kernel); CREID_C64_3X3=0:
+  // the tile kernels
+  {
+    const char* ce = getenv("CREID_C64_3X3");                       // read per call: tests toggle it
+    const bool c64_on = !ce || atoi(ce) != 0;
+    if (c64_on && creid_is16(dtype) && !g.transposed && g.N == 64 && g.K == 576 && g.log2span == 6 && g.kw == 3 && g.stride == 1 &&
+        g.pad == 1 && g.pitch == 64 && g.check_bounds && !add_src && !bnred.x && !wred.ws && g.SH == g.OH && g.SW == g.OW &&
+        !(bn_part && g.epi_scale)) {
+      const int rc = launch_conv3x3_c64(g.M, g.OH, g.OW, src, wgt, out, bn_part, g.epi_scale, g.epi_shift, g.epi_relu, dtype, s);
+      if (rc != CREID_E_SHAPE) return rc;
+    }
   }
   // all-waves-multiply persistent kernel (conv_pipe.hip): plan kind 5, or CREID_IGEMM_PP = 0x1000 | variant for every launch it covers
   {

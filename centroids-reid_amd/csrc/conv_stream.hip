@@ -540,3 +540,240 @@ int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* 
 #undef CREID_ST2_LAUNCH1
   return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------ 3 x 3, 64 -> 64 (round 4)
+// layer1's conv2 (modelling/backbones/resnet.py:58, Bottleneck.conv2 with planes = 64): M = B * 64 * 32 pixels, N = 64, K = 576.
+// The tile kernels run it 4x above its HBM floor (B = 128: 44 us for 67 MB): every one of the nine taps re-fetches its 128-row
+// A tile through the 64 B/clk operand path (9 x 16 KB per tile for 16 KB of distinct input), the 72 KB of weights are re-read by
+// every workgroup-tile, and a 128 x 64 tile gives a wave 8 MFMAs per barrier.  Here
+//   * the INPUT HALO TILE is staged in LDS once per tile: the 128 / W + 2 image rows a tile of 128 consecutive output pixels
+//     touches, W + 2 pixel slots per row (zero pixels left and right; rows outside the image are zero rows), and all nine taps
+//     read their A fragments from it at shifted addresses (slot = (oy + r) * (W + 2) + ox + s) -- no per-tap fetch, no bounds logic
+//     in the multiply loop;
+//   * the WEIGHTS live in REGISTERS: wave (wr, wc) always multiplies against output channels wc * 32 .. + 31, i.e. the same 36
+//     B fragments (9 taps x 4 k-slices x 16 B per lane = 144 registers) for every tile of the launch -- LDS carries only A;
+//   * workgroups are persistent over a CONTIGUOUS run of tiles (vertically adjacent tiles share two input rows: the re-read
+//     hits the workgroup's own L2), the next tile's rows are loaded into registers a tile ahead and finished tiles are stored a
+//     tile late (the scheme of igemm1x1_stream2_kernel).
+// Same k order as the tile kernels (tap-major, 16-wide slices inside a tap) and the same epilogue arithmetic: identical output
+// bits; statistics partials equal up to the grouping of the column sums.  Forward only (training statistics / folded eval-mode
+// affine / plain); W = 32 or 64 with H * W % 128 = 0; anything else takes the tile kernels.
+template <int W, typename ET>
+__global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const unsigned short* __restrict__ src, int M, int H,
+                                                              const unsigned short* __restrict__ wgt,
+                                                              unsigned short* __restrict__ out, float* __restrict__ bn_part,
+                                                              const float* __restrict__ epi_scale, const float* __restrict__ epi_shift,
+                                                              int epi_relu, int n_tiles, int abl) {
+  constexpr int RW = 128 / W;                           // output rows per tile
+  constexpr int PW = W + 2, PX = (RW + 2) * PW;         // pixel slots per halo row / per halo tile
+  constexpr int SLOT = PX * 64;                         // elements per ring slot
+  constexpr int NLD = ((RW + 2) * W * 8) / 512;         // 16-byte chunks per thread and halo tile
+  constexpr int CPT = 128 + 4, CPR = 8, NIT = 2;        // staging pitch; 16-byte chunks per output row; chunks per thread
+  static_assert(((RW + 2) * W * 8) % 512 == 0, "halo tile load map");
+  constexpr int WP = 576 + 8;                           // weight row pitch in the one-time LDS image (conflict-free 16-byte reads)
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * SLOT + 64 * CPT + 4 * 2 * 64 * 2 + 64 * WP];
+  unsigned short* ring = smem;
+  unsigned short* stage = smem + 2 * SLOT;
+  float* red = reinterpret_cast<float*>(stage + 64 * CPT);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave & 3, wc = wave >> 2;
+  const int l31 = lane & 31, kh = lane >> 5;
+  // contiguous run of tiles per workgroup
+  const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per, t_end = min(n_tiles, t_begin + per);
+  const int n_iter = t_end - t_begin;
+  if (n_iter <= 0) return;
+
+  // zero both ring slots once: the pad pixels are never written again
+  for (int i = tid; i < 2 * SLOT / 8; i += 512) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  // the wave's 36 weight fragments: output channel wc * 32 + l31, tap-major k, 8 consecutive channels (2 kk + kh) * 8 ..  The 72 KB
+  // come in ONCE per workgroup with coalesced 16-byte loads and go through LDS (fragment-shaped global loads -- a different 1152-byte
+  // row per lane -- cost more than four tiles of multiplies)
+  constexpr int TREG = 5;                               // taps whose weight fragments live in registers (80); the rest are read from LDS
+  s16x8 bw[TREG][4];
+  unsigned short* wl = reinterpret_cast<unsigned short*>(red + 4 * 2 * 64);
+  {
+    for (int i = tid; i < 64 * 72; i += 512) {
+      const int o = i / 72, c = i - o * 72;
+      *reinterpret_cast<uint4*>(wl + o * WP + c * 8) = *reinterpret_cast<const uint4*>(wgt + (int64_t)o * 576 + c * 8);
+    }
+    __syncthreads();
+    const unsigned short* wrow = wl + (wc * 32 + l31) * WP + kh * 8;
+#pragma unroll
+    for (int tap = 0; tap < TREG; ++tap)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) bw[tap][kk] = *reinterpret_cast<const s16x8*>(wrow + tap * 64 + kk * 16);
+  }
+  const unsigned wl_lane = (unsigned)(uintptr_t)(wl + (wc * 32 + l31) * WP + kh * 8);   // this lane's weight row in the LDS image
+  const int tiles_per_img = (H * W) / 128;
+  uint4 areg[NLD];
+  auto load_a = [&](int it) {
+    const int tile = t_begin + it;
+    const int b = tile / tiles_per_img, y0 = (tile - b * tiles_per_img) * RW;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + 512 * u, ch = idx & 7, pix = idx >> 3;
+      const int row = pix / W, col = pix - row * W;
+      const int y = y0 - 1 + row;
+      const bool ok = (unsigned)y < (unsigned)H;
+      // (branch-free: a row outside the image reads row 0 of the image and is zeroed -- see igemm1x1_stream2_kernel)
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (!CREID_ABL_ON(abl, 2)) v = *reinterpret_cast<const uint4*>(src + ((int64_t)(b * H + (ok ? y : 0)) * W + col) * 64 + ch * 8);
+      areg[u] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto put_a = [&](int it) {
+    unsigned short* slot = ring + (it & 1) * SLOT;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + 512 * u, ch = idx & 7, pix = idx >> 3;
+      const int row = pix / W, col = pix - row * W;
+      const int p = row * PW + col + 1;
+      *reinterpret_cast<uint4*>(slot + p * 64 + ((ch ^ ((p >> 1) & 7)) << 3)) = areg[u];
+    }
+  };
+  const int t4 = lane & 3, q4 = (lane >> 2) & 3, g4 = lane >> 4;
+  auto unit_of = [&](int i, int& rl, int& ch) {
+    const int Q = (wave + 8 * i) * 16 + g4 * 4 + q4;
+    ch = Q % CPR;
+    rl = 4 * (Q / CPR) + t4;
+  };
+  uint4 outv[NIT];
+  auto store_out = [&](int it) {
+    const int64_t row0 = (int64_t)(t_begin + it) * 128;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      int rl, ch;
+      unit_of(i, rl, ch);
+      if (!CREID_ABL_ON(abl, 8)) *reinterpret_cast<uint4*>(out + (row0 + rl) * 64 + ch * 8) = outv[i];
+    }
+  };
+  float sc = 1.f, sh = 0.f;
+  if (epi_scale) { sc = epi_scale[wc * 32 + l31]; sh = epi_shift[wc * 32 + l31]; }
+  // this lane's output pixel inside the tile and its tap (0, 0) halo slot
+  const int ml = wr * 32 + l31, oy = ml / W, ox = ml - oy * W;
+  const int p00 = oy * PW + ox;
+
+  __syncthreads();                                                // ring zeroed
+  load_a(0);
+  put_a(0);
+  if (n_iter > 1) load_a(1);
+  for (int it = 0; it < n_iter; ++it) {
+    __syncthreads();                                              // tile `it` is in the ring; everyone is done with tile it - 1
+    if (it + 1 < n_iter) put_a(it + 1);
+    // stores BEFORE the next loads: the one full vmcnt wait of a tile (the compiler's, in front of put_a above) then sees only
+    // requests that are a whole tile old; the barrier in the middle of the tile must not wait for memory at all
+    if (it > 0) store_out(it - 1);
+    if (it + 2 < n_iter) load_a(it + 2);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const unsigned short* At = ring + (it & 1) * SLOT;
+    // 36 multiply steps; the A fragment of step f + 3 (and, from tap TREG on, its weight fragment from the LDS image) is requested
+    // before step f multiplies: asm reads with counted waits -- left to the compiler, 144 registers of weights made it re-use one
+    // register quad and wait a full LDS round trip per MFMA (6100 of a tile's 7400 cycles), and with all nine taps in registers
+    // there is no room for a pipeline at all
+    {
+      typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+      u32x4v af[4], bf[4];
+      auto rd = [&](int f, u32x4v& da, u32x4v& db) {
+        const int tap = f >> 2, kk = f & 3;
+        const int p = p00 + (tap / 3) * PW + (tap % 3);
+        const unsigned addr = (unsigned)(uintptr_t)(At + p * 64 + (((2 * kk + kh) ^ ((p >> 1) & 7)) << 3));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(da) : "v"(addr) : "memory");
+        if (tap >= TREG) asm volatile("ds_read_b128 %0, %1" : "=v"(db) : "v"(wl_lane + (unsigned)((tap * 64 + kk * 16) * 2)) : "memory");
+      };
+      auto nrd = [](int f) constexpr { return f < 36 ? 1 + ((f >> 2) >= TREG ? 1 : 0) : 0; };
+      if (!CREID_ABL_ON(abl, 1)) {
+      rd(0, af[0], bf[0]); rd(1, af[1], bf[1]); rd(2, af[2], bf[2]);
+#pragma unroll
+      for (int f = 0; f < 36; ++f) {
+        if (f + 3 < 36) rd(f + 3, af[(f + 3) & 3], bf[(f + 3) & 3]);
+        const int young = nrd(f + 1) + nrd(f + 2) + nrd(f + 3);      // reads younger than step f's
+        u32x4v& a = af[f & 3]; u32x4v& b = bf[f & 3];
+        if (young == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) :: "memory");
+        else if (young == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a), "+v"(b) :: "memory");
+        else if (young == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b) :: "memory");
+        else if (young == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a), "+v"(b) :: "memory");
+        else if (young == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b) :: "memory");
+        else if (young == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a), "+v"(b) :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a), "+v"(b) :: "memory");
+        if ((f >> 2) < TREG) acc = ET::mfma(__builtin_bit_cast(s16x8, a), bw[(f >> 2) < TREG ? (f >> 2) : 0][f & 3], acc);
+        else acc = ET::mfma(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc);
+      }
+      }
+    }
+    if (bn_part) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float v = acc[r]; s1 += v; s2 = fmaf(v, v, s2); }
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (kh == 0) { red[(wr * 2 + 0) * 64 + wc * 32 + l31] = s1; red[(wr * 2 + 1) * 64 + wc * 32 + l31] = s2; }
+    }
+    if (CREID_ABL_ON(abl, 4)) continue;                           // (timing ablation: no staging / copy-out)
+    {
+      const int cl = wc * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rl = wr * 32 + 8 * q + 4 * kh;
+        float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
+        if (epi_scale) {
+          v0 = fmaf(v0, sc, sh); v1 = fmaf(v1, sc, sh); v2 = fmaf(v2, sc, sh); v3 = fmaf(v3, sc, sh);
+          if (epi_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        }
+        *reinterpret_cast<uint2*>(&stage[cl * CPT + rl]) = make_uint2(ET::pack2(v0, v1), ET::pack2(v2, v3));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the tile is staged (and `red` is complete): LDS only --
+                                                                  // __syncthreads() would also wait for this tile's loads / stores
+    if (bn_part) {
+      for (int i = tid; i < 2 * 64; i += 512) {
+        const int which = i / 64, cl = i - which * 64;
+        bn_part[((int64_t)(t_begin + it) * 2 + which) * 64 + cl] =
+            (red[(0 * 2 + which) * 64 + cl] + red[(1 * 2 + which) * 64 + cl]) + (red[(2 * 2 + which) * 64 + cl] + red[(3 * 2 + which) * 64 + cl]);
+      }
+    }
+    u32x2 trlo[NIT], trhi[NIT];
+    {
+      const int sq = lane & 3, sj = (lane >> 2) & 3;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int Qs = (wave + 8 * i) * 16 + g4 * 4 + sq;
+        const unsigned addr = (unsigned)(uintptr_t)&stage[((Qs % CPR) * 8 + sj) * CPT + 4 * (Qs / CPR)];
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                     : "=&v"(trlo[i]), "=&v"(trhi[i]) : "v"(addr), "i"(4 * CPT * 2) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) asm volatile("" : "+v"(trlo[i]), "+v"(trhi[i]));
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) outv[i] = make_uint4(trlo[i].x, trlo[i].y, trhi[i].x, trhi[i].y);
+  }
+  store_out(n_iter - 1);
+}
+
+// Returns CREID_E_SHAPE when the convolution is outside the kernel's scope.
+int launch_conv3x3_c64(int M, int H, int Wd, const void* src, const void* wgt, void* out, float* bn_part, const float* epi_scale,
+                       const float* epi_shift, int epi_relu, int dtype, hipStream_t s) {
+  if ((Wd != 32 && Wd != 64) || H <= 0 || (H * Wd) % 128 != 0 || M % (H * Wd) != 0 || !creid_is16(dtype)) return CREID_E_SHAPE;
+  const int n_tiles = M / 128;
+  int wgs = 256;
+  { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
+  if (wgs > n_tiles) wgs = n_tiles;
+  const dim3 grid((unsigned)wgs), block(512);
+#ifdef CREID_ABL_BUILD
+  const char* ae = getenv("CREID_C64_ABL");             // 1 no multiplies, 2 no input loads, 4 no staging / copy-out, 8 no stores
+  const int abl = ae ? atoi(ae) : 0;
+#else
+  const int abl = 0;
+#endif
+#define CREID_C64_LAUNCH(W_, ET_)                                                                              \
+  hipLaunchKernelGGL((conv3x3_c64_kernel<W_, ET_>), grid, block, 0, s, (const unsigned short*)src, M, H,      \
+                     (const unsigned short*)wgt, (unsigned short*)out, bn_part, epi_scale, epi_shift, epi_relu, n_tiles, abl)
+  if (Wd == 32) { if (dtype == CREID_F16) CREID_C64_LAUNCH(32, F16T); else CREID_C64_LAUNCH(32, Bf16T); }
+  else { if (dtype == CREID_F16) CREID_C64_LAUNCH(64, F16T); else CREID_C64_LAUNCH(64, Bf16T); }
+#undef CREID_C64_LAUNCH
+  return (int)hipGetLastError();
+}

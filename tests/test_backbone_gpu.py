@@ -769,3 +769,40 @@ def test_wgrad_two_k_groups_matches_fp64(case):
     assert float((two.double() - ref).abs().max()) <= 2e-5 * scale + 1e-4, "two k-groups vs fp64"
     assert float((two - one).abs().max()) <= 2e-5 * scale + 1e-4, "two k-groups vs one"
     assert torch.equal(two, again), "fixed summation order: run-to-run identical"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("wgs", [256, 3])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 32), (3, 16, 32), (1, 4, 32), (2, 32, 64), (5, 6, 64), (128, 64, 32)])
+def test_conv3x3_c64_halo_tile_kernel_matches_tile_kernels(B, H, W, wgs, dtype, monkeypatch):
+    """layer1's 3 x 3, 64 -> 64 forward (conv3x3_c64_kernel: input halo tile staged once in LDS, weight fragments resident in
+    registers, persistent workgroups over contiguous tile runs) against the tile kernels on the same inputs: identical output
+    bits for the training forward, the folded eval-mode affine with and without ReLU and the plain forward; statistics partials
+    equal up to the grouping of the fp32 column sums.  Image tops / bottoms (zero rows), the zero pad columns, images of ONE tile
+    (H * W = 128), a workgroup cap that makes workgroups walk runs of tiles across image boundaries."""
+    from centroids_reid_amd import layers as ly
+    if B == 128 and (wgs != 256 or dtype != torch.bfloat16):
+        pytest.skip("the full embedding batch once")
+    rng = np.random.default_rng(B * 100 + H + W)
+    x = torch.from_numpy(rng.standard_normal((B, H, W, 64)).astype(np.float32)).to(dtype).cuda()
+    w = torch.from_numpy((rng.standard_normal((64, 64, 3, 3)) / 24.0).astype(np.float32)).cuda()
+    krsc, _ = ly.weight_prep(w, dtype)
+    ss = torch.from_numpy(np.stack([rng.uniform(0.5, 1.5, 64), rng.standard_normal(64) * 0.3]).astype(np.float32)).cuda()
+
+    def run():
+        y, p = ly.conv2d_fwd(x, krsc, 1, 1, with_stats=True)
+        return (y, p, ly.conv2d_fwd(x, krsc, 1, 1), ly.conv2d_fwd_affine(x, krsc, 1, 1, ss, None, True),
+                ly.conv2d_fwd_affine(x, krsc, 1, 1, ss, None, False))
+    monkeypatch.setenv("CREID_C64_3X3", "0")
+    base = run()
+    monkeypatch.setenv("CREID_C64_3X3", "1")
+    monkeypatch.setenv("CREID_STREAM1X1_WGS", str(wgs))
+    new = run()
+    torch.cuda.synchronize()
+    for k in (0, 2, 3, 4):
+        assert torch.equal(new[k], base[k]), k
+    np.testing.assert_allclose(new[1].cpu().numpy(), base[1].cpu().numpy(), rtol=1e-6, atol=1e-5)
+    import torch.nn.functional as F
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), krsc.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    np.testing.assert_allclose(new[0].float().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol)
