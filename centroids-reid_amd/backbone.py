@@ -437,8 +437,7 @@ class BackboneEngine:
                                                1 if self.net.stem_relu else 0, self.dt, st), "stem_conv_fwd_affine")
         H2, W2 = H1 // 2, W1 // 2
         a = self._empty(B * H2 * W2, 64)
-        idx0 = self._empty(B * H2 * W2, 64, dtype=torch.uint8)
-        L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, self.dt, L.ptr(a), L.ptr(idx0), st), "maxpool_fwd")
+        L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, self.dt, L.ptr(a), None, st), "maxpool_fwd")   # no argmax taps
         del xpad, y0
         h, w = H2, W2
         for b in self.blocks:

@@ -474,6 +474,18 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict
 }
 
 // ------------------------------------------------------------------ max-pool 3x3 s2 p1
+// the V argmax taps of one thread as ONE 4- / 8-byte store (byte stores cost a full write transaction each)
+template <int V>
+__device__ __forceinline__ void store_taps(uint8_t* p, const uint8_t (&bi)[V]) {
+  static_assert(V == 4 || V == 8, "16-byte vectors of 4- or 2-byte elements");
+  uint32_t lo = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+  if constexpr (V == 4) {
+    *reinterpret_cast<uint32_t*>(p) = lo;
+  } else {
+    uint32_t hi = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+    *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int B, int H, int W, int C,
                                                           T* __restrict__ y, uint8_t* __restrict__ idx) {
@@ -504,9 +516,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         }
       }
     Vec16<T>::store(y + i * V, best);
-    uint8_t* ip = idx + i * V;
-#pragma unroll
-    for (int k = 0; k < V; ++k) ip[k] = bi[k];
+    if (idx) store_taps<V>(idx + i * V, bi);
   }
 }
 
@@ -549,9 +559,7 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restri
         }
       }
     Vec16<T>::store(y + i * V, best);
-    uint8_t* ip = idx + i * V;
-#pragma unroll
-    for (int k = 0; k < V; ++k) ip[k] = bi[k];
+    if (idx) store_taps<V>(idx + i * V, bi);
   }
 }
 
@@ -956,7 +964,7 @@ int creid_bn2d_bwd(const void* x, const void* g, const void* act, const float* m
 
 int creid_maxpool3x3s2_fwd(const void* x, int64_t B, int64_t H, int64_t W, int64_t C, int dtype, void* y, uint8_t* idx,
                            void* stream) {
-  CREID_CHECK_ARG(x && y && idx && B > 0 && H > 0 && W > 0 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0);
+  CREID_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0);   // idx may be NULL (inference)
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(B * H * W * C / 16, 1)), dim3(256), 0, s,

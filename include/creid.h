@@ -519,7 +519,7 @@ int creid_ibn_bwd_mask(const void* x, const void* g, const void* act, const uint
                        const float* bn_w, int dtype, float* partial, int partial_ready, float* coef, float* per_img,
                        float* d_in_w, float* d_in_b, float* d_bn_w, float* d_bn_b, void* dx, void* stream);
 
-/* nn.MaxPool2d(3, 2, 1) (resnet.py:98) NHWC, with the argmax tap saved for the backward. */
+/* nn.MaxPool2d(3, 2, 1) (resnet.py:98) NHWC, with the argmax tap saved for the backward (idx NULL: inference, no taps written). */
 /* The stem's tail without its full-resolution intermediates (modelling/backbones/resnet.py:123-126, conv1 -> bn1 -> [relu] ->
  * maxpool): creid_bn2d_apply_maxpool3x3s2 = creid_bn2d_apply (no residual) + creid_maxpool3x3s2_fwd in one pass over the raw
  * conv output x [B, H, W, C] -- the normalised tensor is never written; y [B, H/2, W/2, C], idx as creid_maxpool3x3s2_fwd;
