@@ -269,6 +269,7 @@ class BackboneEngine:
         # data-gradient epilogue read that instead of re-reading the activation (CREID_RELU_BITMASK=0: read the activation)
         self.relu_bitmask = dtype == torch.bfloat16 and os.environ.get("CREID_RELU_BITMASK", "1") == "1"
         self.stem_fuse_pool = os.environ.get("CREID_STEM_FUSE", "1") == "1"    # bn1 + maxpool in one pass (38 vs 51 us)
+        self.stem_pool_fused = os.environ.get("CREID_STEM_POOL", "1") == "1"   # eval: conv1 + bn1 + maxpool in one launch
         # the backward counterpart (max-pool gradient gathered inside the BN backward passes) is correct but slower:
         # the gather is VALU-bound and runs twice (146 vs 116 us, tools/debug/stem_tail_probe.py) -- off by default
         self.stem_fuse_pool_bwd = os.environ.get("CREID_STEM_FUSE_BWD", "0") == "1"
@@ -432,13 +433,22 @@ class BackboneEngine:
         self.fold_bn()
         xpad = self._stem_operand(x_nchw, B, H, W)
         H1, W1 = H // 2, W // 2
-        y0 = self._empty(B * H1 * W1, 64)
-        L.check(lib.creid_stem_conv_fwd_affine(B, H, W, L.ptr(xpad), L.ptr(self.stem.w_krsc), L.ptr(y0), L.ptr(self.stem.fold),
-                                               1 if self.net.stem_relu else 0, self.dt, st), "stem_conv_fwd_affine")
         H2, W2 = H1 // 2, W1 // 2
         a = self._empty(B * H2 * W2, 64)
-        L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, self.dt, L.ptr(a), None, st), "maxpool_fwd")   # no argmax taps
-        del xpad, y0
+        rc = -4
+        if self.stem_pool_fused and self.dtype != torch.float32:
+            # conv1 + folded bn1 (+ ReLU) + max-pool in one launch: the full-resolution tensor is never written (conv_stem.hip)
+            rc = lib.creid_stem_conv_pool_fwd_affine(B, H, W, L.ptr(xpad), L.ptr(self.stem.w_krsc), L.ptr(a), L.ptr(self.stem.fold),
+                                                     1 if self.net.stem_relu else 0, self.dt, st)
+            if rc != -4:
+                L.check(rc, "stem_conv_pool_fwd_affine")
+        if rc == -4:                                     # image size outside the fused kernel's tiles (or fp32): two launches
+            y0 = self._empty(B * H1 * W1, 64)
+            L.check(lib.creid_stem_conv_fwd_affine(B, H, W, L.ptr(xpad), L.ptr(self.stem.w_krsc), L.ptr(y0), L.ptr(self.stem.fold),
+                                                   1 if self.net.stem_relu else 0, self.dt, st), "stem_conv_fwd_affine")
+            L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, self.dt, L.ptr(a), None, st), "maxpool_fwd")   # no argmax taps
+            del y0
+        del xpad
         h, w = H2, W2
         for b in self.blocks:
             a_in, hin, win = a, h, w

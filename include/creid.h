@@ -423,6 +423,12 @@ int creid_stem_conv_fwd(int64_t batch, int64_t H, int64_t W, const void* xpad, c
 /* the stem with its eval-mode BatchNorm (scale_shift float[2][64]) and optional ReLU (resnet_ibn_a.py:129) folded in */
 int creid_stem_conv_fwd_affine(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* w_stem, void* y,
                                const float* scale_shift, int relu, int dtype, void* stream);
+/* The whole eval-mode stem in one launch (resnet.py:95-98,123-126: conv1 -> bn1 -> [relu] -> maxpool): creid_stem_conv_fwd_affine +
+ * creid_maxpool3x3s2_fwd without the full-resolution tensor in between; y [batch, H/4, W/4, 64], bit-identical to the two calls.
+ * 16-bit dtypes; CREID_E_SHAPE for image sizes outside the kernel's tiles (W = 128 or 320 with H % 8 = 0): the
+ * caller then makes the two calls. */
+int creid_stem_conv_pool_fwd_affine(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* w_stem, void* y,
+                                    const float* scale_shift, int relu, int dtype, void* stream);
 size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype);
 int creid_stem_conv_wgrad(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* dy,
                           float* dw_oihw, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -159,3 +159,57 @@ def test_eval_forward_after_training_step_uses_fresh_statistics():
         os.environ.pop("CREID_EVAL_FOLD", None)
     assert not torch.equal(e0, e1)
     assert torch.equal(e1, e2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,relu,wgs,form", [
+    (3, 256, 128, 0, 0, 0),       # one run per image part, default grid
+    (3, 256, 128, 1, 5, 0),       # 48 steps over 5 workgroups: runs start inside images (the row above is computed first)
+    (2, 256, 128, 0, 7, 1),       # four-wave workgroups, four rows per step
+    (5, 64, 128, 1, 3, 1),
+    (2, 320, 320, 1, 0, 0),       # the IBN-a configuration's image size
+    (3, 320, 320, 0, 7, 0),
+    (1, 16, 128, 1, 0, 0),        # one step per image
+])
+def test_stem_conv_pool_one_launch_equals_two_launches(B, H, W, relu, wgs, form, dtype, monkeypatch):
+    """creid_stem_conv_pool_fwd_affine (conv_stem.hip: conv1 + folded bn1 (+ ReLU) + 3x3/2 max-pool, the full-resolution tensor
+    never written) against creid_stem_conv_fwd_affine + creid_maxpool3x3s2_fwd: identical bits."""
+    from centroids_reid_amd import _lib as L
+    lib = L.lib()
+    dt = L.dtype_code(torch.empty(0, dtype=dtype))
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H + W + relu)
+    img = torch.randn((B, 3, H, W), generator=g, device="cuda", dtype=torch.float32)
+    xpad = torch.empty((B, H + 8, W + 6, 4), device="cuda", dtype=dtype)
+    st = L.stream()
+    L.check(lib.creid_image_to_nhwc4_pad(L.ptr(img), B, H, W, dt, L.ptr(xpad), st), "image_pad")
+    w = torch.zeros((64, 8, 8, 4), device="cuda", dtype=torch.float32)
+    w[:, :7, :7, :3] = torch.randn((64, 7, 7, 3), generator=g, device="cuda") / 12.0
+    w = w.reshape(64, 256).to(dtype).contiguous()
+    ss = torch.empty((2, 64), device="cuda", dtype=torch.float32)
+    ss[0] = torch.rand(64, generator=g, device="cuda") + 0.5
+    ss[1] = torch.randn(64, generator=g, device="cuda") * 0.3
+    H1, W1 = H // 2, W // 2
+    y0 = torch.empty((B, H1, W1, 64), device="cuda", dtype=dtype)
+    ref = torch.empty((B, H1 // 2, W1 // 2, 64), device="cuda", dtype=dtype)
+    L.check(lib.creid_stem_conv_fwd_affine(B, H, W, L.ptr(xpad), L.ptr(w), L.ptr(y0), L.ptr(ss), relu, dt, st), "stem")
+    L.check(lib.creid_maxpool3x3s2_fwd(L.ptr(y0), B, H1, W1, 64, dt, L.ptr(ref), None, st), "maxpool")
+    if wgs:
+        monkeypatch.setenv("CREID_STEM_WGS", str(wgs))
+    monkeypatch.setenv("CREID_STEM_FORM", str(form))
+    got = torch.full_like(ref, float("nan"))
+    L.check(lib.creid_stem_conv_pool_fwd_affine(B, H, W, L.ptr(xpad), L.ptr(w), L.ptr(got), L.ptr(ss), relu, dt, st), "stem_pool")
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref.float()).all()
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), \
+        f"max |diff| {(got.float() - ref.float()).abs().max().item()}, differing {(got != ref).sum().item()} of {ref.numel()}"
+
+
+def test_stem_conv_pool_refuses_other_sizes():
+    from centroids_reid_amd import _lib as L
+    lib = L.lib()
+    x = torch.zeros((1, 64 + 8, 64 + 6, 4), device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros((64, 256), device="cuda", dtype=torch.bfloat16)
+    ss = torch.zeros((2, 64), device="cuda")
+    y = torch.zeros((1, 16, 16, 64), device="cuda", dtype=torch.bfloat16)
+    assert lib.creid_stem_conv_pool_fwd_affine(1, 64, 64, L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(ss), 0, L.dtype_code(y),
+                                               L.stream()) == -4
