@@ -558,18 +558,22 @@ int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* 
 // Same k order as the tile kernels (tap-major, 16-wide slices inside a tap) and the same epilogue arithmetic: identical output
 // bits; statistics partials equal up to the grouping of the column sums.  Forward only (training statistics / folded eval-mode
 // affine / plain); W = 32 or 64 with H * W % 128 = 0; anything else takes the tile kernels.
-template <int W, typename ET>
-__global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const unsigned short* __restrict__ src, int M, int H,
+// T2D (image widths that are no divisor / multiple of 128 pixels, e.g. the 80 x 80 maps of the 320 x 320 configuration): the tile
+// is TW = 16 columns x 8 rows of the image instead of 128 consecutive pixels, the halo tile carries its left and right columns
+// too (zero outside the image), the image width is a run-time value Wrt; everything behind the staging is unchanged.
+template <int TW, typename ET, bool T2D>
+__global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const unsigned short* __restrict__ src, int M, int H, int Wrt,
                                                               const unsigned short* __restrict__ wgt,
                                                               unsigned short* __restrict__ out, float* __restrict__ bn_part,
                                                               const float* __restrict__ epi_scale, const float* __restrict__ epi_shift,
                                                               int epi_relu, int n_tiles, int abl) {
-  constexpr int RW = 128 / W;                           // output rows per tile
-  constexpr int PW = W + 2, PX = (RW + 2) * PW;         // pixel slots per halo row / per halo tile
+  constexpr int W = TW;                                 // (full-row tiles: the image width)
+  constexpr int RW = 128 / TW;                          // output rows per tile
+  constexpr int PW = TW + 2, PX = (RW + 2) * PW;        // pixel slots per halo row / per halo tile
   constexpr int SLOT = PX * 64;                         // elements per ring slot
-  constexpr int NLD = ((RW + 2) * W * 8) / 512;         // 16-byte chunks per thread and halo tile
+  constexpr int NLD = T2D ? (PX * 8 + 511) / 512 : ((RW + 2) * W * 8) / 512;   // 16-byte chunks per thread and halo tile
   constexpr int CPT = 128 + 4, CPR = 8, NIT = 2;        // staging pitch; 16-byte chunks per output row; chunks per thread
-  static_assert(((RW + 2) * W * 8) % 512 == 0, "halo tile load map");
+  static_assert(T2D || ((RW + 2) * W * 8) % 512 == 0, "halo tile load map");
   constexpr int WP = 576 + 8;                           // weight row pitch in the one-time LDS image (conflict-free 16-byte reads)
   __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * SLOT + 64 * CPT + 4 * 2 * 64 * 2 + 64 * WP];
   unsigned short* ring = smem;
@@ -606,21 +610,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const unsigned shor
       for (int kk = 0; kk < 4; ++kk) bw[tap][kk] = *reinterpret_cast<const s16x8*>(wrow + tap * 64 + kk * 16);
   }
   const unsigned wl_lane = (unsigned)(uintptr_t)(wl + (wc * 32 + l31) * WP + kh * 8);   // this lane's weight row in the LDS image
-  const int tiles_per_img = (H * W) / 128;
+  const int Wimg = T2D ? Wrt : W;
+  const int tiles_x = T2D ? Wimg / TW : 1;
+  const int tiles_per_img = (H * Wimg) / 128;
+  // tile -> image, first output row, first output column
+  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+    b = tile / tiles_per_img;
+    const int t = tile - b * tiles_per_img;
+    if constexpr (T2D) { const int ty = t / tiles_x; y0 = ty * RW; x0 = (t - ty * tiles_x) * TW; }
+    else { y0 = t * RW; x0 = 0; }
+  };
   uint4 areg[NLD];
   auto load_a = [&](int it) {
-    const int tile = t_begin + it;
-    const int b = tile / tiles_per_img, y0 = (tile - b * tiles_per_img) * RW;
+    int b, y0, x0;
+    tile_origin(t_begin + it, b, y0, x0);
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int idx = tid + 512 * u, ch = idx & 7, pix = idx >> 3;
-      const int row = pix / W, col = pix - row * W;
-      const int y = y0 - 1 + row;
-      const bool ok = (unsigned)y < (unsigned)H;
-      // (branch-free: a row outside the image reads row 0 of the image and is zeroed -- see igemm1x1_stream2_kernel)
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (!CREID_ABL_ON(abl, 2)) v = *reinterpret_cast<const uint4*>(src + ((int64_t)(b * H + (ok ? y : 0)) * W + col) * 64 + ch * 8);
-      areg[u] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (T2D) {
+        const int row = pix / PW, col = pix - row * PW;
+        const int y = y0 - 1 + row, x = x0 - 1 + col;
+        const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wimg && pix < PX;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (!CREID_ABL_ON(abl, 2)) v = *reinterpret_cast<const uint4*>(src + ((int64_t)(b * H + (ok ? y : 0)) * Wimg + (ok ? x : 0)) * 64 + ch * 8);
+        areg[u] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        const int row = pix / W, col = pix - row * W;
+        const int y = y0 - 1 + row;
+        const bool ok = (unsigned)y < (unsigned)H;
+        // (branch-free: a row outside the image reads row 0 of the image and is zeroed -- see igemm1x1_stream2_kernel)
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (!CREID_ABL_ON(abl, 2)) v = *reinterpret_cast<const uint4*>(src + ((int64_t)(b * H + (ok ? y : 0)) * W + col) * 64 + ch * 8);
+        areg[u] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+      }
     }
   };
   auto put_a = [&](int it) {
@@ -628,8 +650,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const unsigned shor
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int idx = tid + 512 * u, ch = idx & 7, pix = idx >> 3;
-      const int row = pix / W, col = pix - row * W;
-      const int p = row * PW + col + 1;
+      int p;
+      if constexpr (T2D) { p = pix; if (pix >= PX) continue; }
+      else { const int row = pix / W, col = pix - row * W; p = row * PW + col + 1; }
       *reinterpret_cast<uint4*>(slot + p * 64 + ((ch ^ ((p >> 1) & 7)) << 3)) = areg[u];
     }
   };
@@ -642,11 +665,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const unsigned shor
   uint4 outv[NIT];
   auto store_out = [&](int it) {
     const int64_t row0 = (int64_t)(t_begin + it) * 128;
+    int b = 0, y0 = 0, x0 = 0;
+    if constexpr (T2D) tile_origin(t_begin + it, b, y0, x0);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       int rl, ch;
       unit_of(i, rl, ch);
-      if (!CREID_ABL_ON(abl, 8)) *reinterpret_cast<uint4*>(out + (row0 + rl) * 64 + ch * 8) = outv[i];
+      int64_t pixel = row0 + rl;
+      if constexpr (T2D) pixel = ((int64_t)b * H + y0 + rl / TW) * Wimg + x0 + (rl % TW);
+      if (!CREID_ABL_ON(abl, 8)) *reinterpret_cast<uint4*>(out + pixel * 64 + ch * 8) = outv[i];
     }
   };
   float sc = 1.f, sh = 0.f;
@@ -757,7 +784,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const unsigned shor
 // Returns CREID_E_SHAPE when the convolution is outside the kernel's scope.
 int launch_conv3x3_c64(int M, int H, int Wd, const void* src, const void* wgt, void* out, float* bn_part, const float* epi_scale,
                        const float* epi_shift, int epi_relu, int dtype, hipStream_t s) {
-  if ((Wd != 32 && Wd != 64) || H <= 0 || (H * Wd) % 128 != 0 || M % (H * Wd) != 0 || !creid_is16(dtype)) return CREID_E_SHAPE;
+  const bool full_rows = (Wd == 32 || Wd == 64) && H > 0 && (H * Wd) % 128 == 0;
+  const bool tile2d = !full_rows && Wd > 0 && Wd % 16 == 0 && H > 0 && H % 8 == 0;      // 16 x 8 tiles (80 x 80: 50 per image)
+  if ((!full_rows && !tile2d) || M % (H * Wd) != 0 || !creid_is16(dtype)) return CREID_E_SHAPE;
   const int n_tiles = M / 128;
   int wgs = 256;
   { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
@@ -769,11 +798,12 @@ int launch_conv3x3_c64(int M, int H, int Wd, const void* src, const void* wgt, v
 #else
   const int abl = 0;
 #endif
-#define CREID_C64_LAUNCH(W_, ET_)                                                                              \
-  hipLaunchKernelGGL((conv3x3_c64_kernel<W_, ET_>), grid, block, 0, s, (const unsigned short*)src, M, H,      \
+#define CREID_C64_LAUNCH(W_, ET_, T2D_)                                                                             \
+  hipLaunchKernelGGL((conv3x3_c64_kernel<W_, ET_, T2D_>), grid, block, 0, s, (const unsigned short*)src, M, H, Wd,   \
                      (const unsigned short*)wgt, (unsigned short*)out, bn_part, epi_scale, epi_shift, epi_relu, n_tiles, abl)
-  if (Wd == 32) { if (dtype == CREID_F16) CREID_C64_LAUNCH(32, F16T); else CREID_C64_LAUNCH(32, Bf16T); }
-  else { if (dtype == CREID_F16) CREID_C64_LAUNCH(64, F16T); else CREID_C64_LAUNCH(64, Bf16T); }
+  if (tile2d) { if (dtype == CREID_F16) CREID_C64_LAUNCH(16, F16T, true); else CREID_C64_LAUNCH(16, Bf16T, true); }
+  else if (Wd == 32) { if (dtype == CREID_F16) CREID_C64_LAUNCH(32, F16T, false); else CREID_C64_LAUNCH(32, Bf16T, false); }
+  else { if (dtype == CREID_F16) CREID_C64_LAUNCH(64, F16T, false); else CREID_C64_LAUNCH(64, Bf16T, false); }
 #undef CREID_C64_LAUNCH
   return (int)hipGetLastError();
 }

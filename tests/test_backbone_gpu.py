@@ -773,7 +773,8 @@ def test_wgrad_two_k_groups_matches_fp64(case):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("wgs", [256, 3])
-@pytest.mark.parametrize("B,H,W", [(2, 64, 32), (3, 16, 32), (1, 4, 32), (2, 32, 64), (5, 6, 64), (128, 64, 32)])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 32), (3, 16, 32), (1, 4, 32), (2, 32, 64), (5, 6, 64), (128, 64, 32),
+                                   (2, 80, 80), (3, 16, 48), (1, 8, 16), (2, 24, 112)])     # 16 x 8 tiles (image width run-time)
 def test_conv3x3_c64_halo_tile_kernel_matches_tile_kernels(B, H, W, wgs, dtype, monkeypatch):
     """layer1's 3 x 3, 64 -> 64 forward (conv3x3_c64_kernel: input halo tile staged once in LDS, weight fragments resident in
     registers, persistent workgroups over contiguous tile runs) against the tile kernels on the same inputs: identical output
@@ -801,7 +802,11 @@ def test_conv3x3_c64_halo_tile_kernel_matches_tile_kernels(B, H, W, wgs, dtype, 
     torch.cuda.synchronize()
     for k in (0, 2, 3, 4):
         assert torch.equal(new[k], base[k]), k
-    np.testing.assert_allclose(new[1].cpu().numpy(), base[1].cpu().numpy(), rtol=1e-6, atol=1e-5)
+    if W in (32, 64):
+        np.testing.assert_allclose(new[1].cpu().numpy(), base[1].cpu().numpy(), rtol=1e-6, atol=1e-5)
+    else:       # 16 x 8 tiles: a partial row covers other pixels than the tile kernels' 128 consecutive ones -- per-image sums agree
+        pn, pb = (t.double().reshape(B, (H * W) // 128, 2, 64).sum(1).cpu().numpy() for t in (new[1], base[1]))
+        np.testing.assert_allclose(pn, pb, rtol=1e-6, atol=1e-4)
     import torch.nn.functional as F
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), krsc.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     tol = 2e-2 if dtype == torch.bfloat16 else 3e-3

@@ -7,9 +7,8 @@ sys.path.insert(0, ".")
 from centroids_reid_amd import layers as ly   # noqa: E402
 from bench import time_kernel                  # noqa: E402
 
-for B in (64, 128):
-    H, W = 64, 32
-    R = 4
+for B, H, W in ((64, 64, 32), (128, 64, 32), (56, 80, 80), (256, 80, 80)):
+    R = 4 if B < 256 else 2
     xs = [torch.randn((B, H, W, 64), device="cuda").to(torch.bfloat16) for _ in range(R)]
     w = torch.randn((64, 64, 3, 3), device="cuda") / 24
     krsc, _ = ly.weight_prep(w, torch.bfloat16)
@@ -37,4 +36,4 @@ for B in (64, 128):
             os.environ["CREID_C64_ABL"] = "0"
             print("      " + "  ".join(cells))
         by = 2 * B * H * W * 64 * 2
-        print(f"B={B} {name:6s} tile kernels {res['0']:6.1f} us   halo-tile kernel {res['1']:6.1f} us   ({by / res['1'] / 1e3:.0f} GB/s algorithmic)")
+        print(f"B={B} {H}x{W} {name:6s} tile kernels {res['0']:6.1f} us   halo-tile kernel {res['1']:6.1f} us   ({by / res['1'] / 1e3:.0f} GB/s algorithmic)")
