@@ -143,7 +143,11 @@ int creid_stream_finalize(const int32_t* npos, const uint32_t* hist, int64_t m, 
  * (tile rows 64|128, tile cols 64|128, pixel splits | ring depth << 16 | producer/consumer waves << 20 | two k-groups << 21);
  * kind 1 = implicit-GEMM forward / data gradient: key (GEMM rows M, GEMM cols N, K, transposed 0|1 | stride << 1) ->
  * (N tile 64|128, LDS ring depth 2|3|4, kernel 0 producer/consumer | 1 four-wave DMA | 2 persistent 1x1 | 3 256-row tiles |
- * 4 persistent 1x1, second form: forward only, K = 64|128|256, the ring-depth slot caps its column slab: 2 widest, 3 128, 4 64).  A plan only selects among kernel variants
+ * 4 persistent 1x1, second form: forward only, K = 64|128|256, the ring-depth slot caps its column slab: 2 widest, 3 128, 4 64 |
+ * 5 all-waves-multiply persistent kernel (conv_pipe.hip): forward only, K % 64 = 0, the first slot is then the variant word
+ * tile rows/128 | (tile cols/128) << 2 | k-tiles per phase << 4 | loop form << 8 (0 ping-pong wave groups, 2 free-running),
+ * second slot 0).  Key bit 3 of the last component (| 8) marks a plan that applies to the eval-mode epilogue only (folded affine /
+ * residual / ReLU): such launches look it up first and fall back to the key without the bit.  A plan only selects among kernel variants
  * the library already has; shapes without an entry use the built-in rules.  Not thread-safe against running launches:
  * register before the first convolution (the Python binding does it at load time from tuned_plans.json). */
 int creid_tune_set(int32_t kind, int64_t a, int64_t b, int64_t c, int64_t d, int32_t p0, int32_t p1, int32_t p2);

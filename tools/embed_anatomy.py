@@ -32,20 +32,23 @@ def main(path, B=128, H=256, W=128):
             # downsample entry follows the first block of a layer
             ds = shapes[i]; i += 1
         order += [("c1", blk[0]), ("c2", blk[1])] + ([("ds", ds)] if ds else []) + [("c3", blk[2])]
-    convs = [r for r in seg if "igemm" in r[0]]
+    is_conv = lambda n: "igemm" in n or "conv3x3_c64" in n or "stem_pool" in n      # every kernel that runs a convolution
+    convs = [r for r in seg if is_conv(r[0])]
     print(f"one embedding forward: {len(seg)} kernels, {sum(e - s for _, s, e in seg) / 1e3:.0f} us summed, span {(seg[-1][2] - seg[0][1]) / 1e3:.0f} us; "
-          f"{len(convs)} igemm launches (expected {len(order) + 1})")
+          f"{len(convs)} convolution launches (expected {len(order) + 1})")
     print("| # | role | shape | kernel | us | TF/s | GB/s (algorithmic) |\n|---|---|---|---|---:|---:|---:|")
     tot_fl = tot_t = 0.0
     ci = 0
     for n, s, e in seg:
         t = (e - s) / 1e3
         short = re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:46]
-        if "igemm" in n:
+        if is_conv(n):
             if ci == 0:
                 fl = 2.0 * B * (H // 2) * (W // 2) * 64 * 147
                 by = B * (H + 8) * (W + 6) * 4 * 2 + B * (H // 2) * (W // 2) * 64 * 2
-                role, label = "stem", f"3->64 k7 s2 {H}x{W}"
+                if "stem_pool" in n:                  # one launch with the max-pool: only the pooled tensor is written
+                    by = B * (H + 8) * (W + 6) * 4 * 2 + B * (H // 4) * (W // 4) * 64 * 2
+                role, label = "stem" + (" + pool" if "stem_pool" in n else ""), f"3->64 k7 s2 {H}x{W}"
             else:
                 role, (cin, cout, k, st, h, w) = order[ci - 1]
                 ho, wo = (h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1
@@ -57,7 +60,7 @@ def main(path, B=128, H=256, W=128):
             print(f"| {ci} | {role} | {label} | {short} | {t:.1f} | {fl / t / 1e6:.0f} | {by / t / 1e3:.0f} |")
         else:
             print(f"|  | - | | {short} | {t:.1f} | | |")
-    print(f"\nigemm launches: {tot_t:.0f} us, {tot_fl / tot_t / 1e6:.0f} TF/s over the forward")
+    print(f"\nconvolution launches: {tot_t:.0f} us, {tot_fl / tot_t / 1e6:.0f} TF/s over the forward")
 
 
 if __name__ == "__main__":
