@@ -1318,24 +1318,31 @@ __global__ __launch_bounds__(1024) void ibn_bwd_finalize_kernel(const float* __r
   __shared__ double red[64][2][16];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
+  const int n0 = blockIdx.y * 16;                       // 16 images per workgroup; lane (image rg & 15, quarter rg >> 4)
   const bool live = c < C, is_in = live && c < c_in, is_bn = live && c >= c_in;
   double s1 = 0.0, s2 = 0.0;
-  if (is_bn)
+  if (is_bn) {
     for (int r = rg; r < B * rpi; r += 64) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
+  } else if (is_in) {
+    const int n = n0 + (rg & 15);
+    if (n < B)
+      for (int r = rg >> 4; r < rpi; r += 4) {
+        s1 += (double)partial[(((int64_t)n * rpi + r) * 2) * C + c];
+        s2 += (double)partial[(((int64_t)n * rpi + r) * 2 + 1) * C + c];
+      }
+  }
   red[rg][0][cl] = s1; red[rg][1][cl] = s2;
   __syncthreads();
   if (is_in) {
-    const float g = in_w[c];
-    const float invM = 1.0f / (float)HW;
-    for (int n = rg; n < B; n += 64) {
-      double t1 = 0.0, t2 = 0.0;
-      for (int r = 0; r < rpi; ++r) {
-        t1 += (double)partial[(((int64_t)n * rpi + r) * 2) * C + c];
-        t2 += (double)partial[(((int64_t)n * rpi + r) * 2 + 1) * C + c];
-      }
+    const int il = rg & 15, n = n0 + il;
+    if ((rg >> 4) == 0 && n < B) {
+      const double t1 = ((red[il][0][cl] + red[16 + il][0][cl]) + red[32 + il][0][cl]) + red[48 + il][0][cl];
+      const double t2 = ((red[il][1][cl] + red[16 + il][1][cl]) + red[32 + il][1][cl]) + red[48 + il][1][cl];
+      const float g = in_w[c];
+      const float invM = 1.0f / (float)HW;
       per_img[((int64_t)n * 2) * c_in + c] = (float)t1;         // reduced over images by ibn_in_grad_kernel
       per_img[((int64_t)n * 2 + 1) * c_in + c] = (float)t2;
       const float mu = mean[(int64_t)n * C + c], is = invstd[(int64_t)n * C + c], k1 = g * is;
@@ -1348,12 +1355,13 @@ __global__ __launch_bounds__(1024) void ibn_bwd_finalize_kernel(const float* __r
     s1 = 0.0; s2 = 0.0;
 #pragma unroll 8
     for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
-    if (rg == 0) { if (d_bn_b) d_bn_b[c - c_in] += (float)s1; if (d_bn_w) d_bn_w[c - c_in] += (float)s2; }
+    if (rg == 0 && blockIdx.y == 0) { if (d_bn_b) d_bn_b[c - c_in] += (float)s1; if (d_bn_w) d_bn_w[c - c_in] += (float)s2; }
     const float invM = (float)(1.0 / ((double)B * HW));
     const float mu = mean[c], is = invstd[c], k1 = bn_w[c - c_in] * is;      // same for every image: read image 0
     const float a1 = (float)s1 * invM, a2 = (float)s2 * invM;
     const float cA = k1, cB = -k1 * is * a2, cC = -k1 * a1 + k1 * is * a2 * mu;
-    for (int n = rg; n < B; n += 64) {
+    const int n = n0 + rg;
+    if (rg < 16 && n < B) {
       coef[((int64_t)n * 3) * C + c] = cA;
       coef[((int64_t)n * 3 + 1) * C + c] = cB;
       coef[((int64_t)n * 3 + 2) * C + c] = cC;
@@ -1480,7 +1488,7 @@ int creid_ibn_bwd_mask(const void* x, const void* g, const void* act, const uint
              hipLaunchKernelGGL(ibn_bwd_reduce_kernel<_Float16>, dim3((unsigned)((C / 8 + 31) / 32), rpi, (unsigned)B),
                                 dim3(256), 0, s, (const _Float16*)x, (const _Float16*)g,
                                 (const _Float16*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial, mask));
-  hipLaunchKernelGGL(ibn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial,
+  hipLaunchKernelGGL(ibn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)((B + 15) / 16)), dim3(1024), 0, s, partial,
                      (int)B, rpi, (int)HW, (int)C, (int)c_in, mean, invstd, in_w, bn_w, coef, per_img, d_bn_w, d_bn_b);
   hipLaunchKernelGGL(ibn_in_grad_kernel, dim3((unsigned)((c_in + 255) / 256)), dim3(256), 0, s, per_img, (int)B, (int)c_in,
                      d_in_w, d_in_b);
