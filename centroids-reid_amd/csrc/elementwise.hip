@@ -1160,7 +1160,16 @@ __global__ __launch_bounds__(1024) void ibn_finalize_kernel(const float* __restr
   const bool live = c < C, is_in = live && c < c_in, is_bn = live && c >= c_in;
   double s1 = 0.0, s2 = 0.0;
   if (is_bn && training) {
-    for (int r = rg; r < B * rpi; r += 64) {
+    int r = rg;
+    for (; r + 192 < B * rpi; r += 256) {               // 8 independent loads per trip (the loop is pure load latency)
+      const float a0 = partial[((int64_t)r * 2) * C + c], b0 = partial[((int64_t)r * 2 + 1) * C + c];
+      const float a1 = partial[((int64_t)(r + 64) * 2) * C + c], b1 = partial[((int64_t)(r + 64) * 2 + 1) * C + c];
+      const float a2 = partial[((int64_t)(r + 128) * 2) * C + c], b2 = partial[((int64_t)(r + 128) * 2 + 1) * C + c];
+      const float a3 = partial[((int64_t)(r + 192) * 2) * C + c], b3 = partial[((int64_t)(r + 192) * 2 + 1) * C + c];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; r < B * rpi; r += 64) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
@@ -1322,7 +1331,16 @@ __global__ __launch_bounds__(1024) void ibn_bwd_finalize_kernel(const float* __r
   const bool live = c < C, is_in = live && c < c_in, is_bn = live && c >= c_in;
   double s1 = 0.0, s2 = 0.0;
   if (is_bn) {
-    for (int r = rg; r < B * rpi; r += 64) {
+    int r = rg;
+    for (; r + 192 < B * rpi; r += 256) {               // 8 independent loads per trip (the loop is pure load latency)
+      const float a0 = partial[((int64_t)r * 2) * C + c], b0 = partial[((int64_t)r * 2 + 1) * C + c];
+      const float a1 = partial[((int64_t)(r + 64) * 2) * C + c], b1 = partial[((int64_t)(r + 64) * 2 + 1) * C + c];
+      const float a2 = partial[((int64_t)(r + 128) * 2) * C + c], b2 = partial[((int64_t)(r + 128) * 2 + 1) * C + c];
+      const float a3 = partial[((int64_t)(r + 192) * 2) * C + c], b3 = partial[((int64_t)(r + 192) * 2 + 1) * C + c];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; r < B * rpi; r += 64) {
       s1 += (double)partial[((int64_t)r * 2) * C + c];
       s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
@@ -1369,14 +1387,25 @@ __global__ __launch_bounds__(1024) void ibn_bwd_finalize_kernel(const float* __r
   }
 }
 
-__global__ __launch_bounds__(256) void ibn_in_grad_kernel(const float* __restrict__ per_img, int B, int c_in,
-                                                          float* __restrict__ d_in_w, float* __restrict__ d_in_b) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= c_in) return;
+// d(in_w, in_b) += sum over images of the per-image sums: 16 channels x 64 image lanes per workgroup, fixed-order LDS tree
+// (round 4: one thread per channel walked all B images, 16 us of load latency per launch)
+__global__ __launch_bounds__(1024) void ibn_in_grad_kernel(const float* __restrict__ per_img, int B, int c_in,
+                                                           float* __restrict__ d_in_w, float* __restrict__ d_in_b) {
+  __shared__ float red[64][2][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s1 = 0.f, s2 = 0.f;
-  for (int n = 0; n < B; ++n) { s1 += per_img[((int64_t)n * 2) * c_in + c]; s2 += per_img[((int64_t)n * 2 + 1) * c_in + c]; }
-  if (d_in_b) d_in_b[c] += s1;
-  if (d_in_w) d_in_w[c] += s2;
+  if (c < c_in)
+    for (int n = rg; n < B; n += 64) { s1 += per_img[((int64_t)n * 2) * c_in + c]; s2 += per_img[((int64_t)n * 2 + 1) * c_in + c]; }
+  red[rg][0][cl] = s1; red[rg][1][cl] = s2;
+  __syncthreads();
+  if (rg == 0 && c < c_in) {
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
+    if (d_in_b) d_in_b[c] += s1;
+    if (d_in_w) d_in_w[c] += s2;
+  }
 }
 
 template <typename T>
@@ -1490,7 +1519,7 @@ int creid_ibn_bwd_mask(const void* x, const void* g, const void* act, const uint
                                 (const _Float16*)act, mean, invstd, (int)HW, (int)C, 128, rpi, partial, mask));
   hipLaunchKernelGGL(ibn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)((B + 15) / 16)), dim3(1024), 0, s, partial,
                      (int)B, rpi, (int)HW, (int)C, (int)c_in, mean, invstd, in_w, bn_w, coef, per_img, d_bn_w, d_bn_b);
-  hipLaunchKernelGGL(ibn_in_grad_kernel, dim3((unsigned)((c_in + 255) / 256)), dim3(256), 0, s, per_img, (int)B, (int)c_in,
+  hipLaunchKernelGGL(ibn_in_grad_kernel, dim3((unsigned)((c_in + 15) / 16)), dim3(1024), 0, s, per_img, (int)B, (int)c_in,
                      d_in_w, d_in_b);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(ibn_bwd_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4), (unsigned)B), dim3(256), 0, s,
