@@ -661,23 +661,33 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ layout transforms
-// NCHW fp32 image -> zero-padded NHWC4 [B, H+8, W+6, 4] (image at rows 3.., cols 3..)
+// NCHW fp32 image -> zero-padded NHWC4 [B, H+8, W+6, 4] (image at rows 3.., cols 3..).  Eight padded rows per workgroup trip (no
+// 64-bit index divisions on the per-pixel path), a pixel's four values as ONE 8- / 16-byte store.
+__device__ __forceinline__ void store_px4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store_px4(unsigned short* p, const float (&v)[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(Bf16T::pack2(v[0], v[1]), Bf16T::pack2(v[2], v[3]));
+}
+__device__ __forceinline__ void store_px4(_Float16* p, const float (&v)[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(F16T::pack2(v[0], v[1]), F16T::pack2(v[2], v[3]));
+}
 template <typename T>
 __global__ __launch_bounds__(256) void image_pad_kernel(const float* __restrict__ x, int B, int H, int W, T* __restrict__ y) {
   const int PH = H + 8, PW = W + 6;
-  const int64_t total = (int64_t)B * PH * PW;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int px = (int)(i % PW);
-    const int py = (int)((i / PW) % PH);
-    const int b = (int)(i / ((int64_t)PW * PH));
-    const int iy = py - 3, ix = px - 3;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+  const int rows = B * PH;
+  constexpr int RB = 8;                                 // padded rows per workgroup trip (32-bit index arithmetic inside)
+  for (int row0 = blockIdx.x * RB; row0 < rows; row0 += gridDim.x * RB) {
+    const int n = min(RB, rows - row0) * PW;
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int rl = e / PW, px = e - rl * PW, row = row0 + rl;
+      const int b = row / PH, py = row - b * PH, iy = py - 3, ix = px - 3;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        const float* src = x + (((int64_t)b * 3) * H + iy) * W + ix;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = x[(((int64_t)b * 3 + c) * H + iy) * W + ix];
+        for (int c = 0; c < 3; ++c) v[c] = src[(int64_t)c * H * W];
+      }
+      store_px4(y + ((int64_t)row * PW + px) * 4, v);
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ElemIO<T>::st(y + i * 4 + c, v[c]);
   }
 }
 
@@ -706,7 +716,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 struct BnFoldEntry { const float* gamma; const float* beta; const float* mean; const float* var; float* out; int C; float eps; };
 __global__ __launch_bounds__(256) void bn_fold_multi_kernel(const BnFoldEntry* __restrict__ tab) {
   const BnFoldEntry e = tab[blockIdx.x];
-  for (int c = threadIdx.x; c < e.C; c += 256) {
+  for (int c = blockIdx.y * 256 + threadIdx.x; c < e.C; c += gridDim.y * 256) {     // (grid.y = 8: one channel per thread up to C = 2048)
     const float mu = e.mean[c], is = 1.0f / sqrtf(e.var[c] + e.eps);
     const float sc = is * (e.gamma ? e.gamma[c] : 1.f);
     e.out[c] = sc;
@@ -1065,7 +1075,7 @@ int64_t creid_bn2d_fold_entry_bytes(void) { return (int64_t)sizeof(BnFoldEntry);
 
 int creid_bn2d_fold_multi(const void* table_dev, int64_t n_entries, void* stream) {
   CREID_CHECK_ARG(table_dev && n_entries > 0 && n_entries < (1 << 20));
-  hipLaunchKernelGGL(bn_fold_multi_kernel, dim3((unsigned)n_entries), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(bn_fold_multi_kernel, dim3((unsigned)n_entries, 8), dim3(256), 0, as_stream(stream),
                      (const BnFoldEntry*)table_dev);
   CREID_LAUNCH_RET();
 }

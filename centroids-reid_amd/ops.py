@@ -275,7 +275,7 @@ class BatchNorm1dFn(torch.autograd.Function):
                                        L.ptr(si), L.stream()), "creid_bn1d_fwd")
         if training:
             ctx.save_for_backward(x, weight, sm, si)
-        else:
+        elif ctx.needs_input_grad[0]:       # eval mode under autograd only: inference (no_grad) must not pay three extra launches
             ctx.save_for_backward(x, weight, rmean.clone(), torch.rsqrt(rvar + eps))
         ctx.training = training
         return y
