@@ -675,6 +675,38 @@ __global__ __launch_bounds__(256) void image_pad_kernel(const float* __restrict_
   const int PH = H + 8, PW = W + 6;
   const int rows = B * PH;
   constexpr int RB = 8;                                 // padded rows per workgroup trip (32-bit index arithmetic inside)
+  if ((W & 3) == 0) {
+    // a unit = four image pixels of one row (three 16-byte plane loads -> 32 contiguous output bytes) or one of the row's two
+    // 3-pixel zero borders; rows above / below the image are all zeros
+    const int G = W / 4 + 2;
+    for (int row0 = blockIdx.x * RB; row0 < rows; row0 += gridDim.x * RB) {
+      const int n = min(RB, rows - row0) * G;
+      for (int e = threadIdx.x; e < n; e += 256) {
+        const int rl = e / G, gq = e - rl * G, row = row0 + rl;
+        const int b = row / PH, py = row - b * PH, iy = py - 3;
+        T* dst = y + (int64_t)row * PW * 4;
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gq == 0 || gq == G - 1) {
+          T* d = dst + (gq == 0 ? 0 : (W + 3) * 4);
+          store_px4(d, z); store_px4(d + 4, z); store_px4(d + 8, z);
+          continue;
+        }
+        const int ix = (gq - 1) * 4;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+        if ((unsigned)iy < (unsigned)H) {
+          const float* src = x + (((int64_t)b * 3) * H + iy) * W + ix;
+          p0 = *reinterpret_cast<const float4*>(src);
+          p1 = *reinterpret_cast<const float4*>(src + (int64_t)H * W);
+          p2 = *reinterpret_cast<const float4*>(src + (int64_t)2 * H * W);
+        }
+        T* d = dst + (ix + 3) * 4;
+        const float v0[4] = {p0.x, p1.x, p2.x, 0.f}, v1[4] = {p0.y, p1.y, p2.y, 0.f};
+        const float v2[4] = {p0.z, p1.z, p2.z, 0.f}, v3[4] = {p0.w, p1.w, p2.w, 0.f};
+        store_px4(d, v0); store_px4(d + 4, v1); store_px4(d + 8, v2); store_px4(d + 12, v3);
+      }
+    }
+    return;
+  }
   for (int row0 = blockIdx.x * RB; row0 < rows; row0 += gridDim.x * RB) {
     const int n = min(RB, rows - row0) * PW;
     for (int e = threadIdx.x; e < n; e += 256) {
