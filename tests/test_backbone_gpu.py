@@ -811,3 +811,36 @@ def test_conv3x3_c64_halo_tile_kernel_matches_tile_kernels(B, H, W, wgs, dtype, 
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), krsc.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
     np.testing.assert_allclose(new[0].float().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_weight_prep_multi_equals_single_tensor_prep(dtype):
+    """creid_weight_prep_multi (one table-driven launch for all convolutions of the network; 16-bit full tiles take the
+    contiguous-run path with 16-byte stores) against creid_weight_prep per tensor: identical [O][r][s][I] / [I][r][s][O] copies.
+    Shapes: 1x1 and 3x3 full tiles, channel counts that leave partial 32 x 32 tiles (per-tap path), a 5 x 5 kernel (> 9 taps)."""
+    import ctypes as C
+    from centroids_reid_amd import _lib as L
+    from centroids_reid_amd import layers as ly
+    lib = L.lib()
+    shapes = [(64, 64, 3), (64, 256, 1), (256, 64, 1), (512, 512, 3), (128, 128, 3), (40, 48, 3), (96, 32, 1), (32, 64, 5), (2048, 512, 1)]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    ws = [torch.randn((o, i, k, k), generator=g, device="cuda") for o, i, k in shapes]
+    krsc = [torch.full((o, k, k, i), float("nan"), device="cuda", dtype=dtype) for o, i, k in shapes]
+    crsk = [torch.full((i, k, k, o), float("nan"), device="cuda", dtype=dtype) for o, i, k in shapes]
+    rec = np.zeros(len(shapes), dtype=np.dtype([("w", "<u8"), ("krsc", "<u8"), ("crsk", "<u8"), ("O", "<i4"), ("I", "<i4"),
+                                                 ("kh", "<i4"), ("kw", "<i4"), ("start", "<i8")]))
+    assert lib.creid_weight_prep_entry_bytes() == rec.dtype.itemsize
+    start, tiles, tstart = 0, 0, np.zeros(len(shapes), np.int32)
+    for n, (o, i, k) in enumerate(shapes):
+        rec[n] = (ws[n].data_ptr(), krsc[n].data_ptr(), crsk[n].data_ptr(), o, i, k, k, start)
+        start += o * i * k * k
+        tstart[n] = tiles
+        tiles += ((o + 31) // 32) * ((i + 31) // 32)
+    tab = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    ts = torch.from_numpy(tstart).cuda()
+    L.check(lib.creid_weight_prep_multi(L.ptr(tab), L.ptr(ts), len(shapes), tiles, L.dtype_code(krsc[0]), L.stream()), "multi")
+    torch.cuda.synchronize()
+    for n, (o, i, k) in enumerate(shapes):
+        a, b = ly.weight_prep(ws[n], dtype)
+        assert torch.equal(krsc[n], a), ("krsc", shapes[n])
+        assert torch.equal(crsk[n], b), ("crsk", shapes[n])
