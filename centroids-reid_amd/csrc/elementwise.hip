@@ -493,11 +493,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   const int OH = H / 2, OW = W / 2, cpr = C / V;
   const int64_t total = (int64_t)B * OH * OW * cpr;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    int64_t p = i / cpr;
-    const int ox = (int)(p % OW); p /= OW;
-    const int oy = (int)(p % OH);
-    const int b = (int)(p / OH);
+    int cc, ox, oy, b;
+    if (total < (int64_t)1 << 31) {                      // 32-bit index arithmetic (a 64-bit division is ~40 VALU instructions)
+      const unsigned u = (unsigned)i, q1 = u / (unsigned)cpr, q2 = q1 / (unsigned)OW;
+      cc = (int)(u - q1 * cpr); ox = (int)(q1 - q2 * OW); b = (int)(q2 / (unsigned)OH); oy = (int)(q2 - (unsigned)b * OH);
+    } else {
+      cc = (int)(i % cpr);
+      int64_t p = i / cpr;
+      ox = (int)(p % OW); p /= OW;
+      oy = (int)(p % OH);
+      b = (int)(p / OH);
+    }
     float best[V];
     uint8_t bi[V];
 #pragma unroll
@@ -532,11 +538,17 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* __restri
   const int OH = H / 2, OW = W / 2, cpr = C / V;
   const int64_t total = (int64_t)B * OH * OW * cpr;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    int64_t p = i / cpr;
-    const int ox = (int)(p % OW); p /= OW;
-    const int oy = (int)(p % OH);
-    const int b = (int)(p / OH);
+    int cc, ox, oy, b;
+    if (total < (int64_t)1 << 31) {                      // 32-bit index arithmetic (a 64-bit division is ~40 VALU instructions)
+      const unsigned u = (unsigned)i, q1 = u / (unsigned)cpr, q2 = q1 / (unsigned)OW;
+      cc = (int)(u - q1 * cpr); ox = (int)(q1 - q2 * OW); b = (int)(q2 / (unsigned)OH); oy = (int)(q2 - (unsigned)b * OH);
+    } else {
+      cc = (int)(i % cpr);
+      int64_t p = i / cpr;
+      ox = (int)(p % OW); p /= OW;
+      oy = (int)(p % OH);
+      b = (int)(p / OH);
+    }
     float sc[V], sh[V], best[V];
     uint8_t bi[V];
 #pragma unroll
@@ -651,8 +663,10 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
   const int cpr = C / V;
   const float inv = 1.0f / (float)HW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    const int64_t b = i / ((int64_t)cpr * HW);
+    int cc;
+    int64_t b;
+    if (total_chunks < (int64_t)1 << 31) { const unsigned u = (unsigned)i; cc = (int)(u % (unsigned)cpr); b = u / (unsigned)(cpr * HW); }
+    else { cc = (int)(i % cpr); b = i / ((int64_t)cpr * HW); }
     float v[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) v[k] = dfeat[b * C + cc * V + k] * inv;
