@@ -207,3 +207,48 @@ def test_device_plan_sparse_pid_range_falls_back_to_host_index():
     f = torch.from_numpy(rng.standard_normal((nq + ng, 64)).astype(np.float32))
     a, ra, b, rb = _both(f, pids, cams, nq)
     _assert_same(a, ra, b, rb, pids, cams, nq)
+
+
+def test_streamed_speculative_capacity_is_verified():
+    """A streamed evaluation of a shape seen before assumes the earlier call's positive-list capacity instead of reading the
+    plan's statistics back in the middle of the pipeline, and checks the assumption in the final read-back: right hint ->
+    same results as the synchronous first call; too small -> redone with the right capacity; larger than needed -> identical
+    results, the hint shrinks."""
+    from centroids_reid_amd import reid_metric as rm
+    rng = np.random.default_rng(77)
+    nq, ng, D = 64, 1500, 96
+    f = torch.from_numpy(rng.standard_normal((nq + ng, D)).astype(np.float32)).cuda()
+    few = (rng.integers(0, 300, nq + ng), rng.integers(0, 3, nq + ng))          # ~5 gallery entries per identity
+    many = (rng.integers(0, 20, nq + ng), rng.integers(0, 3, nq + ng))          # ~75 per identity (< 128: no overflow rows)
+
+    def run(labels):
+        m = rm.R1_mAP(num_query=nq, streamed=True)
+        r = m.compute(f, labels[0], labels[1])
+        return m, r
+
+    def same(r0, m0, r1, m1):
+        np.testing.assert_array_equal(r1[0], r0[0]); assert r1[1] == r0[1]; np.testing.assert_array_equal(r1[2], r0[2])
+        for k in ("valid", "ap", "first"):
+            assert torch.equal(m1.last[k], m0.last[k]), k
+
+    rm._CAP_HINT.clear()
+    m0, r0 = run(few)                                     # synchronous: no hint yet
+    cap_few = rm._CAP_HINT[(nq, ng)]
+    assert cap_few == m0.last["plan"].cap and cap_few <= 32
+    m1, r1 = run(few)                                     # speculative, hint right
+    same(r0, m0, r1, m1)
+    rm._CAP_HINT.clear()
+    mb0, rb0 = run(many)                                  # reference for the second label set, synchronous
+    cap_many = mb0.last["plan"].cap
+    assert cap_many > cap_few
+    rm._CAP_HINT[(nq, ng)] = cap_few                      # a hint that is too small
+    mb1, rb1 = run(many)
+    same(rb0, mb0, rb1, mb1)
+    assert mb1.last["plan"].cap == cap_many and rm._CAP_HINT[(nq, ng)] == cap_many
+    m2, r2 = run(few)                                     # hint larger than needed: same results, hint shrinks
+    assert m2.last["plan"].cap == cap_many
+    same(r0, m0, r2, m2)
+    assert rm._CAP_HINT[(nq, ng)] == cap_few
+    a = rm.R1_mAP(num_query=nq)                           # and the materialised path agrees
+    ra = a.compute(f, many[0], many[1])
+    np.testing.assert_array_equal(rb1[0], ra[0]); assert abs(rb1[1] - ra[1]) < 1e-12
