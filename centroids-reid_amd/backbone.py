@@ -270,6 +270,7 @@ class BackboneEngine:
         self.relu_bitmask = dtype == torch.bfloat16 and os.environ.get("CREID_RELU_BITMASK", "1") == "1"
         self.stem_fuse_pool = os.environ.get("CREID_STEM_FUSE", "1") == "1"    # bn1 + maxpool in one pass (38 vs 51 us)
         self.stem_pool_fused = os.environ.get("CREID_STEM_POOL", "1") == "1"   # eval: conv1 + bn1 + maxpool in one launch
+        self.pair_fused = os.environ.get("CREID_PAIR_FUSE", "1") == "1"        # eval, layer1: conv3 of block i + conv1 of block i + 1
         # the backward counterpart (max-pool gradient gathered inside the BN backward passes) is correct but slower:
         # the gather is VALU-bound and runs twice (146 vs 116 us, tools/debug/stem_tail_probe.py) -- off by default
         self.stem_fuse_pool_bwd = os.environ.get("CREID_STEM_FUSE_BWD", "0") == "1"
@@ -450,7 +451,8 @@ class BackboneEngine:
             del y0
         del xpad
         h, w = H2, W2
-        for b in self.blocks:
+        a1_next = None                    # conv1 output of the CURRENT block when the previous block's conv3 launch produced it
+        for bi, b in enumerate(self.blocks):
             a_in, hin, win = a, h, w
             side = b["ds"] is not None and self.eval_ds_side
             if side:
@@ -458,7 +460,9 @@ class BackboneEngine:
                 # captured graph) beside conv1 / conv2 and is joined before conv3, whose epilogue adds it
                 with self._fork_side(a_in):
                     r = self._conv_fold(b["ds"], a_in, B, hin, win, False)[0]
-            if b["c1"].ibn is not None:
+            if a1_next is not None:
+                a1, h1, w1, a1_next = a1_next, hin, win, None
+            elif b["c1"].ibn is not None:
                 _, a1, _, _, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, False, True)
             else:
                 a1, h1, w1 = self._conv_fold(b["c1"], a_in, B, hin, win, True)
@@ -468,7 +472,20 @@ class BackboneEngine:
                 r.record_stream(torch.cuda.current_stream())
             else:
                 r = a_in if b["ds"] is None else self._conv_fold(b["ds"], a_in, B, hin, win, False)[0]
-            a, h, w = self._conv_fold(b["c3"], a2, B, h2, w2, True, residual=r)
+            nb = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            if (self.pair_fused and nb is not None and nb["ds"] is None and nb["c1"].ibn is None and self.dtype != torch.float32
+                    and (b["c3"].cin, b["c3"].cout, nb["c1"].cout) == (64, 256, 64) and nb["c1"].stride == 1):
+                # conv3 + bn3 + residual + ReLU of this block AND conv1 + bn1 + ReLU of the next one in one launch: the block
+                # output is written (it is the next residual) but never read back by conv1 (conv_pair.hip; layer1 only)
+                M3 = B * h2 * w2
+                a = self._empty(M3, 256)
+                a1_next = self._empty(M3, 64)
+                L.check(lib.creid_bottleneck_c3_c1_fwd_affine(M3, 64, 256, 64, L.ptr(a2), L.ptr(b["c3"].w_krsc), L.ptr(b["c3"].fold),
+                                                              L.ptr(r), L.ptr(a), L.ptr(nb["c1"].w_krsc), L.ptr(nb["c1"].fold),
+                                                              L.ptr(a1_next), self.dt, st), "bottleneck_c3_c1_fwd_affine")
+                h, w = h2, w2
+            else:
+                a, h, w = self._conv_fold(b["c3"], a2, B, h2, w2, True, residual=r)
         feat = self._empty(B, 2048, dtype=torch.float32)
         L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), st), "gap_fwd")
         self.saved = None

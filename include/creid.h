@@ -433,6 +433,15 @@ int creid_stem_conv_fwd_affine(int64_t batch, int64_t H, int64_t W, const void* 
  * caller then makes the two calls. */
 int creid_stem_conv_pool_fwd_affine(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* w_stem, void* y,
                                     const float* scale_shift, int relu, int dtype, void* stream);
+/* Eval-mode block boundary of layer1 in one launch (resnet.py:77-87 of bottleneck i, then :69-71 of bottleneck i + 1):
+ * out3 = relu(conv3(a2) * scale3 + shift3 + residual)   [M, c_out]   (= creid_conv2d_fwd_affine_nhwc with residual and ReLU)
+ * out1 = relu(conv1_next(out3) * scale1 + shift1)       [M, c_next]  (= creid_conv2d_fwd_affine_nhwc on out3)
+ * both 1 x 1 stride 1; a2 [M, c_mid]; weights in the [O][I] layout of creid_weight_prep; fold3 float[2][c_out], fold1
+ * float[2][c_next].  The block output is written once and never read back; both outputs are bit-identical to the two calls.
+ * 16-bit dtypes, (c_mid, c_out, c_next) = (64, 256, 64) only -- anything else: CREID_E_SHAPE, the caller makes the two calls. */
+int creid_bottleneck_c3_c1_fwd_affine(int64_t M, int64_t c_mid, int64_t c_out, int64_t c_next, const void* a2, const void* w3_krsc,
+                                      const float* fold3, const void* residual, void* out3, const void* w1_krsc,
+                                      const float* fold1, void* out1, int dtype, void* stream);
 size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype);
 int creid_stem_conv_wgrad(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* dy,
                           float* dw_oihw, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -213,3 +213,38 @@ def test_stem_conv_pool_refuses_other_sizes():
     y = torch.zeros((1, 16, 16, 64), device="cuda", dtype=torch.bfloat16)
     assert lib.creid_stem_conv_pool_fwd_affine(1, 64, 64, L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(ss), 0, L.dtype_code(y),
                                                L.stream()) == -4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,wgs", [(2, 16, 8, 0), (3, 10, 10, 0), (8, 64, 32, 0), (5, 64, 32, 7), (1, 3, 5, 0)])
+def test_block_boundary_one_launch_equals_two_launches(B, H, W, wgs, dtype, monkeypatch):
+    """creid_bottleneck_c3_c1_fwd_affine (conv_pair.hip: conv3 + bn3 + residual + ReLU of a layer1 bottleneck and conv1 + bn1 +
+    ReLU of the next one, the block output written once and never read back) against two creid_conv2d_fwd_affine_nhwc calls:
+    both outputs bit-identical.  Row counts that are no multiple of the 128-row tile, a workgroup cap (several tiles per workgroup)."""
+    from centroids_reid_amd import _lib as L
+    from centroids_reid_amd import layers as ly
+    lib = L.lib()
+    rng = np.random.default_rng(B * 100 + H + W)
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()
+    a2 = t(rng.standard_normal((B, H, W, 64))).to(dtype)
+    res = t(rng.standard_normal((B, H, W, 256))).to(dtype)
+    w3 = t(rng.standard_normal((256, 64, 1, 1)) / 8.0)
+    w1 = t(rng.standard_normal((64, 256, 1, 1)) / 16.0)
+    k3, _ = ly.weight_prep(w3, dtype)
+    k1, _ = ly.weight_prep(w1, dtype)
+    ss3 = t(np.stack([rng.uniform(0.5, 1.5, 256), rng.standard_normal(256) * 0.3]))
+    ss1 = t(np.stack([rng.uniform(0.5, 1.5, 64), rng.standard_normal(64) * 0.3]))
+    ref3 = ly.conv2d_fwd_affine(a2, k3, 1, 0, ss3, res, True)
+    ref1 = ly.conv2d_fwd_affine(ref3, k1, 1, 0, ss1, None, True)
+    if wgs:
+        monkeypatch.setenv("CREID_STREAM1X1_WGS", str(wgs))
+    M = B * H * W
+    out3 = torch.full((B, H, W, 256), float("nan"), device="cuda", dtype=dtype)
+    out1 = torch.full((B, H, W, 64), float("nan"), device="cuda", dtype=dtype)
+    L.check(lib.creid_bottleneck_c3_c1_fwd_affine(M, 64, 256, 64, L.ptr(a2), L.ptr(k3), L.ptr(ss3), L.ptr(res), L.ptr(out3),
+                                                  L.ptr(k1), L.ptr(ss1), L.ptr(out1), L.dtype_code(a2), L.stream()), "pair")
+    torch.cuda.synchronize()
+    assert torch.equal(out3.view(torch.int16), ref3.view(torch.int16)), f"block output: {(out3 != ref3).sum().item()} of {ref3.numel()} differ"
+    assert torch.equal(out1.view(torch.int16), ref1.view(torch.int16)), f"conv1 output: {(out1 != ref1).sum().item()} of {ref1.numel()} differ"
+    assert lib.creid_bottleneck_c3_c1_fwd_affine(M, 128, 512, 128, L.ptr(a2), L.ptr(k3), L.ptr(ss3), L.ptr(res), L.ptr(out3),
+                                                 L.ptr(k1), L.ptr(ss1), L.ptr(out1), L.dtype_code(a2), L.stream()) == -4
