@@ -80,6 +80,7 @@ SIGNATURES = {
     "creid_stem_conv_fwd_affine": (C.c_int, [_i64, _i64, _i64, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "creid_stem_conv_pool_fwd_affine": (C.c_int, [_i64, _i64, _i64, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "creid_bottleneck_c3_c1_fwd_affine": (C.c_int, [_i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p]),
+    "creid_bottleneck_c3_c1_fwd_stats": (C.c_int, [_i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p]),
     "creid_conv2d_dgrad_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p]),
     "creid_conv2d_wgrad_workspace_bytes": (_sz, [_p, C.c_int]),
     "creid_conv2d_wgrad_nhwc": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _sz, C.c_int, _p]),

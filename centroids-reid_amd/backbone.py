@@ -473,16 +473,28 @@ class BackboneEngine:
             else:
                 r = a_in if b["ds"] is None else self._conv_fold(b["ds"], a_in, B, hin, win, False)[0]
             nb = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
-            if (self.pair_fused and nb is not None and nb["ds"] is None and nb["c1"].ibn is None and self.dtype != torch.float32
-                    and (b["c3"].cin, b["c3"].cout, nb["c1"].cout) == (64, 256, 64) and nb["c1"].stride == 1):
-                # conv3 + bn3 + residual + ReLU of this block AND conv1 + bn1 + ReLU of the next one in one launch: the block
-                # output is written (it is the next residual) but never read back by conv1 (conv_pair.hip; layer1 only)
+            pair = (self.pair_fused and nb is not None and nb["ds"] is None and self.dtype != torch.float32
+                    and (b["c3"].cin, b["c3"].cout, nb["c1"].cout) == (64, 256, 64) and nb["c1"].stride == 1)
+            if pair and nb["c1"].ibn is not None:
+                pair = (h2 * w2) % 128 == 0              # the statistics partials must be per-image row blocks
+            if pair:
+                # conv3 + bn3 + residual + ReLU of this block AND conv1 (+ bn1 + ReLU, or the statistics an IBN layer needs) of the
+                # next one in one launch: the block output is written (it is the next residual) but never read back by conv1
+                # (conv_pair.hip; layer1 only)
                 M3 = B * h2 * w2
                 a = self._empty(M3, 256)
-                a1_next = self._empty(M3, 64)
-                L.check(lib.creid_bottleneck_c3_c1_fwd_affine(M3, 64, 256, 64, L.ptr(a2), L.ptr(b["c3"].w_krsc), L.ptr(b["c3"].fold),
-                                                              L.ptr(r), L.ptr(a), L.ptr(nb["c1"].w_krsc), L.ptr(nb["c1"].fold),
-                                                              L.ptr(a1_next), self.dt, st), "bottleneck_c3_c1_fwd_affine")
+                x1 = self._empty(M3, 64)
+                if nb["c1"].ibn is None:
+                    L.check(lib.creid_bottleneck_c3_c1_fwd_affine(M3, 64, 256, 64, L.ptr(a2), L.ptr(b["c3"].w_krsc), L.ptr(b["c3"].fold),
+                                                                  L.ptr(r), L.ptr(a), L.ptr(nb["c1"].w_krsc), L.ptr(nb["c1"].fold),
+                                                                  L.ptr(x1), self.dt, st), "bottleneck_c3_c1_fwd_affine")
+                    a1_next = x1
+                else:
+                    part = self._empty((M3 // 128) * 2, 64, dtype=torch.float32)
+                    L.check(lib.creid_bottleneck_c3_c1_fwd_stats(M3, 64, 256, 64, L.ptr(a2), L.ptr(b["c3"].w_krsc), L.ptr(b["c3"].fold),
+                                                                 L.ptr(r), L.ptr(a), L.ptr(nb["c1"].w_krsc), L.ptr(x1), L.ptr(part),
+                                                                 self.dt, st), "bottleneck_c3_c1_fwd_stats")
+                    a1_next = self._ibn_tail(nb["c1"], x1, B, h2 * w2, False, True, part)[0]
                 h, w = h2, w2
             else:
                 a, h, w = self._conv_fold(b["c3"], a2, B, h2, w2, True, residual=r)

@@ -15,7 +15,10 @@
 
 namespace creid_pair {
 
-template <typename ET>
+// STATS (the next block's conv1 feeds an IBN layer, resnet_ibn_a.py:27-32): out1 is the RAW convolution output and bn_part1 gets
+// the per-tile (sum, sum of squares) of the fp32 accumulators, [tiles][2][64] -- creid_conv2d_fwd_nhwc's statistics partials
+// (rows of a tile belong to one image when H * W % 128 = 0; M % 128 = 0 required: no padded rows in the sums).
+template <typename ET, bool STATS>
 __global__ __launch_bounds__(512, 1) void c3_c1_kernel(const unsigned short* __restrict__ src,      // [M][64]   conv2's output
                                                        const unsigned short* __restrict__ w3,       // [256][64]
                                                        const unsigned short* __restrict__ res,      // [M][256]  the block's input
@@ -24,19 +27,21 @@ __global__ __launch_bounds__(512, 1) void c3_c1_kernel(const unsigned short* __r
                                                        const unsigned short* __restrict__ w1,       // [64][256] next block's conv1
                                                        const float* __restrict__ ss1,               // [2][64]   folded bn1
                                                        unsigned short* __restrict__ out1,           // [M][64]
-                                                       int M, int tiles_m, int abl) {
+                                                       float* __restrict__ bn_part1, int M, int tiles_m, int abl) {
   constexpr int BN = 256, HB = 128, NH = 2, TW = 4;
   constexpr int CPT = 128 + 4;                         // staging pitch: [HB columns][128 rows + 4]
   constexpr int CPR = HB / 8, NIT = (128 * CPR) / 512; // 16-byte chunks per row of a half; chunks per thread and half (4)
   constexpr int CPR2 = 8, NIT2 = (128 * CPR2) / 512;   // the 64-column second output (2)
   constexpr int W3_ELEMS = BN * 64, TILE_ELEMS = 128 * 64, STAGE_ELEMS = HB * CPT, W1_ELEMS = 4 * 64 * 64, A2_ELEMS = 2 * TILE_ELEMS;
-  static_assert(2 * (W3_ELEMS + TILE_ELEMS + STAGE_ELEMS + W1_ELEMS + A2_ELEMS) <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(1024))) unsigned short smem[W3_ELEMS + TILE_ELEMS + STAGE_ELEMS + W1_ELEMS + A2_ELEMS];
+  constexpr int RED_ELEMS = STATS ? 4 * 2 * 64 * 2 : 0;  // fp32 [4 row waves][2][64] in 2-byte units
+  static_assert(2 * (W3_ELEMS + TILE_ELEMS + STAGE_ELEMS + W1_ELEMS + A2_ELEMS + RED_ELEMS) <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[W3_ELEMS + TILE_ELEMS + STAGE_ELEMS + W1_ELEMS + A2_ELEMS + RED_ELEMS + 8];
   unsigned short* Ws = smem;                           // conv3 weights [256][64]
   unsigned short* slot = smem + W3_ELEMS;              // this tile's A operand [128][64]
   unsigned short* stage = slot + TILE_ELEMS;           // [HB][CPT]
   unsigned short* Ws1 = stage + STAGE_ELEMS;           // conv1 weights [4 k-chunks][64 columns][64]
   unsigned short* A2 = Ws1 + W1_ELEMS;                 // the finished half of the block output as an operand: [2 k-chunks][128][64]
+  float* red = reinterpret_cast<float*>(A2 + A2_ELEMS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave & 3, wc = wave >> 2;
   const int l31 = lane & 31, kh = lane >> 5;
@@ -117,7 +122,8 @@ __global__ __launch_bounds__(512, 1) void c3_c1_kernel(const unsigned short* __r
   float sc[TW], sh[TW];
 #pragma unroll
   for (int j = 0; j < TW; ++j) { sc[j] = ss3[(2 * j + wc) * 32 + l31]; sh[j] = ss3[BN + (2 * j + wc) * 32 + l31]; }
-  const float sc1 = ss1[wc * 32 + l31], sh1 = ss1[64 + wc * 32 + l31];
+  float sc1 = 1.f, sh1 = 0.f;
+  if constexpr (!STATS) { sc1 = ss1[wc * 32 + l31]; sh1 = ss1[64 + wc * 32 + l31]; }
 
   for (int it = 0; it < n_iter; ++it) {
     __syncthreads();                                              // everyone is done with tile it - 1 (slot, staging, A2)
@@ -226,17 +232,33 @@ __global__ __launch_bounds__(512, 1) void c3_c1_kernel(const unsigned short* __r
     // conv1's epilogue: folded bn1 + ReLU, staged column-major in the (free) staging area, read back as 16-byte row chunks
     {
       const int cl = wc * 32 + l31;
+      if constexpr (STATS) {                                      // column sums of the fp32 accumulators (igemm1x1_stream2_kernel's)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc2[r]; s1 += v; s2 = fmaf(v, v, s2); }
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (kh == 0) { red[(wr * 2 + 0) * 64 + cl] = s1; red[(wr * 2 + 1) * 64 + cl] = s2; }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int rl = wr * 32 + 8 * q + 4 * kh;
-        float v0 = fmaf(acc2[4 * q], sc1, sh1), v1 = fmaf(acc2[4 * q + 1], sc1, sh1);
-        float v2 = fmaf(acc2[4 * q + 2], sc1, sh1), v3 = fmaf(acc2[4 * q + 3], sc1, sh1);
-        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));      // (as above)
-        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        float v0 = acc2[4 * q], v1 = acc2[4 * q + 1], v2 = acc2[4 * q + 2], v3 = acc2[4 * q + 3];
+        if constexpr (!STATS) {
+          v0 = fmaf(v0, sc1, sh1); v1 = fmaf(v1, sc1, sh1); v2 = fmaf(v2, sc1, sh1); v3 = fmaf(v3, sc1, sh1);
+          asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));    // (as above)
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
         *reinterpret_cast<uint2*>(&stage[cl * CPT + rl]) = make_uint2(ET::pack2(v0, v1), ET::pack2(v2, v3));
       }
     }
     __syncthreads();
+    if constexpr (STATS) {
+      if (tid < 2 * 64) {
+        const int which = tid >> 6, cl = tid & 63;
+        bn_part1[((int64_t)(wg + it * groups) * 2 + which) * 64 + cl] =
+            (red[(0 * 2 + which) * 64 + cl] + red[(1 * 2 + which) * 64 + cl]) + (red[(2 * 2 + which) * 64 + cl] + red[(3 * 2 + which) * 64 + cl]);
+      }
+    }
     {
       u32x2 trlo[NIT2], trhi[NIT2];
       const int sq = lane & 3, sj = (lane >> 2) & 3;
@@ -262,12 +284,12 @@ __global__ __launch_bounds__(512, 1) void c3_c1_kernel(const unsigned short* __r
 extern "C" {
 
 /* see include/creid.h */
-int creid_bottleneck_c3_c1_fwd_affine(int64_t M, int64_t c_mid, int64_t c_out, int64_t c_next, const void* a2, const void* w3_krsc,
-                                      const float* fold3, const void* residual, void* out3, const void* w1_krsc, const float* fold1,
-                                      void* out1, int dtype, void* stream) {
-  CREID_CHECK_ARG(a2 && w3_krsc && fold3 && residual && out3 && w1_krsc && fold1 && out1 && M > 0);
+static int launch_pair(int64_t M, int64_t c_mid, int64_t c_out, int64_t c_next, const void* a2, const void* w3_krsc, const float* fold3,
+                       const void* residual, void* out3, const void* w1_krsc, const float* fold1, void* out1, float* bn_part1,
+                       int dtype, hipStream_t s) {
   if (!creid_is16(dtype)) return CREID_E_DTYPE;
   if (c_mid != 64 || c_out != 256 || c_next != 64 || M >= ((int64_t)1 << 31) - 128) return CREID_E_SHAPE;
+  if (bn_part1 && M % 128 != 0) return CREID_E_SHAPE;
   const int tiles_m = (int)((M + 127) / 128);
   int wgs = 256;
   { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
@@ -278,16 +300,29 @@ int creid_bottleneck_c3_c1_fwd_affine(int64_t M, int64_t c_mid, int64_t c_out, i
 #else
   const int abl = 0;
 #endif
-  hipStream_t s = as_stream(stream);
-  if (dtype == CREID_F16)
-    hipLaunchKernelGGL(creid_pair::c3_c1_kernel<F16T>, dim3((unsigned)wgs), dim3(512), 0, s, (const unsigned short*)a2,
-                       (const unsigned short*)w3_krsc, (const unsigned short*)residual, fold3, (unsigned short*)out3,
-                       (const unsigned short*)w1_krsc, fold1, (unsigned short*)out1, (int)M, tiles_m, abl);
-  else
-    hipLaunchKernelGGL(creid_pair::c3_c1_kernel<Bf16T>, dim3((unsigned)wgs), dim3(512), 0, s, (const unsigned short*)a2,
-                       (const unsigned short*)w3_krsc, (const unsigned short*)residual, fold3, (unsigned short*)out3,
-                       (const unsigned short*)w1_krsc, fold1, (unsigned short*)out1, (int)M, tiles_m, abl);
-  CREID_LAUNCH_RET();
+#define CREID_PAIR_LAUNCH(ET_, ST_)                                                                                             \
+  hipLaunchKernelGGL((creid_pair::c3_c1_kernel<ET_, ST_>), dim3((unsigned)wgs), dim3(512), 0, s, (const unsigned short*)a2,     \
+                     (const unsigned short*)w3_krsc, (const unsigned short*)residual, fold3, (unsigned short*)out3,             \
+                     (const unsigned short*)w1_krsc, fold1, (unsigned short*)out1, bn_part1, (int)M, tiles_m, abl)
+  if (bn_part1) { if (dtype == CREID_F16) CREID_PAIR_LAUNCH(F16T, true); else CREID_PAIR_LAUNCH(Bf16T, true); }
+  else { if (dtype == CREID_F16) CREID_PAIR_LAUNCH(F16T, false); else CREID_PAIR_LAUNCH(Bf16T, false); }
+#undef CREID_PAIR_LAUNCH
+  return (int)hipGetLastError();
+}
+
+int creid_bottleneck_c3_c1_fwd_affine(int64_t M, int64_t c_mid, int64_t c_out, int64_t c_next, const void* a2, const void* w3_krsc,
+                                      const float* fold3, const void* residual, void* out3, const void* w1_krsc, const float* fold1,
+                                      void* out1, int dtype, void* stream) {
+  CREID_CHECK_ARG(a2 && w3_krsc && fold3 && residual && out3 && w1_krsc && fold1 && out1 && M > 0);
+  return launch_pair(M, c_mid, c_out, c_next, a2, w3_krsc, fold3, residual, out3, w1_krsc, fold1, out1, nullptr, dtype, as_stream(stream));
+}
+
+int creid_bottleneck_c3_c1_fwd_stats(int64_t M, int64_t c_mid, int64_t c_out, int64_t c_next, const void* a2, const void* w3_krsc,
+                                     const float* fold3, const void* residual, void* out3, const void* w1_krsc, void* out1_raw,
+                                     float* bn_partial1, int dtype, void* stream) {
+  CREID_CHECK_ARG(a2 && w3_krsc && fold3 && residual && out3 && w1_krsc && out1_raw && bn_partial1 && M > 0);
+  return launch_pair(M, c_mid, c_out, c_next, a2, w3_krsc, fold3, residual, out3, w1_krsc, nullptr, out1_raw, bn_partial1, dtype,
+                     as_stream(stream));
 }
 
 }  // extern "C"

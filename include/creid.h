@@ -442,6 +442,12 @@ int creid_stem_conv_pool_fwd_affine(int64_t batch, int64_t H, int64_t W, const v
 int creid_bottleneck_c3_c1_fwd_affine(int64_t M, int64_t c_mid, int64_t c_out, int64_t c_next, const void* a2, const void* w3_krsc,
                                       const float* fold3, const void* residual, void* out3, const void* w1_krsc,
                                       const float* fold1, void* out1, int dtype, void* stream);
+/* The same launch when the next block's conv1 feeds an IBN layer (resnet_ibn_a.py:27-32): out1_raw [M, c_next] is the raw
+ * convolution output and bn_partial1 float[M / 128][2][c_next] its per-128-row (sum, sum of squares) -- what creid_conv2d_fwd_nhwc
+ * hands to creid_ibn_fwd (rows of a tile belong to one image when H * W % 128 = 0); M % 128 = 0 required. */
+int creid_bottleneck_c3_c1_fwd_stats(int64_t M, int64_t c_mid, int64_t c_out, int64_t c_next, const void* a2, const void* w3_krsc,
+                                     const float* fold3, const void* residual, void* out3, const void* w1_krsc, void* out1_raw,
+                                     float* bn_partial1, int dtype, void* stream);
 size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype);
 int creid_stem_conv_wgrad(int64_t batch, int64_t H, int64_t W, const void* xpad, const void* dy,
                           float* dw_oihw, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -248,3 +248,34 @@ def test_block_boundary_one_launch_equals_two_launches(B, H, W, wgs, dtype, monk
     assert torch.equal(out1.view(torch.int16), ref1.view(torch.int16)), f"conv1 output: {(out1 != ref1).sum().item()} of {ref1.numel()} differ"
     assert lib.creid_bottleneck_c3_c1_fwd_affine(M, 128, 512, 128, L.ptr(a2), L.ptr(k3), L.ptr(ss3), L.ptr(res), L.ptr(out3),
                                                  L.ptr(k1), L.ptr(ss1), L.ptr(out1), L.dtype_code(a2), L.stream()) == -4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_block_boundary_statistics_variant(dtype):
+    """creid_bottleneck_c3_c1_fwd_stats (the next block's conv1 feeds an IBN layer): the block output and the RAW conv1 output are
+    bit-identical to creid_conv2d_fwd_affine_nhwc + creid_conv2d_fwd_nhwc, the per-tile statistics partials equal up to the
+    grouping of the fp32 column sums; row counts that are no multiple of 128 are refused."""
+    from centroids_reid_amd import _lib as L
+    from centroids_reid_amd import layers as ly
+    lib = L.lib()
+    B, H, W = 6, 16, 16
+    rng = np.random.default_rng(17)
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()
+    a2 = t(rng.standard_normal((B, H, W, 64))).to(dtype)
+    res = t(rng.standard_normal((B, H, W, 256))).to(dtype)
+    k3, _ = ly.weight_prep(t(rng.standard_normal((256, 64, 1, 1)) / 8.0), dtype)
+    k1, _ = ly.weight_prep(t(rng.standard_normal((64, 256, 1, 1)) / 16.0), dtype)
+    ss3 = t(np.stack([rng.uniform(0.5, 1.5, 256), rng.standard_normal(256) * 0.3]))
+    ref3 = ly.conv2d_fwd_affine(a2, k3, 1, 0, ss3, res, True)
+    ref1, refp = ly.conv2d_fwd(ref3, k1, 1, 0, with_stats=True)
+    M = B * H * W
+    out3 = torch.full_like(ref3, float("nan")); out1 = torch.full_like(ref1, float("nan"))
+    part = torch.full((M // 128, 2, 64), float("nan"), device="cuda")
+    L.check(lib.creid_bottleneck_c3_c1_fwd_stats(M, 64, 256, 64, L.ptr(a2), L.ptr(k3), L.ptr(ss3), L.ptr(res), L.ptr(out3), L.ptr(k1),
+                                                 L.ptr(out1), L.ptr(part), L.dtype_code(a2), L.stream()), "pair_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(out3.view(torch.int16), ref3.view(torch.int16))
+    assert torch.equal(out1.view(torch.int16), ref1.view(torch.int16))
+    np.testing.assert_allclose(part.cpu().numpy().reshape(-1), refp.cpu().numpy().reshape(-1), rtol=2e-6, atol=1e-5)
+    assert lib.creid_bottleneck_c3_c1_fwd_stats(M - 64, 64, 256, 64, L.ptr(a2), L.ptr(k3), L.ptr(ss3), L.ptr(res), L.ptr(out3), L.ptr(k1),
+                                                L.ptr(out1), L.ptr(part), L.dtype_code(a2), L.stream()) == -4
