@@ -101,7 +101,7 @@ def forward_flops(B, H, W, arch="resnet50"):
     return fl
 
 
-_GROUPS = [("igemm", r"igemm|conv3x3_c64|stem_pool"), ("wgrad", r"wgrad_bf16|wgrad_f32|wgrad_reduce"), ("bn", r"bn2d_|ibn_|bn_apply|bn_bwd|bn_fold|col_stats"),
+_GROUPS = [("igemm", r"igemm|conv3x3_c64|stem_pool|c3_c1_kernel"), ("wgrad", r"wgrad_bf16|wgrad_f32|wgrad_reduce"), ("bn", r"bn2d_|ibn_|bn_apply|bn_bwd|bn_fold|col_stats"),
            ("heads", r"triplet|center_|xent|bn1d|loo_|gemm_f32|ctl_step|scale_matrix"), ("optim", r"adam|sgd_scaled"),
            ("pool_layout", r"maxpool|gap_|weight_prep|image_pad|nhwc")]
 
@@ -228,7 +228,7 @@ def run_embed(arch="resnet50", B=128, H=256, W=128, steps=20, warmup=3, insitu=N
            "dtype": "f16" if dtype == torch.float16 else "bf16", "hip_graph": True,
            "config": {"workload": label or f"{arch} {H}x{W} eval-mode embedding forward (validation_step: backbone + GAP + BNNeck), "
                                            f"batch {B}, BatchNorm folded into the conv epilogues", "batch": B},
-           "roofline": {"kernel": "convolution kernels of the forward (53 launches: igemm_bf16_{ws,dma,pp}, igemm1x1_stream2, conv3x3_c64, stem_pool; folded BN epilogue)", "bound": "mfma",
+           "roofline": {"kernel": "convolution kernels of the forward (53 convolutions in 51 launches: igemm_bf16_{ws,dma,pp}, igemm1x1_stream2, conv3x3_c64, stem_pool, c3_c1; folded BN epilogue)", "bound": "mfma",
                         "achieved": fl / dt / 1e12, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / dt / 1e12 / MFMA_BF16_TFLOPS,
                         "source": "whole forward (wall time of the replayed graph, all kernels)", "traffic": None}}
     if insitu and "embed" in insitu and "igemm" in insitu["embed"]:

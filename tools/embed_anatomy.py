@@ -32,10 +32,11 @@ def main(path, B=128, H=256, W=128):
             # downsample entry follows the first block of a layer
             ds = shapes[i]; i += 1
         order += [("c1", blk[0]), ("c2", blk[1])] + ([("ds", ds)] if ds else []) + [("c3", blk[2])]
-    is_conv = lambda n: "igemm" in n or "conv3x3_c64" in n or "stem_pool" in n      # every kernel that runs a convolution
+    is_conv = lambda n: "igemm" in n or "conv3x3_c64" in n or "stem_pool" in n or "c3_c1_kernel" in n   # kernels that run convolutions
     convs = [r for r in seg if is_conv(r[0])]
+    n_pair = sum(1 for r in convs if "c3_c1_kernel" in r[0])
     print(f"one embedding forward: {len(seg)} kernels, {sum(e - s for _, s, e in seg) / 1e3:.0f} us summed, span {(seg[-1][2] - seg[0][1]) / 1e3:.0f} us; "
-          f"{len(convs)} convolution launches (expected {len(order) + 1})")
+          f"{len(convs)} convolution launches running {len(convs) + n_pair} convolutions (expected {len(order) + 1})")
     print("| # | role | shape | kernel | us | TF/s | GB/s (algorithmic) |\n|---|---|---|---|---:|---:|---:|")
     tot_fl = tot_t = 0.0
     ci = 0
@@ -49,6 +50,13 @@ def main(path, B=128, H=256, W=128):
                 if "stem_pool" in n:                  # one launch with the max-pool: only the pooled tensor is written
                     by = B * (H + 8) * (W + 6) * 4 * 2 + B * (H // 4) * (W // 4) * 64 * 2
                 role, label = "stem" + (" + pool" if "stem_pool" in n else ""), f"3->64 k7 s2 {H}x{W}"
+            elif "c3_c1_kernel" in n:
+                # conv3 of this block and conv1 of the next in one launch (conv_pair.hip): two entries of the layer order
+                (_, (cin, cout, k, st, h, w)), (_, (cin2, cout2, _, _, _, _)) = order[ci - 1], order[ci]
+                fl = 2.0 * B * h * w * (cout * cin + cout2 * cin2)
+                by = B * h * w * (cin + 2 * cout + cout2) * 2
+                role, label = "c3 + next c1", f"{cin}->{cout}->{cout2} k1 s1 {h}x{w}"
+                ci += 1
             else:
                 role, (cin, cout, k, st, h, w) = order[ci - 1]
                 ho, wo = (h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1

@@ -4,7 +4,7 @@ import re
 import sqlite3
 import sys
 
-GROUPS = [("conv fwd + dgrad (igemm)", r"igemm_|conv3x3_c64|stem_pool"), ("conv wgrad", r"wgrad_bf16|wgrad_f32"), ("wgrad split reduce", r"wgrad_reduce"),
+GROUPS = [("conv fwd + dgrad (igemm)", r"igemm_|conv3x3_c64|stem_pool|c3_c1_kernel"), ("conv wgrad", r"wgrad_bf16|wgrad_f32"), ("wgrad split reduce", r"wgrad_reduce"),
           ("BN backward apply", r"bn2d_bwd_apply|ibn_bwd_apply"), ("BN apply", r"bn2d_apply|ibn_apply"),
           ("BN finalize (fwd+bwd)", r"finalize"), ("BN reduce (unfused)", r"bwd_reduce|col_stats"),
           ("optimisers", r"adam|sgd_scaled"), ("pool / gap", r"maxpool|gap_"), ("layout", r"weight_prep|image_pad|nhwc"),
