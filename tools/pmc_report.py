@@ -11,10 +11,16 @@ F, W, S, D = (json.load(open(os.path.join(G, f"pmc_{n}.json"))) for n in ("fetch
 NSIMD = 256 * 4
 
 
+# every kernel that runs a forward / data-gradient convolution (round 4 added the last three; the family figures of the first
+# round-4 report missed them)
+IGEMM = ("igemm_bf16_", "creid_pp::igemm_bf16_pp", "igemm1x1_stream", "conv3x3_c64")
+
+
 def fam(db, prefix, counter):
+    prefixes = IGEMM if prefix == "igemm_bf16_" else (prefix,)
     tot = n = 0
     for k, v in db.items():
-        if k.startswith(prefix) and counter in v:
+        if k.startswith(prefixes) and counter in v:
             tot += v[counter]["sum"]; n += v[counter]["dispatches"]
     return tot, n
 
@@ -86,6 +92,21 @@ for k in sorted(S):
 for fam_name, prefix in (("igemm family (conv fwd + dgrad, whole layer mix)", "igemm_bf16_"), ("wgrad family", "wgrad_bf16_")):
     mf, _ = fam(S, prefix, "SQ_VALU_MFMA_BUSY_CYCLES"); ga, n = fam(S, prefix, "GRBM_GUI_ACTIVE")
     lines.append(f"| **{fam_name}** | {n} | **{100 * mf / (ga / 8 * NSIMD):.1f}** | | | |")
+ES_path, ED_path = os.path.join(G, "pmc_embed_sq.json"), os.path.join(G, "pmc_embed_derived.json")
+if os.path.exists(ES_path):
+    ES = json.load(open(ES_path)); ED = json.load(open(ED_path)) if os.path.exists(ED_path) else {}
+    lines += ["", "## Eval-mode embedding forward, ResNet50 256 x 128, batch 128 (tools/pmc_embed.py: three forwards, every kernel of the forward)", "",
+              "| kernel | dispatches | MFMA busy % | MfmaUtil % | VALUBusy % | LDS bank-conflict cycles / SQ busy cycles |", "|---|---:|---:|---:|---:|---:|"]
+    for k in sorted(ES):
+        if k.startswith("_") or "at::" in k or "rocclr" in k or "GRBM_GUI_ACTIVE" not in ES[k]:
+            continue
+        v = ES[k]
+        busy = 100 * v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (v["GRBM_GUI_ACTIVE"]["sum"] / 8 * NSIMD)
+        d = ED.get(k, {})
+        mu = d.get("MfmaUtil", {}).get("sum", 0) / max(1, d.get("MfmaUtil", {}).get("dispatches", 1))
+        vb = d.get("VALUBusy", {}).get("sum", 0) / max(1, d.get("VALUBusy", {}).get("dispatches", 1))
+        bc = v["SQ_LDS_BANK_CONFLICT"]["sum"] / max(1.0, v["SQ_BUSY_CYCLES"]["sum"])
+        lines.append(f"| {k} | {v['GRBM_GUI_ACTIVE']['dispatches']} | {busy:.1f} | {mu:.1f} | {vb:.1f} | {bc:.2f} |")
 lines += ["", f"HBM-side traffic and the FETCH_SIZE calibration: profiles/{RND}_pmc_traffic.json.", ""]
 open(os.path.join(ROOT, "profiles", f"{RND}_pmc_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines[:4])); print(open(os.path.join(ROOT, "profiles", f"{RND}_pmc_summary.md")).read()[-2500:])
