@@ -18,6 +18,11 @@ namespace creid_pair {
 // STATS (the next block's conv1 feeds an IBN layer, resnet_ibn_a.py:27-32): out1 is the RAW convolution output and bn_part1 gets
 // the per-tile (sum, sum of squares) of the fp32 accumulators, [tiles][2][64] -- creid_conv2d_fwd_nhwc's statistics partials
 // (rows of a tile belong to one image when H * W % 128 = 0; M % 128 = 0 required: no padded rows in the sums).
+// 16-byte chunk swizzle of the second operand image: conflict-free for the 16-byte WRITES of the copy-out lanes (eight contiguous
+// lanes = four consecutive rows x two adjacent chunks, banks mod 128 bytes) as well as for the fragment reads (ds_read_b128's lane
+// groups over 32 consecutive rows, banks mod 256 bytes); the (r >> 1) & 7 swizzle of the DMA-written images serves only the reads
+__device__ __forceinline__ int a2_key(int r) { return (((r & 3) << 1) ^ ((r >> 2) & 3)) & 7; }
+
 template <typename ET, bool STATS>
 __global__ __launch_bounds__(512, 1) void c3_c1_kernel(const unsigned short* __restrict__ src,      // [M][64]   conv2's output
                                                        const unsigned short* __restrict__ w3,       // [256][64]
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(512, 1) void c3_c1_kernel(const unsigned short* __r
         // the same chunk as an operand of the second multiply: row rl, channels h * 128 + ch * 8 ..
         int rl, ch;
         unit_of(i, CPR, rl, ch);
-        *reinterpret_cast<uint4*>(A2 + (ch >> 3) * TILE_ELEMS + rl * 64 + (((ch & 7) ^ ((rl >> 1) & 7)) << 3)) = v;
+        *reinterpret_cast<uint4*>(A2 + (ch >> 3) * TILE_ELEMS + rl * 64 + (((ch & 7) ^ a2_key(rl)) << 3)) = v;
       }
       __syncthreads();                                            // this half of the block output is an operand
       if (!CREID_ABL_ON(abl, 8)) {
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void c3_c1_kernel(const unsigned short* __r
           for (int kk = 0; kk < 4; ++kk) {
             const int chk = 2 * kk + kh;
             const int r = wr * 32 + l31, cc = wc * 32 + l31;
-            const s16x8 a = *reinterpret_cast<const s16x8*>(&A2[kc * TILE_ELEMS + r * 64 + ((chk ^ ((r >> 1) & 7)) << 3)]);
+            const s16x8 a = *reinterpret_cast<const s16x8*>(&A2[kc * TILE_ELEMS + r * 64 + ((chk ^ a2_key(r)) << 3)]);
             const s16x8 b = *reinterpret_cast<const s16x8*>(&Ws1[((2 * h + kc) * 64 + cc) * 64 + ((chk ^ ((cc >> 1) & 7)) << 3)]);
             acc2 = ET::mfma(a, b, acc2);
           }

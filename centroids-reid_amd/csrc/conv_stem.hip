@@ -245,10 +245,17 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void stem_pool_kernel(const unsign
     // or left of it is replaced by its neighbour inside the window (a duplicate does not change a maximum), all nine reads are
     // requested before the first comparison.
     const int p_first = r_first >> 1;
+    // lane -> (pixel of a group of four, 16-byte channel chunk): ds_read_b128 is serviced in four NON-contiguous 16-lane groups
+    // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32); with this map every group reads all eight chunks of two ADJACENT pool
+    // pixels, whose taps lie in different halves of the 256-byte bank row -- the plain map (chunk = lane & 7, pixel = lane >> 3)
+    // put pixels p and p + 2 (same half, complementary chunk halves XOR-ed onto each other by the column swizzle) into one group
+    const int l5 = lane & 31;
+    const int dpx = l5 < 4 ? 0 : l5 < 12 ? 2 : l5 < 16 ? 0 : l5 < 20 ? 3 : l5 < 28 ? 1 : 3;
+    const int c_lane = l5 < 4 ? l5 : l5 < 12 ? l5 - 4 : l5 < 16 ? l5 - 8 : l5 < 20 ? l5 - 16 : l5 < 28 ? l5 - 20 : l5 - 24;
     if constexpr (PR == 2) {
       // two vertically adjacent pool rows per item: five ring rows x three columns, the middle row's maximum serves both
       for (int item = tid; item < (RS / 4) * HALF * 8; item += NT) {
-        const int c = item & 7, pxl = (item >> 3) % HALF, pp = (item >> 3) / HALF;
+        const int pq = (item >> 5) * 4 + dpx, c = c_lane, pxl = pq % HALF, pp = pq / HALF;
         const int py = p_first + 2 * pp;
         uint4 tap[15];
 #pragma unroll
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void stem_pool_kernel(const unsign
       }
     } else {
       for (int item = tid; item < (RS / 2) * HALF * 8; item += NT) {
-        const int c = item & 7, pxl = (item >> 3) % HALF, pyl = (item >> 3) / HALF;
+        const int pq = (item >> 5) * 4 + dpx, c = c_lane, pxl = pq % HALF, pyl = pq / HALF;
         const int py = p_first + pyl;
         uint4 tap[9];
 #pragma unroll
