@@ -184,6 +184,13 @@ def run_eval(args, rank, world, steps=None, warmup=None, shape=None, extras=True
     _so, sys.stdout = sys.stdout, _quiet                   # R1_mAP.compute mirrors the reference's banner print per call
     try:
         dt_m, out_m = timed(step_materialised)
+        # the FIRST streamed evaluation of a label-set shape in a process reads the index statistics back mid-pipeline (8 bytes,
+        # one extra host synchronisation); calls 2..N speculate on that capacity (reid_metric._CAP_HINT) and verify it in the
+        # final read-back.  The timed steps below are all "call >= 2": the first call is timed separately, kernels warm.
+        step_streamed(); rm._CAP_HINT.clear()
+        barrier_sync(world)
+        t0 = time.perf_counter(); step_streamed(); barrier_sync(world)
+        first_call_ms = (time.perf_counter() - t0) * 1e3
         dt, out = timed(step_streamed)
     finally:
         sys.stdout = _so
@@ -253,7 +260,11 @@ def run_eval(args, rank, world, steps=None, warmup=None, shape=None, extras=True
                              "rank_index_agreement": float((idx16 == idx).float().mean().item())}
         res["stages_ms"] = {"l2norm": t_norm, "plan_device_build_wall": t_plan, "poslist": t_pos, "sqdist_count": t_count}
         res["timed_region"] = ("R1_mAP(streamed=True).compute(device feats, host pids, host camids) -> host (cmc, mAP, topk): "
-                               "index build and every host sync inside the clock")
+                               "index build and every host sync inside the clock.  The timed steps are evaluations 2..N of one "
+                               "label-set shape: they ASSUME the positive-list capacity of the previous call (verified in the final "
+                               "read-back, redone synchronously if wrong) instead of reading 8 bytes back mid-pipeline; "
+                               "first_call_ms = the same call without that hint (the first validation of a run)")
+        res["first_call_ms"] = first_call_ms
         # BASELINE target line "HBM roofline on the distance matrix": the materialised fp32 matrix moves
         # (m + n) * D * 4 + m * n * 4 algorithmic bytes; the contraction is MFMA-bound (2 D FLOP per 4 output bytes), so this
         # fraction is capped at flops_floor / hbm_floor -- reported because the target is phrased in it
@@ -279,6 +290,63 @@ def run_eval(args, rank, world, steps=None, warmup=None, shape=None, extras=True
                    "queries_per_rank": nq, "gallery": ng, "D": D,
                    "parallelism": f"query-shard x{world}, gallery all-gather" if world > 1 else "single"},
         **res}
+
+
+def run_eval_configs3_shard(steps=2, warmup=1):
+    """BASELINE configs[3], retrieval half: the per-rank shard of the 50k x 200k Street2Shop-shaped evaluation -- 6250 queries
+    (50 000 / 8 ranks) x the all-gathered 200 000-row gallery x 2048 fp32 -- streamed END TO END (the 5 GB distance matrix and
+    the 10 GB index matrix are never written; utils/reid_metric.py:93-110 is the reference's batched fallback for this size).
+    Same timed region as run_eval; roofline of the counting contraction against the f32 MFMA peak."""
+    from centroids_reid_amd import reid_metric as rm
+    nq, ng, D, npid = 6250, 200_000, 2048, 50_000
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    feats = torch.randn((nq + ng, D), generator=gen, device="cuda", dtype=torch.float32)
+    rng = np.random.default_rng(4)
+    pids = np.concatenate([rng.integers(0, npid, nq), np.arange(ng) % npid])       # every query has 4 gallery matches
+    cams = np.concatenate([np.zeros(nq, np.int64), np.ones(ng, np.int64)])          # datasets/bases.py:226-229
+    metric = rm.R1_mAP(num_query=nq, streamed=True)
+    _quiet = open(os.devnull, "w")
+    _so, sys.stdout = sys.stdout, _quiet
+    try:
+        for _ in range(warmup):
+            metric.compute(feats, pids, cams)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cmc, m_ap, topk = metric.compute(feats, pids, cams)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        sys.stdout = _so
+        _quiet.close()
+    plan = metric.last["plan"]
+    fn, sq = rm.l2_normalize(feats, return_sqnorm=True)
+    q, g = fn[:nq], fn[nq:]
+    qq, gg = sq[:nq].contiguous(), sq[nq:].contiguous()
+    L = rm.L
+    lib = L.lib()
+    cap = plan.cap
+    pos_key = torch.empty((nq, cap), dtype=torch.int32, device="cuda"); pos_idx = torch.empty_like(pos_key)
+    npos = torch.empty(nq, dtype=torch.int32, device="cuda"); hist = torch.zeros((nq, cap), dtype=torch.int32, device="cuda")
+    L.check(lib.creid_stream_poslist(L.ptr(q), L.ptr(g), L.ptr(qq), L.ptr(gg), nq, ng, D, L.ptr(plan.q_slot), L.ptr(plan.csr_off),
+                                     L.ptr(plan.g_order), L.ptr(plan.q_cams), L.ptr(plan.g_cams), cap, L.ptr(pos_key),
+                                     L.ptr(pos_idx), L.ptr(npos), L.stream()), "poslist")
+
+    def count():
+        L.check(lib.creid_stream_count(L.ptr(q), L.ptr(g), L.ptr(qq), L.ptr(gg), nq, ng, D, L.ptr(plan.q_pids), L.ptr(plan.g_pids),
+                                       cap, L.ptr(pos_key), L.ptr(pos_idx), L.ptr(npos), L.ptr(hist), L.stream()), "count")
+    t_count = time_kernel(count, 2)
+    flops = 2.0 * nq * ng * D
+    return {"metric": "eval_dist_pairs_per_sec", "value": float(nq) * ng * steps / dt, "unit": "pairs/s",
+            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32", "mAP": float(m_ap),
+            "config": {"workload": "per-rank shard of BASELINE configs[3] retrieval: 6250 queries (50 000 / 8 ranks) x 200 000 gallery "
+                                   "x 2048, normalise + squared-L2 + rank + CMC/mAP end to end, streamed (no 5 GB matrix)",
+                       "queries_per_rank": nq, "gallery": ng, "D": D, "positive_list_capacity": int(cap)},
+            "roofline": {"kernel": "sqdist_count_f32_kernel", "bound": "mfma", "achieved": flops / (t_count * 1e-3) / 1e12,
+                         "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": flops / (t_count * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
+                         "ms": t_count, "traffic": None,
+                         "algorithmic_bytes": (nq + ng) * D * 4, "note": "4096 FLOP per pair; operands 1.69 GB, read once by HBM and "
+                         "re-read from L2 / Infinity Cache while MFMA-bound"}}
 
 
 def cpu_baseline_eval(feats, pids, cams, nq, ng):
@@ -326,7 +394,10 @@ def cpu_baseline_train(P, K, H, W):
         step(P)
     dt = time.perf_counter() - t0
     return {"value": nsteps * P * K / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{nsteps} steps of {P * K} images (fwd + bwd, no optimiser) after 1 warm-up step, torch-CPU oracle",
+            "sample": f"{nsteps} steps of {P * K} images (fwd + bwd, no optimiser) after 1 warm-up step, torch-CPU oracle; "
+                      f"{cores} of {os.cpu_count()} host threads: torch-CPU (oneDNN) convolutions of a 64-image batch stop scaling past "
+                      "one socket's worth of cores and get SLOWER when oversubscribed across all of them, so 32 is the fastest setting "
+                      "for this baseline (the eval leg, a pure GEMM + sort, uses every core)",
             "seconds": dt}
 
 
@@ -350,7 +421,8 @@ def cpu_baseline_embed(B=64, H=256, W=128, reps=3):
         fwd()
     dt = time.perf_counter() - t0
     return {"value": reps * B / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} eval-mode forwards of {B} images after 1 warm-up, torch-CPU oracle", "seconds": dt}
+            "sample": f"{reps} eval-mode forwards of {B} images after 1 warm-up, torch-CPU oracle ({cores} of {os.cpu_count()} host "
+                      "threads, the fastest setting: see the training leg's note)", "seconds": dt}
 
 
 # ----------------------------------------------------------------------------- main
@@ -401,10 +473,13 @@ def main():
             # the same invocation: 5 steps after 2 warm-up of the configs[4] workload
             ev = run_eval(args, rank, world, steps=5, warmup=2)
             ns = run_eval(args, rank, world, steps=5, warmup=2, shape=(3000, 15000, 2048), extras=False) if world == 1 else None
+            c3 = run_eval_configs3_shard() if (world == 1 and os.environ.get("CREID_BENCH_NO_CONFIGS3", "0") != "1") else None
             if rank == 0:
                 ev["higher_is_better"] = True
                 if ns is not None:
                     ev["north_star_3000x15000"] = ns
+                if c3 is not None:
+                    ev["configs3_shard"] = c3
                 out["eval"] = ev
     else:
         args.steps = args.steps or 5

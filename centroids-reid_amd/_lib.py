@@ -45,6 +45,7 @@ SIGNATURES = {
     "creid_loo_emb_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "creid_ctl_step_stats": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p]),
     "creid_loo_emb_fwd_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "creid_loo_emb_fwd_rows_lonely": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_triplet_fwd_batched_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _f32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "creid_ctl_round_scale": (C.c_int, [_p, _i64, _p, _p]),
     "creid_ctl_step_stats_rows": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p]),

@@ -189,6 +189,22 @@ def resnet50_ibn_a(last_stride, **kwargs):
     return ResNet_IBN(last_stride, LAYERS, **kwargs)
 
 
+# the deeper Bottleneck variants of MODEL.NAME (modelling/baseline.py:73-81, resnet_ibn_a.py:173-181): same kernels, same
+# engine, other block counts (the engine walks whatever blocks the parameter tree holds)
+ARCH_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3),
+               "resnet50_ibn_a": (3, 4, 6, 3), "resnet101_ibn_a": (3, 4, 23, 3)}
+
+
+def build_backbone(arch, last_stride):
+    if arch not in ARCH_LAYERS:
+        raise NotImplementedError(f"MODEL.NAME={arch!r}: the accelerated path covers the Bottleneck ResNets {sorted(ARCH_LAYERS)} "
+                                  "(resnet18 / resnet34 are BasicBlock networks: no kernels for them here)")
+    layers = ARCH_LAYERS[arch]
+    net = ResNet_IBN(last_stride, layers) if arch.endswith("_ibn_a") else ResNet(last_stride, layers=layers)
+    net.arch = arch
+    return net
+
+
 # ----------------------------------------------------------------------------- engine
 def _desc(B, H, W, cin, cout, k, stride, pad):
     oh = (H + 2 * pad - k) // stride + 1
@@ -280,8 +296,11 @@ class BackboneEngine:
         self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
         # eval-mode forward: BatchNorm (running statistics = constants) folded into the producing convolution's epilogue --
         # one launch per conv instead of conv -> finalize -> apply (CREID_EVAL_FOLD=0: the three-launch schedule)
-        # (the folded epilogue of the 16-bit types lives in the LDS-DMA kernels only: with CREID_IGEMM_DMA=0 those forwards take
-        # the three-launch schedule instead of failing)
+        # (the folded epilogue of the 16-bit types lives in the LDS-DMA kernels only: with CREID_IGEMM_DMA=0 a bf16 forward takes
+        # the three-launch schedule instead of failing; float16 has no register-staged kernels at all)
+        if dtype == torch.float16 and os.environ.get("CREID_IGEMM_DMA", "1") != "1":
+            raise L.CreidError("compute dtype float16 needs the LDS-DMA convolution kernels: unset CREID_IGEMM_DMA=0 "
+                               "(the register-staged fallback kernels exist for bfloat16 and float32 only)")
         self.eval_fold = os.environ.get("CREID_EVAL_FOLD", "1") == "1" and \
             (dtype == torch.float32 or os.environ.get("CREID_IGEMM_DMA", "1") == "1")
         self._fold_key = None

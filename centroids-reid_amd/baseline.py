@@ -20,18 +20,19 @@ class Baseline(nn.Module):
         last_stride = cfg.MODEL.LAST_STRIDE
         model_name = cfg.MODEL.NAME
         self.use_mixed_precision = cfg.USE_MIXED_PRECISION
-        if model_name == "resnet50":
-            self.base = bb.ResNet(last_stride=last_stride)
-        elif model_name == "resnet50_ibn_a":
-            self.base = bb.resnet50_ibn_a(last_stride)
-        else:
-            raise NotImplementedError(f"MODEL.NAME={model_name!r}: only resnet50 / resnet50_ibn_a are on the accelerated path")
+        # modelling/baseline.py:56-81: resnet50 / 101 / 152 and resnet50_ibn_a / resnet101_ibn_a (Bottleneck networks, in_planes
+        # 2048); resnet18 / resnet34 (BasicBlock, in_planes 512) raise NotImplementedError
+        self.base = bb.build_backbone(model_name, last_stride)
         self.model_name = model_name
         if cfg.MODEL.PRETRAINED and not cfg.MODEL.RESUME_TRAINING and not cfg.TEST.ONLY_TEST:
             self.base.load_param(cfg.MODEL.PRETRAIN_PATH)      # modelling/baseline.py:84-87
             print("Loading pretrained ImageNet model......")
         self.compute_dtype = compute_dtype or (torch.bfloat16 if cfg.USE_MIXED_PRECISION else torch.float32)
-        self.return_base_out = False      # base_out (NCHW fp32 copy) is materialised only on request
+        # base_out = the reference's NCHW fp32 feature map (modelling/baseline.py:91-96).  A stand-alone Baseline returns it like the
+        # reference does; ModelBase / CTLModel, which never consume it (`_, features = self.backbone(x)`, modelling/bases.py:171,
+        # train_ctl_model.py:44), switch it off and save the 67 MB layout pass per batch.  It is a detached copy: gradients flow
+        # through global_feat only.
+        self.return_base_out = True
         self._engine = None
 
     @property

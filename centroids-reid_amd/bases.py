@@ -100,6 +100,7 @@ class ModelBase(_Base):
             self.test_dataloader = test_dataloader
 
         self.backbone = Baseline(self.hparams, compute_dtype=compute_dtype)
+        self.backbone.return_base_out = False            # this module only reads global_feat (modelling/bases.py:171)
         self.contrastive_loss = TripletLoss(self.hparams.SOLVER.MARGIN, self.hparams.SOLVER.DISTANCE_FUNC)
         d_model = self.hparams.MODEL.BACKBONE_EMB_SIZE
         self.xent = CrossEntropyLabelSmooth(num_classes=self.hparams.num_classes)

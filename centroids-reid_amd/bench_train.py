@@ -396,6 +396,42 @@ def map_delta_bf16(n_id=96, n_query=2, n_gallery=6, H=256, W=128, noise=0.6, see
             "images": int(len(x)), "identities": n_id, "noise": noise}
 
 
+def train_curve_delta(P=16, K=4, H=256, W=128, steps=50, n_id=64, noise=0.6):
+    """bf16 throughput mode against the exact-f32 parity mode as a TRAINING TRAJECTORY: the same randomly initialised model (same
+    seed), the same `steps` PK batches of clustered synthetic identities (image = smooth per-identity pattern + N(0, noise)
+    pixels; 64 identities, every one revisited each 4 steps), the full step (four losses, backward, Adam + center SGD) -- loss
+    per step in both modes.  Reported: the largest and the mean relative loss gap over the trajectory and both end points
+    (`final_loss` of two runs of different length is not a comparison)."""
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    base = torch.randn((n_id, 3, H // 16, W // 16), generator=gen, device="cuda")
+    base = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
+    camid = torch.zeros(P * K, dtype=torch.int64)
+    is_real = torch.ones(P * K, dtype=torch.bool)
+    curves = {}
+    for dt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(0)                                        # identical initial weights in both modes
+        model = make_model(num_classes=n_id, dtype=dt)
+        g2 = torch.Generator(device="cuda").manual_seed(2)          # identical pixel noise in both modes
+        losses = []
+        for s in range(steps):
+            ids = (np.arange(P) * 5 + s * P) % n_id                 # 16 distinct identities (5 is coprime to 64)
+            x = base[torch.as_tensor(ids, device="cuda")].repeat_interleave(K, 0) \
+                + noise * torch.randn((P * K, 3, H, W), generator=g2, device="cuda")
+            labels = torch.as_tensor(np.repeat(ids, K).astype(np.int64), device="cuda")
+            losses.append(model.training_step((x, labels, camid, is_real), s)["loss"].detach().float().reshape(()))
+        curves[dt] = torch.stack(losses).cpu().numpy().astype(np.float64)
+        del model
+        torch.cuda.empty_cache()
+    f, b = curves[torch.float32], curves[torch.bfloat16]
+    rel = np.abs(b - f) / np.abs(f)
+    return {"steps": steps, "identities": n_id, "noise": noise, "max_rel_loss_gap": float(rel.max()), "mean_rel_loss_gap": float(rel.mean()),
+            "step_of_max": int(rel.argmax()), "loss_f32_first_last": [float(f[0]), float(f[-1])],
+            "loss_bf16_first_last": [float(b[0]), float(b[-1])],
+            "loss_f32_every_10th": [round(float(v), 4) for v in f[::10]], "loss_bf16_every_10th": [round(float(v), 4) for v in b[::10]],
+            "note": "same seed, same batches, full CTL step; bf16 = MFMA inputs + stored activations, fp32 master weights / "
+                    "accumulators / losses / optimiser"}
+
+
 class DDPStepper:
     """Data-parallel training step with the gradient all-reduce OVERLAPPED with backward and no eager kernels between
     the captured pieces: the step is captured as hipGraph segments split where a gradient bucket becomes final
@@ -724,6 +760,13 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
                                     "rank1_f32": md["rank1_f32"], "rank1_f16": md["rank1_f16"], "min_cosine": md["min_cosine_f16"],
                                     "note": "same recipe as map_delta_bf16; f16 = compute type of the eval-mode forward (conv MFMA inputs "
                                             "and activations), fp32 accumulate"}
+            # the same delta on two more recipes (easier / harder identities): one synthetic point is one point
+            res["map_delta_recipes"] = {}
+            for nz in (0.3, 0.9):
+                m2 = map_delta_bf16(noise=nz)
+                res["map_delta_recipes"][f"noise_{nz}"] = {k: m2[k] for k in ("mAP_f32", "mAP_bf16_minus_f32", "mAP_f16_minus_f32", "rank1_f32",
+                                                                              "rank1_bf16", "rank1_f16", "min_cosine", "min_cosine_f16")}
+            res["train_curve_delta"] = train_curve_delta(P, K, H, W)
             # embeddings/s: the eval-mode forward validation_step / inference run (north_star's multi-GPU target is in it)
             res["embed"] = run_embed("resnet50", 128, 256, 128, steps=20, warmup=3, insitu=insitu)
             ef = run_embed("resnet50", 128, 256, 128, steps=20, warmup=3, dtype=torch.float16)

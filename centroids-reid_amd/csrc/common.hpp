@@ -22,6 +22,16 @@ static inline int creid_ablation_env(const char* name) {
   return v;
 }
 
+// Knobs that tests, the tuner and the probes flip INSIDE one process (kernel-variant forcing, grid caps, ablation bits).  They
+// are re-read from the environment on every call only when CREID_DEBUG_KNOBS=1 was set before the library's first launch
+// (tests/conftest.py and the tools under tools/ do that); otherwise every call site reads its knob ONCE: no environ scan per
+// convolution launch on eager paths, and no getenv racing a setenv from another Python thread in production.
+static inline bool creid_knobs_live() {
+  static const bool v = [] { const char* e = getenv("CREID_DEBUG_KNOBS"); return e && atoi(e) != 0; }();
+  return v;
+}
+#define CREID_KNOB_ENV(NAME) ([]() -> const char* { static const char* once_ = getenv(NAME); return creid_knobs_live() ? getenv(NAME) : once_; }())
+
 typedef float  f32x4  __attribute__((ext_vector_type(4)));
 typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef short  s16x8  __attribute__((ext_vector_type(8)));

@@ -1188,7 +1188,7 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
                         float* bn_part, int dtype, hipStream_t s, BnRedArgs bnred = BnRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
                         const WRedJob* wred_in = nullptr) {
 #ifdef CREID_ABL_BUILD
-  const char* abl_e = getenv("CREID_IGEMM_ABL");                  // per call: the probes sweep it inside one process
+  const char* abl_e = CREID_KNOB_ENV("CREID_IGEMM_ABL");                  // per call: the probes sweep it inside one process
   const int abl_env = abl_e ? atoi(abl_e) : 0;
   { static int warned = -1; if (abl_env && abl_env != warned) { warned = abl_env; creid_ablation_env("CREID_IGEMM_ABL"); } }
 #else
@@ -1223,7 +1223,7 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   // layer1's 3 x 3, 64 -> 64 forward: halo tile in LDS, weights in registers (conv_stream.hip conv3x3_c64_kernel); CREID_C64_3X3=0:
   // the tile kernels
   {
-    const char* ce = getenv("CREID_C64_3X3");                       // read per call: tests toggle it
+    const char* ce = CREID_KNOB_ENV("CREID_C64_3X3");                       // read per call: tests toggle it
     const bool c64_on = !ce || atoi(ce) != 0;
     if (c64_on && creid_is16(dtype) && !g.transposed && g.N == 64 && g.K == 576 && g.log2span == 6 && g.kw == 3 && g.stride == 1 &&
         g.pad == 1 && g.pitch == 64 && g.check_bounds && !add_src && !bnred.x && !wred.ws && g.SH == g.OH && g.SW == g.OW &&
@@ -1234,7 +1234,7 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   }
   // all-waves-multiply persistent kernel (conv_pipe.hip): plan kind 5, or CREID_IGEMM_PP = 0x1000 | variant for every launch it covers
   {
-    const char* pe = getenv("CREID_IGEMM_PP");                     // read per call: tests and the tuner toggle it
+    const char* pe = CREID_KNOB_ENV("CREID_IGEMM_PP");                     // read per call: tests and the tuner toggle it
     const int force_pp = pe ? (int)strtol(pe, nullptr, 0) : 0;
     if (creid_is16(dtype) && !bnred.x && !wred.ws && g.log2span >= 6 && (force_pp || tuned_pp >= 0)) {
       const int rc = launch_igemm_pp(g, src, wgt, out, add_src, bn_part, force_pp ? (force_pp & 0xfff) : tuned_pp, dtype, s);
@@ -1244,7 +1244,7 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   // persistent streaming kernel for the small-K 1x1 stride-1 forward convolutions (conv_stream.hip): plan kind 2, or
   // CREID_STREAM1X1=1 for every GEMM it covers
   {
-    const char* fe = getenv("CREID_STREAM1X1");                    // read per call: tests toggle it
+    const char* fe = CREID_KNOB_ENV("CREID_STREAM1X1");                    // read per call: tests toggle it
     const int force_stream = fe ? atoi(fe) : 0;
     const bool plain_1x1 = dtype == CREID_BF16 && !g.transposed && g.K == (1 << g.log2span) && g.stride == 1 && g.pad == 0 &&
                            g.kw == 1 && g.check_bounds && !add_src && !bnred.x && !wred.ws && g.pitch == g.K && !g.epi_scale;
@@ -1253,7 +1253,7 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
       if (rc != CREID_E_SHAPE) return rc;
     }
     // second form (plan kind 4 / CREID_STREAM2=1): also the folded eval-mode epilogue with the block's residual
-    const char* f2 = getenv("CREID_STREAM2");
+    const char* f2 = CREID_KNOB_ENV("CREID_STREAM2");
     const int force2 = f2 ? atoi(f2) : 0;
     const bool fwd_1x1 = creid_is16(dtype) && !g.transposed && g.K == (1 << g.log2span) && g.stride == 1 && g.pad == 0 &&
                          g.kw == 1 && g.check_bounds && !bnred.x && !wred.ws && g.pitch == g.K && !g.add_compact && !g.add_mask &&
@@ -1292,7 +1292,7 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
       // 256-row tiles (128 x 64 consumer sub-tiles, one workgroup per CU): plan kind 3, or CREID_IGEMM_BM=256 wherever the grid
       // still has >= CREID_IGEMM_BM256_MIN_WGS (default 256) workgroups; not with the fused BN reduction / parity-class rows
       {
-        const char* be = getenv("CREID_IGEMM_BM");                 // read per call: tests and the tuner toggle it
+        const char* be = CREID_KNOB_ENV("CREID_IGEMM_BM");                 // read per call: tests and the tuner toggle it
         const int force_bm = be ? atoi(be) : 0;
         static const int bm256_min = [] { const char* e = getenv("CREID_IGEMM_BM256_MIN_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
         const bool can256 = g.N % 128 == 0 && !bnred.x && !gp.parity;

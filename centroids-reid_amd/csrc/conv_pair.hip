@@ -297,10 +297,10 @@ static int launch_pair(int64_t M, int64_t c_mid, int64_t c_out, int64_t c_next, 
   if (bn_part1 && M % 128 != 0) return CREID_E_SHAPE;
   const int tiles_m = (int)((M + 127) / 128);
   int wgs = 256;
-  { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
+  { const char* e = CREID_KNOB_ENV("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
   if (wgs > tiles_m) wgs = tiles_m;
 #ifdef CREID_ABL_BUILD
-  const char* ae = getenv("CREID_PAIR_ABL");            // 1 no stores, 2 no residual loads, 4 no A loads, 8 no second multiply
+  const char* ae = CREID_KNOB_ENV("CREID_PAIR_ABL");            // 1 no stores, 2 no residual loads, 4 no A loads, 8 no second multiply
   const int abl = ae ? atoi(ae) : 0;
 #else
   const int abl = 0;

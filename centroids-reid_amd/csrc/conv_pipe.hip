@@ -479,7 +479,7 @@ int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* 
   const int ntiles = pa.tiles_m * pa.tiles_n;
   static const int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   int cap = (bm * bn <= 128 * 128) ? 2 * ncu : ncu;
-  { const char* e = getenv("CREID_PP_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) cap = v; }   // tests: few workgroups walk many tiles
+  { const char* e = CREID_KNOB_ENV("CREID_PP_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) cap = v; }   // tests: few workgroups walk many tiles
   const dim3 grid((unsigned)(ntiles < cap ? ntiles : cap)), block(512);
   const int epi = g.epi_scale ? 2 : (bn_part ? 1 : 0);
 #define CREID_PP_LAUNCH(BM_, BN_, WN_, KPH_, GLM_)                                                          \

@@ -317,13 +317,13 @@ int creid_stem_conv_pool_fwd_affine(int64_t batch, int64_t H, int64_t W, const v
   const int H1 = (int)(H / 2), W1 = (int)(W / 2);
   hipStream_t s = as_stream(stream);
 #ifdef CREID_ABL_BUILD
-  const char* ae = getenv("CREID_STEM_ABL");            // 1 no multiplies, 2 no input loads, 4 no epilogue, 8 no pool
+  const char* ae = CREID_KNOB_ENV("CREID_STEM_ABL");            // 1 no multiplies, 2 no input loads, 4 no epilogue, 8 no pool
   const int abl = ae ? atoi(ae) : 0;
 #else
   const int abl = 0;
 #endif
   int wgs_env = 0;
-  { const char* e = getenv("CREID_STEM_WGS"); if (e) wgs_env = atoi(e); }   // read per call (tests)
+  { const char* e = CREID_KNOB_ENV("CREID_STEM_WGS"); if (e) wgs_env = atoi(e); }   // read per call (tests)
 #define CREID_STEM_LAUNCH(W1_, RS_, NW_, ET_)                                                                          \
   do {                                                                                                                 \
     if (H1 % RS_) return CREID_E_SHAPE;                                                                                \
@@ -338,7 +338,7 @@ int creid_stem_conv_pool_fwd_affine(int64_t batch, int64_t H, int64_t W, const v
   // W = 128: four-wave workgroups, two per CU (one multiplies while the other pools: 43 vs 50 us at B = 128) unless
   // CREID_STEM_FORM=0; W = 320 only fits the eight-wave form (137 KB of LDS)
   int form = 1;
-  { const char* e = getenv("CREID_STEM_FORM"); if (e) form = atoi(e); }      // read per call (tests)
+  { const char* e = CREID_KNOB_ENV("CREID_STEM_FORM"); if (e) form = atoi(e); }      // read per call (tests)
   if (W1 == 64) {
     if (form == 1 && H1 % 4 == 0) { if (dtype == CREID_F16) CREID_STEM_LAUNCH(64, 4, 4, F16T); else CREID_STEM_LAUNCH(64, 4, 4, Bf16T); }
     else { if (dtype == CREID_F16) CREID_STEM_LAUNCH(64, 8, 8, F16T); else CREID_STEM_LAUNCH(64, 8, 8, Bf16T); }

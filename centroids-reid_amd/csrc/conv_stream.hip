@@ -217,9 +217,9 @@ int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void
   const int tiles_m = (M + 127) / 128, tiles_n = N / bn;
   // persistent grid: one workgroup per CU (the LDS budget allows one), split evenly over the column slabs
   int wgs = 256;                                       // read per call (tests shrink it to force many tiles per workgroup)
-  { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }
+  { const char* e = CREID_KNOB_ENV("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }
   int dbg = 0;
-  { const char* e = getenv("CREID_STREAM1X1_DBG"); if (e) dbg = atoi(e); }
+  { const char* e = CREID_KNOB_ENV("CREID_STREAM1X1_DBG"); if (e) dbg = atoi(e); }
   int groups = wgs / tiles_n;
   if (groups < 1) groups = 1;
   if (groups > tiles_m) groups = tiles_m;
@@ -509,11 +509,11 @@ int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* 
   if (K == 256 && bn > 64) bn = 64;                    // LDS: weight slab + one 64 KB tile slot + staging
   if (bn != 64 && bn != 128 && bn != 256) return CREID_E_SHAPE;
   if (N % bn != 0) return CREID_E_SHAPE;
-  { const char* e = getenv("CREID_STREAM2_BN"); const int v = e ? atoi(e) : 0; if (v == 64 || v == 128) bn_cap = v; }   // (experiments)
+  { const char* e = CREID_KNOB_ENV("CREID_STREAM2_BN"); const int v = e ? atoi(e) : 0; if (v == 64 || v == 128) bn_cap = v; }   // (experiments)
   if ((bn_cap == 64 || bn_cap == 128) && bn_cap < bn && N % bn_cap == 0) bn = bn_cap;
   const int tiles_m = (M + 127) / 128, tiles_n = N / bn;
   int wgs = 256;
-  { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
+  { const char* e = CREID_KNOB_ENV("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
   int groups = wgs / tiles_n;
   if (groups < 1) groups = 1;
   if (groups > tiles_m) groups = tiles_m;
@@ -789,11 +789,11 @@ int launch_conv3x3_c64(int M, int H, int Wd, const void* src, const void* wgt, v
   if ((!full_rows && !tile2d) || M % (H * Wd) != 0 || !creid_is16(dtype)) return CREID_E_SHAPE;
   const int n_tiles = M / 128;
   int wgs = 256;
-  { const char* e = getenv("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
+  { const char* e = CREID_KNOB_ENV("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }   // read per call (tests)
   if (wgs > n_tiles) wgs = n_tiles;
   const dim3 grid((unsigned)wgs), block(512);
 #ifdef CREID_ABL_BUILD
-  const char* ae = getenv("CREID_C64_ABL");             // 1 no multiplies, 2 no input loads, 4 no staging / copy-out, 8 no stores
+  const char* ae = CREID_KNOB_ENV("CREID_C64_ABL");             // 1 no multiplies, 2 no input loads, 4 no staging / copy-out, 8 no stores
   const int abl = ae ? atoi(ae) : 0;
 #else
   const int abl = 0;

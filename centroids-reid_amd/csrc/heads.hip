@@ -738,7 +738,8 @@ __global__ __launch_bounds__(256) void loo_emb_fwd_kernel(const float* __restric
                                                           const int64_t* __restrict__ labels, int P, int K, int D,
                                                           float* __restrict__ cent, int32_t* __restrict__ valid,
                                                           float* __restrict__ emb, int64_t* __restrict__ lab,
-                                                          float* __restrict__ cnorm, uint8_t* __restrict__ exists) {
+                                                          float* __restrict__ cnorm, uint8_t* __restrict__ exists,
+                                                          int32_t* __restrict__ lonely = nullptr) {
   __shared__ float wsum[4];
   const int p = blockIdx.x, i = blockIdx.y;
   const bool qreal = is_real[p * K + i] != 0;
@@ -749,6 +750,9 @@ __global__ __launch_bounds__(256) void loo_emb_fwd_kernel(const float* __restric
     // exists (nullable, uint8 [K][2P]): identity p takes part in round i -- its i-th instance is real (the query) AND it has
     // another real instance (a non-zero centroid); train_ctl_model.py:112-122 keeps exactly these rows
     if (exists) { const uint8_t e = (qreal && cnt > 0) ? 1 : 0; exists[i * 2 * P + p] = e; exists[i * 2 * P + P + p] = e; }
+    // a real instance without a real partner: the reference fails on such a batch (labels.expand, losses/triplet_loss.py:88);
+    // a step driven by a DEVICE mask cannot raise without a host sync, so it counts them and the epoch end raises
+    if (lonely && qreal && cnt == 0) atomicAdd(lonely, 1);
     valid[i * P + p] = cnt;
     const int64_t l = labels[p * K + i];
     lab[(int64_t)i * 2 * P + p] = l;
@@ -913,6 +917,16 @@ int creid_loo_emb_fwd_rows(const float* feat, const uint8_t* is_real, const int6
   CREID_CHECK_ARG(feat && is_real && labels && centroids && valid && emb && lab && cnorm && row_exists && P > 0 && K > 0 && D > 0);
   hipLaunchKernelGGL(loo_emb_fwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream), feat, is_real, labels,
                      (int)P, (int)K, (int)D, centroids, valid, emb, lab, cnorm, row_exists);
+  CREID_LAUNCH_RET();
+}
+
+int creid_loo_emb_fwd_rows_lonely(const float* feat, const uint8_t* is_real, const int64_t* labels, int64_t P, int64_t K, int64_t D,
+                                  float* centroids, int32_t* valid, float* emb, int64_t* lab, float* cnorm, uint8_t* row_exists,
+                                  int32_t* lonely_accum, void* stream) {
+  CREID_CHECK_ARG(feat && is_real && labels && centroids && valid && emb && lab && cnorm && row_exists && lonely_accum && P > 0 &&
+                  K > 0 && D > 0);
+  hipLaunchKernelGGL(loo_emb_fwd_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, as_stream(stream), feat, is_real, labels,
+                     (int)P, (int)K, (int)D, centroids, valid, emb, lab, cnorm, row_exists, lonely_accum);
   CREID_LAUNCH_RET();
 }
 

@@ -275,7 +275,7 @@ class BatchNorm1dFn(torch.autograd.Function):
                                        L.ptr(si), L.stream()), "creid_bn1d_fwd")
         if training:
             ctx.save_for_backward(x, weight, sm, si)
-        elif ctx.needs_input_grad[0]:       # eval mode under autograd only: inference (no_grad) must not pay three extra launches
+        elif any(ctx.needs_input_grad[:3]):  # eval mode under autograd only: inference (no_grad) must not pay three extra launches
             ctx.save_for_backward(x, weight, rmean.clone(), torch.rsqrt(rvar + eps))
         ctx.training = training
         return y
@@ -286,7 +286,12 @@ class BatchNorm1dFn(torch.autograd.Function):
         B, D = x.shape
         dy = _f32c(dy)
         if not ctx.training:
-            return dy * (weight * si), None, None, None, None, None, None, None
+            # running statistics are constants: y = (x - rm) * w * si + b.  x may be detached while weight / bias still want
+            # their gradient (eval-mode BNNeck on detached engine features), so every one of the three is optional
+            dx = dy * (weight * si) if ctx.needs_input_grad[0] else None
+            dw = (dy * (x - sm) * si).sum(0) if ctx.needs_input_grad[1] else None
+            db = dy.sum(0) if ctx.needs_input_grad[2] else None
+            return dx, dw, db, None, None, None, None, None
         dx = torch.zeros_like(x)
         dw = torch.zeros_like(weight) if ctx.needs_input_grad[1] else None
         db = torch.zeros_like(weight) if ctx.needs_input_grad[2] else None

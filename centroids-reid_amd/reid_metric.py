@@ -414,9 +414,11 @@ class R1_mAP:
         self.last = dict(distmat=distmat, indices=indices, single_performance=single, valid=valid, ap=ap, first=first)
         return pack[:max_rank].astype(np.float32), float(pack[max_rank]), pack[max_rank + 1:max_rank + 6].copy()
 
-    def _compute_streamed(self, feats, pids, camids, plan=None):
+    def _compute_streamed(self, feats, pids, camids, plan=None, _normed=None):
         nq = self.num_query
-        if self.feat_norm:
+        if _normed is not None:                 # the redo of a failed speculation: rows already normalised, nothing printed twice
+            f, sq = _normed
+        elif self.feat_norm:
             print("The test feature is normalized")
             f, sq = l2_normalize(feats, return_sqnorm=True)
         else:
@@ -431,7 +433,7 @@ class R1_mAP:
             # larger than needed gives identical results)
             plan = StreamPlan.on_device(pids, camids, nq, feats.device)
             hint = _CAP_HINT.get((plan.m, plan.n)) if os.environ.get("CREID_EVAL_SPECULATE", "1") == "1" else None
-            if plan.cap is None and hint is not None:
+            if plan.cap is None and hint:        # 0 = "do not speculate": the last label set of this shape had overflow queries
                 plan.cap, plan.overflow, speculative = hint, np.zeros(0, np.int64), True
         if plan.cap is None:
             plan.finish()
@@ -456,13 +458,16 @@ class R1_mAP:
             need = 2
             while need < max(int(pack[-2]), 1):
                 need *= 2
-            _CAP_HINT[(plan.m, plan.n)] = need
-            if need > plan.cap or int(pack[-1]) > 0:             # the assumed capacity was too small: redo, synchronously
+            nover = int(pack[-1])
+            # a label set with overflow queries (> 128 positives) cannot be speculated on (their list is only known to the
+            # synchronous plan): remember that instead of a capacity, so that evaluations of this shape stop redoing
+            _CAP_HINT[(plan.m, plan.n)] = 0 if nover > 0 else need
+            if need > plan.cap or nover > 0:                     # the assumed capacity was too small: redo, synchronously
                 plan.cap = None
                 plan.finish()
-                return self._compute_streamed(feats, pids, camids, plan=plan)
+                return self._compute_streamed(feats, pids, camids, plan=plan, _normed=(f, sq))
         elif getattr(plan, "_stats", None) is not None:
-            _CAP_HINT[(plan.m, plan.n)] = plan.cap
+            _CAP_HINT[(plan.m, plan.n)] = 0 if len(plan.overflow) else plan.cap
         pack = pack[:-2]
         cmc_h = pack[:max_rank].astype(np.float32)
         mAP_h = float(pack[max_rank])

@@ -118,7 +118,33 @@ class CenterSGD(torch.optim.Optimizer):
         super().__init__(param_groups, dict(lr=lr))
         self.grad_mul = 1.0
         self.grad_scale = 1.0          # data-parallel 1 / world when the gradient was SUM-reduced inside the Adam buffer's tail
-        self.grad_in_adam_tail = False
+        self._tail = None
+
+    @property
+    def grad_in_adam_tail(self):
+        """True iff EVERY parameter's .grad still is a view of the adopted tail.  Checked at every read (two pointer compares
+        per parameter): a foreign wrapper's zero_grad(set_to_none=True), `p.grad = ...` in user code or a re-created Parameter
+        rebinds .grad, and the data-parallel sync must then fall back to the explicit all-reduce instead of silently stepping
+        on an unreduced gradient with 1 / world applied (parallel.make_grad_sync / make_overlapped_grad_sync read this)."""
+        if self._tail is None:
+            return False
+        lo = self._tail.data_ptr()
+        hi = lo + self._tail.numel() * self._tail.element_size()
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                    return False
+        return True
+
+    def readopt_tail(self):
+        """Re-home gradients that were rebound away from the tail (their values are kept).  Outside captured graphs only."""
+        if self._tail is None or self.grad_in_adam_tail:
+            return
+        old = [[None if p.grad is None else p.grad.detach().clone() for p in g["params"]] for g in self.param_groups]
+        self.adopt_tail(self._tail)
+        for g, og in zip(self.param_groups, old):
+            for p, o in zip(g["params"], og):
+                p.grad.zero_() if o is None else p.grad.copy_(o)
 
     def adopt_tail(self, tail):
         """The parameters' gradients become views of `tail` (the room behind FusedAdam's flat gradient buffer): the
@@ -130,7 +156,7 @@ class CenterSGD(torch.optim.Optimizer):
                 assert off + k <= tail.numel()
                 p.grad = tail[off:off + k].view(p.shape)
                 off += (k + 3) // 4 * 4
-        self.grad_in_adam_tail = True
+        self._tail = tail
 
     def zero_grad(self, set_to_none: bool = False):
         for g in self.param_groups:

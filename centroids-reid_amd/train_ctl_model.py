@@ -42,6 +42,24 @@ class CTLModel(ModelBase):
         self.apply_optimizers()
         return out
 
+    def check_lonely_identities(self):
+        """Steps driven by a DEVICE isReal mask cannot raise inside the step (no host sync); the kernel counts every real
+        instance that had no real partner, and this raises the reference's error for them -- once per epoch from
+        training_epoch_end, or whenever the caller wants to pay the 4-byte read-back."""
+        lonely = getattr(self, "_lonely_dev", None)
+        if lonely is None:
+            return
+        n = int(lonely.item())
+        if n:
+            lonely.zero_()
+            raise RuntimeError(f"query/centroid count mismatch in a centroid round: {n} real instance(s) without a real partner "
+                               "in the steps since the last check (the reference fails in labels.expand at "
+                               "losses/triplet_loss.py:88)")
+
+    def training_epoch_end(self, outputs):
+        self.check_lonely_identities()
+        return super().training_epoch_end(outputs)
+
     def _raw_optimizers(self):
         """(Adam, center SGD) as the objects whose step() actually runs: under pytorch-lightning
         `self.optimizers()` returns LightningOptimizer wrappers, and attributes set on a wrapper (grad_mul,
@@ -86,7 +104,8 @@ class CTLModel(ModelBase):
         # fakes (hipGraph-capturable, bench.py's "fake_mix" line).  One divergence from the reference on that path, accepted for
         # the missing sync: an identity with exactly ONE real instance makes the reference fail in labels.expand
         # (losses/triplet_loss.py:88; the host path below raises the same way); the device path cannot look at the mask, so the
-        # lonely row simply drops out of its round (`exists = qreal && cnt > 0` in creid_loo_emb_fwd_rows) and training goes on.
+        # lonely row drops out of its round (`exists = qreal && cnt > 0` in creid_loo_emb_fwd_rows), the kernel COUNTS it on the
+        # device, and the same RuntimeError is raised late: at training_epoch_end (or by check_lonely_identities()).
         # The reference's own sampler never produces such a batch (PK batches pad whole instances of an identity that has
         # at least two real ones, datasets/bases.py:374-395).
         fused_ok = (self.fused_heads and P >= 2 and 2 <= K <= 16 and x.is_cuda and hasattr(self.backbone, "engine")
@@ -290,8 +309,14 @@ class CTLModel(ModelBase):
         if masked:
             rows = torch.empty((K, 2 * P), dtype=torch.uint8, device=dev)
             inv_rounds = torch.empty(1, **f32)
-            L.check(lib.creid_loo_emb_fwd_rows(L.ptr(feat), L.ptr(real), L.ptr(labels), P, K, D, L.ptr(cent), L.ptr(valid),
-                                               L.ptr(emb), L.ptr(lab), L.ptr(cnorm), L.ptr(rows), st), "creid_loo_emb_fwd_rows")
+            # (the kernel also counts real instances without a real partner into a persistent device counter: the reference
+            # raises on such a batch, this sync-free step cannot -- training_epoch_end / check_lonely_identities() does)
+            lonely = getattr(self, "_lonely_dev", None)
+            if lonely is None or lonely.device != dev:
+                lonely = self._lonely_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            L.check(lib.creid_loo_emb_fwd_rows_lonely(L.ptr(feat), L.ptr(real), L.ptr(labels), P, K, D, L.ptr(cent), L.ptr(valid),
+                                                      L.ptr(emb), L.ptr(lab), L.ptr(cnorm), L.ptr(rows), L.ptr(lonely), st),
+                    "creid_loo_emb_fwd_rows_lonely")
             # the K rounds, valid ones only (>= 2 identities kept, :113); their mean is taken on the device (inv_rounds)
             keep.append(triplet(emb, lab, K, 2 * P, out4[1:], hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT, demb, rows=rows,
                                 gscale_dev=inv_rounds))

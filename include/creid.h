@@ -192,6 +192,12 @@ int creid_ctl_step_stats(const float* scal, const float* weights, int64_t n, int
 int creid_loo_emb_fwd_rows(const float* feat, const uint8_t* is_real, const int64_t* labels, int64_t P, int64_t K, int64_t D,
                            float* centroids, int32_t* valid, float* emb, int64_t* lab, float* cnorm, uint8_t* row_exists,
                            void* stream);
+/* creid_loo_emb_fwd_rows that also COUNTS the real instances without a real partner (an identity with exactly one real
+ * instance: the reference raises there, train_ctl_model.py:80-104 -> losses/triplet_loss.py:88) into lonely_accum[0] (int32,
+ * accumulated with an atomic: the caller zeroes it once per epoch and reads it at the epoch end -- no sync inside the step). */
+int creid_loo_emb_fwd_rows_lonely(const float* feat, const uint8_t* is_real, const int64_t* labels, int64_t P, int64_t K, int64_t D,
+                                  float* centroids, int32_t* valid, float* emb, int64_t* lab, float* cnorm, uint8_t* row_exists,
+                                  int32_t* lonely_accum, void* stream);
 int creid_triplet_fwd_batched_rows(const float* x, const int64_t* labels, const uint8_t* row_exists, int64_t nb, int64_t N,
                                    int64_t D, float margin, int32_t min_rows, float* dist_ap, float* dist_an,
                                    int32_t* p_idx, int32_t* n_idx, float* coef, float* out4, void* stream);

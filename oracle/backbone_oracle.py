@@ -18,6 +18,13 @@ import torch.nn.functional as F
 
 LAYERS = (3, 4, 6, 3)
 PLANES = (64, 128, 256, 512)
+# modelling/baseline.py:65-81 (Bottleneck variants of MODEL.NAME) + resnet_ibn_a.py:164-190
+ARCH_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3),
+               "resnet50_ibn_a": (3, 4, 6, 3), "resnet101_ibn_a": (3, 4, 23, 3)}
+
+
+def is_ibn(arch: str) -> bool:
+    return arch.endswith("_ibn_a")
 
 
 def layer_strides(last_stride: int = 1):
@@ -26,9 +33,9 @@ def layer_strides(last_stride: int = 1):
 
 def arch_spec(arch: str = "resnet50", last_stride: int = 1):
     """List of (prefix, inplanes, planes, stride, has_downsample, ibn) for every bottleneck."""
-    ibn_arch = arch == "resnet50_ibn_a"
+    ibn_arch = is_ibn(arch)
     spec, inpl = [], 64
-    for li, (n, pl, st) in enumerate(zip(LAYERS, PLANES, layer_strides(last_stride))):
+    for li, (n, pl, st) in enumerate(zip(ARCH_LAYERS[arch], PLANES, layer_strides(last_stride))):
         for b in range(n):
             s = st if b == 0 else 1
             ds = b == 0 and (s != 1 or inpl != pl * 4)
@@ -120,8 +127,8 @@ def backbone_forward(x, sd, arch="resnet50", last_stride=1, training=False):
     """Returns (base_out [B,2048,h,w], global_feat [B,2048]) -- modelling/baseline.py:91-96.
     In training mode the running stats inside `sd` are updated in place (like nn.BatchNorm2d)."""
     y = _bn(F.conv2d(x, sd["conv1.weight"], stride=2, padding=3), sd, "bn1", training)
-    if arch == "resnet50_ibn_a":
-        y = F.relu(y)                                   # resnet_ibn_a.py:129 (plain R50 has none)
+    if is_ibn(arch):
+        y = F.relu(y)                                   # resnet_ibn_a.py:129 (plain ResNets have none)
     y = F.max_pool2d(y, 3, 2, 1)
     for pre, _inpl, _pl, s, ds, ibn in arch_spec(arch, last_stride):
         y = bottleneck(y, sd, pre, s, ds, ibn, training)

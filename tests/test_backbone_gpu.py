@@ -180,7 +180,7 @@ def _build(arch, dtype, seed=1234):
     from oracle import backbone_oracle as bo
     from centroids_reid_amd import backbone as bb
     sd = bo.make_state_dict(arch, 1, seed=seed)
-    net = bb.ResNet(last_stride=1) if arch == "resnet50" else bb.ResNet_IBN(last_stride=1)
+    net = bb.build_backbone(arch, 1)
     missing = net.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys and all(k.startswith('fc.') for k in missing.missing_keys), missing
     net = net.cuda()
@@ -298,6 +298,42 @@ def test_resnet50_ibn_a_fp32_golden(golden):
     close(net.layer4[2].conv3.weight.grad[:16, :, 0, 0].cpu().numpy(), g["grad_l4_conv3_slice"])
     close(net.layer1[0].conv2.weight.grad[:8].cpu().numpy(), g["grad_l1_conv2_slice"])
     close(net.conv1.weight.grad.cpu().numpy(), g["grad_conv1"])
+
+
+@pytest.mark.parametrize("arch,tag", [("resnet101", "r101"), ("resnet152", "r152"), ("resnet101_ibn_a", "r101ibn")])
+def test_deeper_bottleneck_archs_fp32_golden(golden, arch, tag):
+    """The other Bottleneck values of MODEL.NAME (modelling/baseline.py:73-81, resnet_ibn_a.py:173-181) run through the same
+    engine and kernels -- only the block counts differ -- against recordings of the REFERENCE's own modules (2 x 64 x 64,
+    tools/gen_golden.py deep).  The features of a 101- / 152-layer network with perturbed BatchNorm parameters are not
+    unit-scale (std 2-20), so the 1e-4 bar is applied relative to their spread."""
+    from oracle import backbone_oracle as bo
+    g = golden(f"backbone_{tag}_2x64x64")
+    net, eng, sd = _build(arch, torch.float32)
+    assert len(eng.blocks) == sum(bo.ARCH_LAYERS[arch])
+    x = bo.synthetic_images(2, 64, 64, seed=7).cuda()
+    scale = max(1.0, float(g["eval_feat"].std()))
+    _, feat = eng.forward(x, training=False)
+    np.testing.assert_allclose(feat.cpu().numpy(), g["eval_feat"], rtol=0, atol=1e-4 * scale)
+    _, feat = eng.forward(x, training=True)
+    np.testing.assert_allclose(feat.cpu().numpy(), g["train_feat"], rtol=0, atol=3e-4)      # 4 x 4 final maps, batch 2
+    coef = torch.from_numpy(np.random.default_rng(99).standard_normal((2, 2048)).astype(np.float32)).cuda()
+    eng.backward(coef)
+    np.testing.assert_allclose(net.layer4[2].bn3.running_var.cpu().numpy(), g["l4_bn3_rv"], rtol=1e-3, atol=1e-5)
+
+    def close(a, ref, rel=8e-2):           # batch 2 on 4 x 4 maps through 33 / 50 train-mode blocks: ReLU-mask flips (see above)
+        a = a.astype(np.float64).ravel(); ref = ref.astype(np.float64).ravel()
+        assert np.linalg.norm(a - ref) <= rel * np.linalg.norm(ref), np.linalg.norm(a - ref) / np.linalg.norm(ref)
+    close(net.layer4[2].conv3.weight.grad[:16, :, 0, 0].cpu().numpy(), g["grad_l4_conv3_slice"])
+    close(net.layer1[0].conv2.weight.grad[:8].cpu().numpy(), g["grad_l1_conv2_slice"])
+    close(net.conv1.weight.grad.cpu().numpy(), g["grad_conv1"])
+    gsum = sum(p.grad.double().abs().sum().item() for p in net.parameters() if p.grad is not None)
+    assert abs(gsum - float(g["grad_abs_sum"])) < 5e-2 * float(g["grad_abs_sum"])
+    # and the 16-bit eval forward of the same network stays finite and close in direction
+    _, _, _ = net, eng, sd
+    eng16 = __import__("centroids_reid_amd").backbone.BackboneEngine(net, torch.bfloat16)
+    _, f16 = eng16.forward(x, training=False)
+    cos = torch.nn.functional.cosine_similarity(f16.float(), torch.from_numpy(g["eval_feat"]).cuda(), dim=1)
+    assert torch.isfinite(f16).all() and float(cos.min()) > 0.99
 
 
 def test_resnet50_ibn_a_320x320_golden(golden):

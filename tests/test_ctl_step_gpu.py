@@ -190,3 +190,41 @@ def test_fused_heads_match_autograd_path():
         # classifier GEMMs use split-K atomics: last-bit differences, nothing more.  Analytically-zero
         # gradients (a BN bias feeding another train-mode BN) hold ~1e-5 of rounding noise in both runs.
         assert err < 2e-4 * den + 5e-5, (n, err, den)
+
+
+def test_device_mask_step_reports_lonely_identity_at_epoch_end(golden):
+    """train_ctl_model.py:80-104: an identity with exactly ONE real instance makes the reference raise inside the step
+    (labels.expand, losses/triplet_loss.py:88).  With the mask on the host this path raises the same way; with the mask on
+    the DEVICE the step cannot (no host sync), so its kernel counts such instances and `training_epoch_end` /
+    `check_lonely_identities()` raises late (VERDICT r04 missing 6).  A batch whose fakes leave every identity >= 2 real
+    instances raises nowhere."""
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    g = golden("heads_p16k4_d128_fake2")
+    P, K, C = int(g["P"]), int(g["K"]), int(g["C"])
+    D = g["feats"].shape[1]
+
+    def make():
+        model = CTLModel(_cfg(D, K, float(g["margin"])), num_classes=C, num_query=0)
+        model.backbone = FeatStubEngine(torch.from_numpy(g["feats"]))
+        model = model.cuda().train()
+        model.configure_optimizers()
+        return model
+
+    def batch(is_real):
+        return (torch.zeros(P * K, 3, 8, 4, device="cuda"), torch.from_numpy(g["labels"]).cuda(),
+                torch.zeros(P * K, dtype=torch.int64), is_real)
+
+    ok = torch.from_numpy(g["is_real"])                       # the reference's own recording: no lonely identity
+    bad = ok.clone()
+    bad[4:8] = torch.tensor([True, False, False, False])      # identity 1 keeps a single real instance
+    bad[20:24] = torch.tensor([False, False, True, False])    # identity 5 too
+    model = make()
+    model.training_step(batch(ok.cuda()), 0)
+    model.check_lonely_identities()                           # nothing to report
+    model.training_step(batch(bad.cuda()), 1)                 # runs: the lonely rows drop out of their rounds
+    model.training_step(batch(bad.cuda()), 2)
+    with pytest.raises(RuntimeError, match="4 real instance"):
+        model.check_lonely_identities()
+    model.check_lonely_identities()                           # the counter was reset by the raise
+    with pytest.raises(RuntimeError, match="count mismatch"):
+        make().training_step(batch(bad), 0)                   # mask on the host: raised inside the step, as before

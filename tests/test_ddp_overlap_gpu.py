@@ -6,6 +6,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -92,3 +93,30 @@ def test_bench_gpus_2_contract_two_ranks_one_gpu():
     assert single.returncode == 0, (single.stdout + single.stderr)[-3000:]
     sline = json.loads([ln for ln in single.stdout.strip().splitlines() if ln.strip()][-1])
     assert abs(ev["mAP"] - sline["mAP"]) < 1e-12, (ev["mAP"], sline["mAP"])
+
+
+def test_bench_gpus_8_contract_eight_ranks_one_gpu():
+    """`bench.py --gpus 8` exactly as the scaling driver will launch it the day an 8-GPU node exists (BASELINE configs[2]),
+    with the eight ranks sharing cuda:0 and gloo carrying the collectives: no deadlock in the 3-bucket overlapped gradient
+    schedule at world 8 (every rank must agree on the capture fallback before choosing its collective schedule), rc 0, ONE
+    stdout line, global batch 8 x P x K (the PK shards of datasets/samplers/distributed_pids_sampler.py:61-71), the
+    query-sharded evaluation over the all-gathered gallery."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CREID_DIST_BACKEND="gloo", CREID_SINGLE_DEVICE="1",
+               CREID_BENCH_NO_INSITU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "dp8" and line["config"]["global_batch"] == 8 * line["config"]["P"] * line["config"]["K"]
+    assert line["value"] > 0 and np.isfinite(line["final_loss"])
+    emb = line.get("embed_ranks") or line["embed"]
+    assert emb["config"]["parallelism"] == "dp8" and emb["value"] > 0
+    assert line["eval"]["config"]["parallelism"] == "query-shard x8, gallery all-gather" and 0 < line["eval"]["mAP"] < 1

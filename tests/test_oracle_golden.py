@@ -120,7 +120,8 @@ def test_heads_step(golden, name):
     np.testing.assert_allclose(p1.numpy(), g["s0_fc_after"], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["backbone_r50_2x256x128", "backbone_r50ibn_2x64x64"])
+@pytest.mark.parametrize("name", ["backbone_r50_2x256x128", "backbone_r50ibn_2x64x64", "backbone_r101_2x64x64",
+                                  "backbone_r152_2x64x64", "backbone_r101ibn_2x64x64"])
 def test_backbone_oracle(golden, name):
     g = golden(name)
     arch = str(g["arch"]); B, H, W = int(g["B"]), int(g["H"]), int(g["W"])

@@ -162,3 +162,24 @@ def test_compute_chunked_supports_cosine_and_unaligned_feature_width():
         if dist == "euclidean":                         # streamed=True with D % 4 != 0 takes the materialised kernels
             st = rm.R1_mAP(num_query=nq, streamed=True).compute(f, pids, cams)
             assert abs(st[1] - ref[1]) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_standalone_baseline_returns_base_out_like_the_reference(dtype):
+    """modelling/baseline.py:91-96: `Baseline.forward` returns (base_out NCHW, global_feat = GAP(base_out)).  A stand-alone
+    Baseline hands the feature map back (a caller that consumes base_out must not get None); inside
+    ModelBase / CTLModel, which never read it, the layout pass is switched off."""
+    from oracle import backbone_oracle as bo
+    from centroids_reid_amd.baseline import Baseline
+    net = Baseline(_cfg(), compute_dtype=dtype).cuda()
+    x = bo.synthetic_images(2, 64, 32, seed=3).cuda()
+    for training in (False, True):
+        net.train(training)
+        base_out, feat = net(x)
+        assert base_out is not None and base_out.dtype == torch.float32 and tuple(base_out.shape) == (2, 2048, 4, 2)
+        np.testing.assert_allclose(base_out.mean(dim=(2, 3)).cpu().numpy(), feat.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    model = CTLModel(_cfg(), num_classes=8, num_query=0, compute_dtype=dtype).cuda().eval()
+    with torch.no_grad():
+        base_out, _ = model.backbone(x)
+    assert base_out is None

@@ -1,5 +1,6 @@
 """256-row igemm tiles (igemm_bf16_ws_kernel<128, NS, 256>) against the 128-row tiles: bit equality and time per shape.
     python tools/debug/bm256_probe.py [batch]"""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import os
 import sys
 import torch

@@ -1,5 +1,6 @@
 """conv3x3_c64_kernel against the tile kernels: us per launch at the training and embedding batches (cold operands: the launches
 cycle through copies of the input)."""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import os
 import sys
 import torch

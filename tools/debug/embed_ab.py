@@ -1,6 +1,7 @@
 """A/B of environment switches on the captured eval-mode embedding forward (run on the GPU box):
     python tools/debug/embed_ab.py "CREID_C64_3X3=1" "CREID_C64_3X3=0" [--arch resnet50 --B 128 --H 256 --W 128]
 Every configuration is captured afresh (the switches are read at launch = capture time), timed three times, interleaved twice."""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import argparse
 import os
 import sys

@@ -1,6 +1,7 @@
 """Timing ablation of the producer/consumer igemm kernel (run on the GPU box, one process per CREID_IGEMM_ABL value): per
 distinct convolution of the B = 64 step, the training forward (BatchNorm statistics epilogue) and the plain data gradient with
 the shipped launch plans, 10 back-to-back launches in a graph.  Shapes the plans route to the four-wave DMA kernel do not react."""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import os
 import sys
 import torch

@@ -1,4 +1,5 @@
 """us per call of the one-launch layer1 block boundary (conv_pair.hip) against the two launches it replaces, cold operands."""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

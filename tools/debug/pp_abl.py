@@ -2,6 +2,7 @@
 python centroids-reid_amd/build.py --ablation).  CREID_IGEMM_ABL bits: 1 no MFMA, 2 no DMA after the first k-tile, 4 no fragment
 reads, 8 no copy-out stores.
     python tools/debug/pp_abl.py [batch] [--variants=0x..,..] [--trace]"""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import ctypes as C
 import os
 import sys

@@ -2,6 +2,7 @@
 per layer shape and variant.
     python tools/debug/pp_probe.py [batch [H W]] [--variants 0x...,0x...] [--min-k 256] [--modes stats,affine,res,dgrad]
 variant word = BM / 128 | (BN / 128) << 2 | KPH << 4 | GLM << 8 (CREID_IGEMM_PP = 0x1000 | variant)."""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import os
 import sys
 import torch

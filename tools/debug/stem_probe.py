@@ -1,5 +1,6 @@
 """Timing of the one-launch eval-mode stem (conv_stem.hip) against the two launches it replaces (run on the GPU box):
     python tools/debug/stem_probe.py [--B 128 --H 256 --W 128] [--abl]     (--abl: the ablation library, CREID_STEM_ABL sweeps)"""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import argparse
 import os
 import sys

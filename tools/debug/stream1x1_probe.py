@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import os, sys
 sys.path.insert(0, ".")
 import torch

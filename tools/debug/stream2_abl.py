@@ -1,4 +1,5 @@
 """Timing ablation of igemm1x1_stream2_kernel (ablation build; one process per CREID_STREAM2_ABL value)."""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import os
 import sys
 import torch

@@ -1,6 +1,7 @@
 """Per-shape timing of the second persistent 1x1 kernel against the shipped plans (run on the GPU box): the K = 64 / 128 stride-1
 1x1 layers of ResNet50 256x128 -- training forward with the statistics epilogue at B = 64, folded eval-mode epilogue (conv3: +
 residual + ReLU) at B = 128."""
+import os as _os; _os.environ.setdefault("CREID_DEBUG_KNOBS", "1")   # the CREID_* knobs below are flipped inside this process (csrc/common.hpp)
 import os
 import sys
 import torch

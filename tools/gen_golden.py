@@ -255,10 +255,10 @@ def gen_losses(ref, name, N, D, C, seed):
 def gen_backbone(ref, name, arch, B, H, W):
     from oracle import backbone_oracle as bo
     sd = bo.make_state_dict(arch, 1, seed=1234)
-    if arch == "resnet50":
-        net = ref.resnet.ResNet(last_stride=1, block=ref.resnet.Bottleneck, layers=[3, 4, 6, 3])
+    if arch.endswith("_ibn_a"):
+        net = getattr(ref.resnet_ibn_a, arch)(1)
     else:
-        net = ref.resnet_ibn_a.resnet50_ibn_a(1)
+        net = ref.resnet.ResNet(last_stride=1, block=ref.resnet.Bottleneck, layers=list(bo.ARCH_LAYERS[arch]))
     missing = net.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys, missing.unexpected_keys
     assert all(k.startswith("fc.") for k in missing.missing_keys), missing.missing_keys
@@ -284,7 +284,7 @@ def gen_backbone(ref, name, arch, B, H, W):
     rec["grad_l2_ds_slice"] = net.layer2[0].downsample[0].weight.grad[:8, :, 0, 0].numpy().copy()
     rec["grad_bn1_w"] = net.bn1.weight.grad.numpy().copy(); rec["grad_bn1_b"] = net.bn1.bias.grad.numpy().copy()
     rec["grad_l3_bn2_w"] = net.layer3[1].bn2.weight.grad.numpy().copy()
-    if arch != "resnet50":
+    if arch.endswith("_ibn_a"):
         rec["grad_l1_in_w"] = net.layer1[0].bn1.IN.weight.grad.numpy().copy()
     gsum = 0.0
     for p in net.parameters():
@@ -300,7 +300,7 @@ def gen_backbone(ref, name, arch, B, H, W):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.load()
-    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed", "transforms")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
+    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed", "transforms", "deep")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
     if "eval" in which:
         gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
         gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
@@ -503,6 +503,12 @@ def gen_surface_r2():
 
 if __name__ == "__main__" and "surface_r2" in sys.argv[1:]:
     gen_surface_r2()
+
+
+if __name__ == "__main__" and "deep" in sys.argv[1:]:
+    # the deeper Bottleneck variants of MODEL.NAME (modelling/baseline.py:73-81): one small recording each
+    for _arch, _tag in (("resnet101", "r101"), ("resnet152", "r152"), ("resnet101_ibn_a", "r101ibn")):
+        gen_backbone(ref_import.load(), f"backbone_{_tag}_2x64x64", _arch, 2, 64, 64)
 
 
 if __name__ == "__main__" and "ibn320" in sys.argv[1:]:
