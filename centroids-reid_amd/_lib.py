@@ -73,6 +73,11 @@ SIGNATURES = {
     "creid_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p]),
     "creid_adam_step_dev": (C.c_int, [_p, _p, _p, _p, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p]),
     "creid_sgd_scaled_step": (C.c_int, [_p, _p, _i64, _f32, _f32, _p]),
+    "creid_amp_scale": (C.c_int, [_p, _i64, _p, _p, _p]),
+    "creid_amp_unscale_check": (C.c_int, [_p, _i64, _p, _p, _p]),
+    "creid_amp_update": (C.c_int, [_p, _p, _f32, _f32, C.c_int32, _p]),
+    "creid_adam_step_dev_amp": (C.c_int, [_p, _p, _p, _p, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p, _p]),
+    "creid_sgd_scaled_step_amp": (C.c_int, [_p, _p, _i64, _f32, _f32, _p, _p]),
     "creid_conv2d_bn_partial_rows": (_i64, [_p]),
     "creid_conv2d_fwd_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p]),
     "creid_conv2d_fwd_affine_nhwc": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),

@@ -265,7 +265,9 @@ class BackboneEngine:
         # CREID_FIN_CARRIER: "wgrad" (above) | "wred" (finalize and the pending split reduction share one launch between the data
         # gradient and the apply; launch order wgrad -> dgrad as before) | "none"
         carrier = os.environ.get("CREID_FIN_CARRIER", "wgrad")
-        if os.environ.get("CREID_BNFIN_PIGGYBACK", "1") != "1" or not (self.wred_piggyback and dtype == torch.bfloat16):
+        is16 = dtype in (torch.bfloat16, torch.float16)
+        self.loss_scaler = None        # f16 training: solver.LossScaler; backward() multiplies the incoming head gradient by its scale
+        if os.environ.get("CREID_BNFIN_PIGGYBACK", "1") != "1" or not (self.wred_piggyback and is16):
             carrier = "none"
         self.bnfin_piggyback = carrier == "wgrad"
         self.fin_with_wred = carrier == "wred"
@@ -283,7 +285,7 @@ class BackboneEngine:
         self.saved = None
         # training forward writes each ReLU's mask as bits (1 byte per 8 channels); the BatchNorm backward and the fused
         # data-gradient epilogue read that instead of re-reading the activation (CREID_RELU_BITMASK=0: read the activation)
-        self.relu_bitmask = dtype == torch.bfloat16 and os.environ.get("CREID_RELU_BITMASK", "1") == "1"
+        self.relu_bitmask = is16 and os.environ.get("CREID_RELU_BITMASK", "1") == "1"
         self.stem_fuse_pool = os.environ.get("CREID_STEM_FUSE", "1") == "1"    # bn1 + maxpool in one pass (38 vs 51 us)
         self.stem_pool_fused = os.environ.get("CREID_STEM_POOL", "1") == "1"   # eval: conv1 + bn1 + maxpool in one launch
         self.pair_fused = os.environ.get("CREID_PAIR_FUSE", "1") == "1"        # eval, layer1: conv3 of block i + conv1 of block i + 1
@@ -291,7 +293,7 @@ class BackboneEngine:
         # the gather is VALU-bound and runs twice (146 vs 116 us, tools/debug/stem_tail_probe.py) -- off by default
         self.stem_fuse_pool_bwd = os.environ.get("CREID_STEM_FUSE_BWD", "0") == "1"
         self.drop_gm = os.environ.get("CREID_DROP_GM", "1") == "1"     # A/B knob: 0 = bn3's backward still writes the masked copy
-        self.fuse_bn_reduce = dtype == torch.bfloat16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
+        self.fuse_bn_reduce = is16 and os.environ.get("CREID_FUSE_BN_REDUCE", "1") == "1" \
             and os.environ.get("CREID_IGEMM_DMA", "1") == "1"
         self._pending_steps = None     # device counter of training forwards not yet folded into num_batches_tracked
         # eval-mode forward: BatchNorm (running statistics = constants) folded into the producing convolution's epilogue --
@@ -627,10 +629,8 @@ class BackboneEngine:
         B, _, H, W = x_nchw.shape
         if not training and self.eval_fold:
             return self._forward_eval_folded(x_nchw, want_base_out)
-        if training and self.dtype == torch.float16:
-            # f16 (the reference's precision=16, utils/misc.py:111) is an eval / inference compute type here: the weight-gradient
-            # kernels and the loss scaling its training would need are not built -- train in bf16 or fp32
-            raise NotImplementedError("compute dtype float16 covers the eval-mode / inference forward only; train in bfloat16 or float32")
+        # (f16 -- the reference's precision=16, utils/misc.py:111 -- trains like bf16; its gradients need the dynamic loss scale
+        # that ModelBase.configure_optimizers attaches as `loss_scaler`: solver.LossScaler)
         sv = {"B": B, "H": H, "W": W, "training": training}
         if training:      # one counter kernel per step instead of 53 per-layer `num_batches_tracked += 1`
             if self._pending_steps is None:
@@ -836,6 +836,8 @@ class BackboneEngine:
         B = sv["B"]
         h, w = sv["final"]
         dfeat = dfeat.contiguous().float()
+        if self.loss_scaler is not None and self.dtype == torch.float16:
+            dfeat = self.loss_scaler.scale_(dfeat)        # every f16 gradient tensor / backbone parameter gradient below is scaled
         g = self._empty(B * h * w, 2048)
         L.check(lib.creid_gap_bwd(L.ptr(dfeat), B, h * w, 2048, self.dt, L.ptr(g), st), "gap_bwd")
         blocks = list(zip(self.blocks, sv["blocks"]))

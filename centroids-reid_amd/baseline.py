@@ -34,11 +34,13 @@ class Baseline(nn.Module):
         # through global_feat only.
         self.return_base_out = True
         self._engine = None
+        self.loss_scaler = None           # f16 training: solver.LossScaler (ModelBase.configure_optimizers attaches it)
 
     @property
     def engine(self):
         if self._engine is None or self._engine.dtype != self.compute_dtype:
             self._engine = bb.BackboneEngine(self.base, self.compute_dtype)
+        self._engine.loss_scaler = self.loss_scaler
         return self._engine
 
     def state_dict(self, *args, **kwargs):

@@ -125,6 +125,13 @@ class ModelBase(_Base):
     def configure_optimizers(self):
         optimizers_list = build_optimizer(self.named_parameters(), self.hparams)
         self.lr_scheduler = build_scheduler(optimizers_list[0], self.hparams)
+        if getattr(self.backbone, "compute_dtype", None) == torch.float16 and optimizers_list[0].flat.is_cuda:
+            # the reference's precision=16 (utils/misc.py:111): f16 backbone + dynamic loss scale, state on the device
+            from .solver import LossScaler
+            self.loss_scaler = LossScaler(optimizers_list[0].flat.device)
+            optimizers_list[0].attach_scaler(self.loss_scaler)
+            optimizers_list[1].scaler = self.loss_scaler
+            self.backbone.loss_scaler = self.loss_scaler
         if pl is None:
             self._optimizers = optimizers_list
         return optimizers_list, self.lr_scheduler

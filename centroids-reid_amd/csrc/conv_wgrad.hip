@@ -202,7 +202,9 @@ template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_
 // and fragment reads) over HALF of the split's pixel range on the SAME output tile; at the end group 1 hands its accumulators to
 // group 0 through LDS (fixed order: deterministic) and one partial tile leaves the CU.  Same waves per CU as two workgroups of
 // a split twice as fine, half the fp32 partial-tile traffic (write here + re-read by the split reduction).
-template <int TM, int TN, int NS, bool WS = false, int KG = 1>
+// ET = element type traits (common.hpp Bf16T / F16T): the operands move as raw 16-bit words (DMA, transposing LDS reads), so the
+// element type only selects the MFMA instruction -- f16 is the reference's own mixed precision (utils/misc.py:111, precision=16)
+template <int TM, int TN, int NS, bool WS = false, int KG = 1, typename ET = Bf16T>
 __global__ __launch_bounds__(WS ? 512 : 256 * KG, (KG * NS * (TM + TN) * 128 <= 80 * 1024) ? ((WS || KG == 2) ? 4 : 2) : ((WS || KG == 2) ? 2 : 1)) void wgrad_bf16_dma_kernel(IGemmGeom g, const unsigned short* __restrict__ dy,
                                                                  const unsigned short* __restrict__ x, int NCO,
                                                                  float* __restrict__ ws, int tiles_k, int m_per_split,
@@ -428,8 +430,7 @@ __global__ __launch_bounds__(WS ? 512 : 256 * KG, (KG * NS * (TM + TN) * 128 <= 
       if (!CREID_ABL_ON(abl, 1)) {                                                                                 \
       _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                     \
         _Pragma("unroll") for (int j = 0; j < JN; ++j)                                                   \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),          \
-                                                              __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0); \
+          acc[i][j] = ET::mfma(a[i], b[j], acc[i][j]);                                                   \
       }                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
     }
@@ -706,12 +707,12 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype, int stride = 1) {
   // reduction riding on the next launch: 256 / 384 / 512 / 768 -> 7.20 / 7.10 / 7.08 / 7.18 ms per step).
   static const int target = [] { const char* e = getenv("CREID_WGRAD_TARGET_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   static const int max_splits_pref = [] { const char* e = getenv("CREID_WGRAD_MAX_SPLITS"); int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 30); }();
-  const int ks = (dtype == CREID_BF16) ? WKS : WKF;
+  const int ks = creid_is16(dtype) ? WKS : WKF;
   const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   WgradPlan p;
   p.stages = 0; p.ws = 0; p.kg = 0;
   TunePlan tp;
-  if (dtype == CREID_BF16 && creid_tune_lookup(CREID_TUNE_WGRAD, M, NCO, K, stride << 1, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
+  if (creid_is16(dtype) && creid_tune_lookup(CREID_TUNE_WGRAD, M, NCO, K, stride << 1, tp) && (tp.p0 == 64 || tp.p0 == 128) &&
       (tp.p1 == 64 || tp.p1 == 128) && NCO % tp.p0 == 0 && K % tp.p1 == 0 && tp.p2 >= 1) {
     // measured plan for this shape: tile tp.p0 x tp.p1, tp.p2 = pixel splits | ring depth << 16 | producer/consumer << 20 |
     // two k-groups << 21
@@ -741,7 +742,7 @@ static WgradPlan plan_wgrad(int M, int NCO, int K, int dtype, int stride = 1) {
     // pixel ranges; CREID_WGRAD_XCD=0 keeps the round-1 rule
     static const int xcd_mode = [] { const char* e = getenv("CREID_WGRAD_XCD"); return e ? atoi(e) : 1; }();
     p.xcd = 0;
-    if (xcd_mode && dtype == CREID_BF16) {
+    if (xcd_mode && creid_is16(dtype)) {
       if (splits >= 8) { splits = (splits + 4) / 8 * 8; p.xcd = 1; }                     // nearest multiple of 8
       else if (xcd_mode >= 2) { splits = splits >= 6 ? 8 : (splits >= 3 ? 4 : splits); p.xcd = 1; }   // 1, 2, 4, 8
     }
@@ -783,34 +784,33 @@ static bool launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
   static const int stages_env = [] { const char* e = getenv("CREID_WGRAD_STAGES"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 2; }();
   static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
   const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0 && stem_dma;
-  if (dtype == CREID_BF16 && use_dma && ((1 << g.log2span) >= TN || stem_geom)) {
+  if (creid_is16(dtype) && use_dma && ((1 << g.log2span) >= TN || stem_geom)) {
     static const int use_ws_env = [] { const char* e = getenv("CREID_WGRAD_WS"); return e ? atoi(e) : 0; }();
     const int use_ws = p.ws ? 1 : use_ws_env;
     const int stages = (p.stages >= 2 && p.stages <= 4) ? p.stages : stages_env;
     static const int kg_env = [] { const char* e = getenv("CREID_WGRAD_KG"); return e ? atoi(e) : 0; }();
     const bool kg2 = (p.kg || kg_env == 2) && !use_ws && !stem_geom;
     constexpr bool kg3_fits = 2 * 3 * (TM + TN) * 128 <= 160 * 1024;
+#define CREID_WG_LAUNCH(NS_, WS_, KG_, BLOCK_)                                                                                   \
+    do {                                                                                                                          \
+      if (dtype == CREID_F16)                                                                                                     \
+        hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, NS_, WS_, KG_, F16T>), grid_dma, BLOCK_, 0, s, g, (const unsigned short*)dy, \
+                           (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);               \
+      else                                                                                                                        \
+        hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, NS_, WS_, KG_, Bf16T>), grid_dma, BLOCK_, 0, s, g, (const unsigned short*)dy, \
+                           (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);               \
+    } while (0)
     if (kg2 && stages >= 3 && kg3_fits) {
-      if constexpr (kg3_fits)
-        hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 3, false, 2>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
-                           (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
-    } else if (kg2)
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, false, 2>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
-    else if (use_ws && !stem_geom)
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2, true>), grid_dma, dim3(512), 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
-    else if (stages == 2)
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 2>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
-    else if (stages == 3)
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 3>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
-    else
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TM, TN, 4>), grid_dma, block, 0, s, g, (const unsigned short*)dy,
-                         (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split, xt, p.splits, fin, wg_abl);
+      if constexpr (kg3_fits) CREID_WG_LAUNCH(3, false, 2, dim3(512));
+    } else if (kg2) CREID_WG_LAUNCH(2, false, 2, dim3(512));
+    else if (use_ws && !stem_geom) CREID_WG_LAUNCH(2, true, 1, dim3(512));
+    else if (stages == 2) CREID_WG_LAUNCH(2, false, 1, block);
+    else if (stages == 3) CREID_WG_LAUNCH(3, false, 1, block);
+    else CREID_WG_LAUNCH(4, false, 1, block);
+#undef CREID_WG_LAUNCH
     return fin.partial != nullptr;
   }
+  else if (dtype == CREID_F16) return false;                     // (run_wgrad refuses f16 shapes the DMA kernels do not cover)
   else if (dtype == CREID_BF16)
     hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN>), grid, block, 0, s, g, (const unsigned short*)dy,
                        (const unsigned short*)x, NCO, ws, p.tiles_k, p.m_per_split);
@@ -823,8 +823,17 @@ static bool launch_wgrad_t(const IGemmGeom& g, const void* dy, const void* x, in
 static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO, float* dw, int kw_taps, int cpitch,
                      int cin, int kh, int kw, int accumulate, void* ws, size_t ws_bytes, int dtype, hipStream_t s,
                      int phases = 3, const BnBwdFinJob* fin = nullptr) {
-  if (dtype != CREID_BF16 && dtype != CREID_F32) return CREID_E_DTYPE;
+  if (!creid_is16(dtype) && dtype != CREID_F32) return CREID_E_DTYPE;
+  // f16 exists in the LDS-DMA kernels only (no register-staged fallback): shapes those do not cover are refused, not mis-run
+  if (dtype == CREID_F16) {
+    static const int dma_on = [] { const char* e = getenv("CREID_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+    if (!dma_on) return CREID_E_DTYPE;
+  }
   const WgradPlan p = plan_wgrad(g.M, NCO, g.K, dtype, g.stride);
+  if (dtype == CREID_F16 && (phases & 1)) {
+    const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0;
+    if (!((1 << g.log2span) >= p.tn || stem_geom)) return CREID_E_SHAPE;
+  }
   const size_t need = (size_t)p.splits * NCO * g.K * sizeof(float);
   if (ws_bytes < need) return CREID_E_WS;
   if (phases & 1) {

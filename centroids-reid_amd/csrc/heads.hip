@@ -605,7 +605,8 @@ __global__ void adam_advance_kernel(float* __restrict__ hyper, float b1, float b
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                        const float* __restrict__ hyper, float b1, float b2, float eps,
-                                                       float wd, float gscale) {
+                                                       float wd, float gscale, const int32_t* __restrict__ skip = nullptr) {
+  if (skip && skip[0]) return;                                // f16 training: a non-finite gradient skips the whole step
   const float lr = hyper[0], bc1 = hyper[2], bc2s = hyper[3];
   const float step_size = lr / bc1;
   const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -627,13 +628,62 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 }
 
 __global__ __launch_bounds__(256) void sgd_scaled_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n,
-                                                         float lr, float gmul) {
+                                                         float lr, float gmul, const int32_t* __restrict__ skip = nullptr) {
+  if (skip && skip[0]) return;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const float gv = g[i] * gmul;     // train_ctl_model.py:157-158 rescale (kept in .grad like the reference)
     g[i] = gv;
     p[i] = p[i] - lr * gv;
   }
+}
+
+
+// ======================================================================================
+// f16 mixed-precision training (the reference's precision=16, utils/misc.py:111): dynamic loss scale RESIDENT ON THE DEVICE with
+// torch.cuda.amp.GradScaler's rule (x backoff on a non-finite gradient, x growth after `interval` clean steps), so that a
+// captured hipGraph of the step replays correctly through overflow steps -- no host synchronisation anywhere.
+//   amp_state = float[2] {scale, 1 / scale};  amp_flags = int32[2] {found_inf of the current step, clean steps in a row}
+// ======================================================================================
+__global__ __launch_bounds__(256) void amp_scale_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ state,
+                                                        float* __restrict__ y) {
+  const float s = state[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * s;
+}
+
+// g *= 1 / scale in place; any non-finite element raises flags[0] (the step is then skipped by the *_amp optimiser kernels)
+__global__ __launch_bounds__(256) void amp_unscale_check_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ state,
+                                                                int32_t* __restrict__ flags) {
+  const float inv = state[1];
+  bool bad = false;
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  for (int64_t i = i0; i + 3 < n; i += stride) {             // n % 4 == 0 (flat buffer offsets are 16-byte aligned)
+    float4 v = *reinterpret_cast<float4*>(g + i);
+    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+    // (x - x) is 0 for finite x and NaN for +-inf / NaN: one test per element without the class intrinsics
+    bad |= !((v.x - v.x) == 0.f) | !((v.y - v.y) == 0.f) | !((v.z - v.z) == 0.f) | !((v.w - v.w) == 0.f);
+    *reinterpret_cast<float4*>(g + i) = v;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+}
+
+__global__ void amp_update_kernel(float* __restrict__ state, int32_t* __restrict__ flags, float growth, float backoff,
+                                  int interval) {
+  float s = state[0];
+  if (flags[0]) { s *= backoff; flags[1] = 0; }
+  else if (++flags[1] >= interval) { s *= growth; flags[1] = 0; }
+  s = fminf(fmaxf(s, 1.0f), 16777216.0f);                     // keep 1 / scale and scale * gradient representable
+  state[0] = s; state[1] = 1.0f / s;
+  flags[0] = 0;
+}
+
+__global__ void adam_advance_amp_kernel(float* __restrict__ hyper, float b1, float b2, const int32_t* __restrict__ skip) {
+  if (skip[0]) return;                                        // an overflow step does not count (GradScaler.step skips optimizer.step)
+  const float step = hyper[1] + 1.0f;
+  hyper[1] = step;
+  hyper[2] = 1.0f - powf(b1, step);
+  hyper[3] = sqrtf(1.0f - powf(b2, step));
 }
 
 
@@ -1201,6 +1251,56 @@ int creid_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
     hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper_dev, beta1, beta2,
                        eps, weight_decay, grad_scale);
   }
+  CREID_LAUNCH_RET();
+}
+
+int creid_amp_scale(const float* x, int64_t n, const float* amp_state, float* y, void* stream) {
+  CREID_CHECK_ARG(x && y && amp_state && n > 0);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(amp_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, n, amp_state, y);
+  CREID_LAUNCH_RET();
+}
+
+int creid_amp_unscale_check(float* g, int64_t n, const float* amp_state, int32_t* amp_flags, void* stream) {
+  CREID_CHECK_ARG(g && amp_state && amp_flags && n >= 0);
+  if (n % 4 != 0) return CREID_E_SHAPE;
+  if (n == 0) return 0;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(amp_unscale_check_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, n, amp_state, amp_flags);
+  CREID_LAUNCH_RET();
+}
+
+int creid_amp_update(float* amp_state, int32_t* amp_flags, float growth_factor, float backoff_factor, int32_t growth_interval,
+                     void* stream) {
+  CREID_CHECK_ARG(amp_state && amp_flags && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0);
+  hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, as_stream(stream), amp_state, amp_flags, growth_factor, backoff_factor,
+                     (int)growth_interval);
+  CREID_LAUNCH_RET();
+}
+
+int creid_adam_step_dev_amp(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev, float beta1, float beta2,
+                            float eps, float weight_decay, float grad_scale, const int32_t* skip_flag, void* stream) {
+  CREID_CHECK_ARG(p && g && m && v && hyper_dev && skip_flag && n >= 0);
+  if (n % 4 != 0) return CREID_E_SHAPE;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(adam_advance_amp_kernel, dim3(1), dim3(1), 0, s, hyper_dev, beta1, beta2, skip_flag);
+  if (n > 0) {
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper_dev, beta1, beta2, eps,
+                       weight_decay, grad_scale, skip_flag);
+  }
+  CREID_LAUNCH_RET();
+}
+
+int creid_sgd_scaled_step_amp(float* p, float* g, int64_t n, float lr, float grad_mul, const int32_t* skip_flag, void* stream) {
+  CREID_CHECK_ARG(p && g && skip_flag && n >= 0);
+  if (n == 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sgd_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, n, lr, grad_mul, skip_flag);
   CREID_LAUNCH_RET();
 }
 

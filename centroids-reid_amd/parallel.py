@@ -46,7 +46,8 @@ def make_grad_sync(world):
         if getattr(opt_c, "grad_in_adam_tail", False):          # (re-checked per call: .grad may have been rebound, solver.CenterSGD)
             opt_c.grad_scale = 1.0 / world
         else:
-            opt_c.grad_scale = 1.0
+            if hasattr(opt_c, "grad_scale"):
+                opt_c.grad_scale = 1.0
             cg = model.center_loss.centers.grad
             dist.all_reduce(cg, op=dist.ReduceOp.SUM)
             cg.mul_(1.0 / world)
@@ -126,7 +127,8 @@ def make_overlapped_grad_sync(model, world, groups=None):
     opt.grad_scale = 1.0 / world
     if hasattr(opt_c, "readopt_tail"):
         opt_c.readopt_tail()                                      # gradients rebound before the sync was built: back into the tail
-    opt_c.grad_scale = 1.0 / world if getattr(opt_c, "grad_in_adam_tail", False) else 1.0
+    if hasattr(opt_c, "grad_scale"):
+        opt_c.grad_scale = 1.0 / world if getattr(opt_c, "grad_in_adam_tail", False) else 1.0
     side = torch.cuda.Stream()
     layer_to_bucket = {}
     for i, g in enumerate(groups):
@@ -150,7 +152,8 @@ def make_overlapped_grad_sync(model, world, groups=None):
             _launch(state["next"]); state["next"] += 1
         # evaluated at every step: a gradient rebound away from the tail since the last one takes the explicit all-reduce
         tail = getattr(opt_c, "grad_in_adam_tail", False)
-        opt_c.grad_scale = 1.0 / world if tail else 1.0
+        if hasattr(opt_c, "grad_scale"):
+            opt_c.grad_scale = 1.0 / world if tail else 1.0
         if not tail:
             cg = model.center_loss.centers.grad
             side.wait_stream(torch.cuda.current_stream())

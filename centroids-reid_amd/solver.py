@@ -37,6 +37,51 @@ def flatten_(params, device, grad_tail=0):
     return flat, gflat
 
 
+class LossScaler:
+    """Dynamic loss scale of f16 mixed-precision training (the reference's `precision=16`, utils/misc.py:111 = native AMP with
+    torch.cuda.amp.GradScaler: init 2**16, x 0.5 on a non-finite gradient, x 2 after 2000 clean steps) with ALL of its state on
+    the device: {scale, 1 / scale} and {found_inf, clean steps}.  Nothing here synchronises with the host, so a captured
+    hipGraph of the training step replays correctly through overflow steps (the skipped update, the halved scale and Adam's
+    un-advanced step counter are all decided by the kernels: csrc/heads.hip amp_*).
+
+    Where it acts: `scale_(dfeat)` multiplies the heads' gradient as it ENTERS the f16 backbone backward (the heads run in
+    fp32 and need no scaling; every f16 gradient tensor and every backbone parameter gradient downstream is then scaled);
+    FusedAdam.step unscales the backbone prefix of its flat gradient buffer in place, checks it for inf / nan and skips itself
+    when one is found; CenterSGD.step skips with it; `update()` applies GradScaler's growth / backoff rule and clears the flag."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 1.0 / init_scale], dtype=torch.float32, device=device)
+        self.flags = torch.zeros(2, dtype=torch.int32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+
+    def scale_(self, x):
+        y = torch.empty_like(x)
+        L.check(L.lib().creid_amp_scale(L.ptr(x), x.numel(), L.ptr(self.state), L.ptr(y), L.stream()), "creid_amp_scale")
+        return y
+
+    def unscale_check_(self, g):
+        L.check(L.lib().creid_amp_unscale_check(L.ptr(g), g.numel(), L.ptr(self.state), L.ptr(self.flags), L.stream()),
+                "creid_amp_unscale_check")
+
+    def update(self):
+        L.check(L.lib().creid_amp_update(L.ptr(self.state), L.ptr(self.flags), self.growth_factor, self.backoff_factor,
+                                         self.growth_interval, L.stream()), "creid_amp_update")
+
+    def get_scale(self):            # (host read-back: diagnostics / tests only)
+        return float(self.state[0].item())
+
+    def state_dict(self):
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self.flags[1].item())}
+
+    def load_state_dict(self, sd):
+        s = float(sd["scale"])
+        self.state.copy_(torch.tensor([s, 1.0 / s], dtype=torch.float32))
+        self.flags.copy_(torch.tensor([0, int(sd.get("_growth_tracker", 0))], dtype=torch.int32))
+        self.growth_factor, self.backoff_factor = float(sd.get("growth_factor", 2.0)), float(sd.get("backoff_factor", 0.5))
+        self.growth_interval = int(sd.get("growth_interval", 2000))
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (L2 weight decay in the gradient) -- one kernel over the flat buffer."""
 
@@ -49,6 +94,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.grad_scale = 1.0
+        self.scaler, self.n_scaled = None, 0       # f16 training: LossScaler + length of the loss-scaled prefix of gflat
         # device-resident {lr, step, bc1, bc2s}: keeps a captured hipGraph of the step valid
         self.hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
         self._lr_on_device = None
@@ -86,6 +132,18 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.gflat.zero_()
 
+    def attach_scaler(self, scaler, scaled_prefix_names=("backbone.",)):
+        """f16 training: gradients of the parameters whose name starts with one of `scaled_prefix_names` (the f16 backbone)
+        arrive multiplied by the loss scale; they must form a PREFIX of the flat buffer (they do: the backbone is the first
+        module of ModelBase, solver/build.py keeps named_parameters order), which step() unscales and checks in one pass."""
+        names = self.param_groups[0].get("names")
+        assert names is not None and len(names) == len(self._params), "attach_scaler needs the reference's 'names' key"
+        scaled = [n.startswith(tuple(scaled_prefix_names)) for n in names]
+        k = sum(scaled)
+        assert all(scaled[:k]) and not any(scaled[k:]), "loss-scaled parameters must be a prefix of the flat gradient buffer"
+        self.n_scaled = self._offsets[k] if k < len(self._params) else self.flat.numel()
+        self.scaler = scaler
+
     @property
     def step_count(self):
         return int(self.hyper[1].item())
@@ -104,6 +162,15 @@ class FusedAdam(torch.optim.Optimizer):
             self.hyper[0:1].copy_(torch.tensor([lr], dtype=torch.float32))
             self._lr_on_device = lr
         b1, b2 = g["betas"]
+        if self.scaler is not None:
+            # (after the data-parallel all-reduce: a non-finite value on any rank has reached every rank's buffer by now, so all
+            # ranks skip the same steps without a collective of their own)
+            self.scaler.unscale_check_(self.gflat[:self.n_scaled])
+            L.check(L.lib().creid_adam_step_dev_amp(L.ptr(self.flat), L.ptr(self.gflat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                                    self.flat.numel(), L.ptr(self.hyper), b1, b2, g["eps"], g["weight_decay"],
+                                                    float(self.grad_scale), L.ptr(self.scaler.flags), L.stream()),
+                    "creid_adam_step_dev_amp")
+            return
         L.check(L.lib().creid_adam_step_dev(L.ptr(self.flat), L.ptr(self.gflat), L.ptr(self.exp_avg),
                                             L.ptr(self.exp_avg_sq), self.flat.numel(), L.ptr(self.hyper), b1, b2,
                                             g["eps"], g["weight_decay"], float(self.grad_scale), L.stream()),
@@ -119,6 +186,7 @@ class CenterSGD(torch.optim.Optimizer):
         self.grad_mul = 1.0
         self.grad_scale = 1.0          # data-parallel 1 / world when the gradient was SUM-reduced inside the Adam buffer's tail
         self._tail = None
+        self.scaler = None             # f16 training: the step is skipped together with Adam's on a non-finite backbone gradient
 
     @property
     def grad_in_adam_tail(self):
@@ -171,6 +239,11 @@ class CenterSGD(torch.optim.Optimizer):
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
+                    continue
+                if self.scaler is not None:
+                    L.check(L.lib().creid_sgd_scaled_step_amp(L.ptr(p.data), L.ptr(p.grad), p.numel(), float(g["lr"]),
+                                                              float(self.grad_mul) * float(self.grad_scale),
+                                                              L.ptr(self.scaler.flags), L.stream()), "creid_sgd_scaled_step_amp")
                     continue
                 L.check(L.lib().creid_sgd_scaled_step(L.ptr(p.data), L.ptr(p.grad), p.numel(), float(g["lr"]),
                                                       float(self.grad_mul) * float(self.grad_scale), L.stream()), "creid_sgd_scaled_step")

@@ -76,6 +76,9 @@ class CTLModel(ModelBase):
             eng.weights_dirty = True
         opt_center.grad_mul = 1.0 / hp.SOLVER.CENTER_LOSS_WEIGHT               # :157-158 (fused into the step)
         opt_center.step()                                                      # :159
+        scaler = getattr(self, "loss_scaler", None)
+        if scaler is not None:
+            scaler.update()                                                    # f16: GradScaler.update() after both steps
 
     def forward_backward(self, batch, batch_idx=0):
         hp = self.hparams

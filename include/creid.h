@@ -322,6 +322,24 @@ int creid_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
 /* train_ctl_model.py:157-159 + solver/build.py:44: g *= grad_mul (in place); p -= lr * g. */
 int creid_sgd_scaled_step(float* p, float* g, int64_t n, float lr, float grad_mul, void* stream);
 
+/* f16 mixed-precision training -- the reference's own mixed precision (utils/misc.py:111 `precision=16`, i.e. native AMP with
+ * torch.cuda.amp.GradScaler under pytorch-lightning 1.1.4) -- with the dynamic loss scale RESIDENT ON THE DEVICE, so that the
+ * step contains no host synchronisation and a captured hipGraph replays through overflow steps:
+ *   amp_state = float[2] {scale, 1 / scale}; amp_flags = int32[2] {found_inf of this step, clean steps in a row}.
+ * creid_amp_scale          y = x * scale (the head gradient entering the f16 backbone backward);
+ * creid_amp_unscale_check  g *= 1 / scale in place over n (% 4 == 0) floats, any non-finite element sets amp_flags[0];
+ * creid_adam_step_dev_amp / creid_sgd_scaled_step_amp  = the plain steps, skipped entirely (Adam's step counter included) while
+ *                          *skip_flag != 0 (GradScaler.step);
+ * creid_amp_update         found_inf ? scale *= backoff : (after growth_interval clean steps) scale *= growth; clears found_inf
+ *                          (GradScaler.update; scale clamped to [1, 2^24]). */
+int creid_amp_scale(const float* x, int64_t n, const float* amp_state, float* y, void* stream);
+int creid_amp_unscale_check(float* g, int64_t n, const float* amp_state, int32_t* amp_flags, void* stream);
+int creid_amp_update(float* amp_state, int32_t* amp_flags, float growth_factor, float backoff_factor, int32_t growth_interval,
+                     void* stream);
+int creid_adam_step_dev_amp(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev, float beta1, float beta2,
+                            float eps, float weight_decay, float grad_scale, const int32_t* skip_flag, void* stream);
+int creid_sgd_scaled_step_amp(float* p, float* g, int64_t n, float lr, float grad_mul, const int32_t* skip_flag, void* stream);
+
 /* ------------------------------------------------------------------ small fp32 GEMM */
 
 /* Classifier of the BNNeck head (modelling/bases.py:86-87 fc_query = Linear(D -> C, bias=False);

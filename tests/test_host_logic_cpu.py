@@ -55,3 +55,28 @@ def test_feature_width_padding_changes_no_distance():
     d_p = (p.double()[:, None] - p.double()[None]).pow(2).sum(-1)
     d_f = (f.double()[:, None] - f.double()[None]).pow(2).sum(-1)
     assert torch.allclose(d_p, d_f, rtol=1e-13, atol=0)     # zero columns add zeros to every sum (reduction trees may differ)
+
+
+def test_center_sgd_tail_adoption_is_rechecked_when_grad_is_rebound():
+    """the centers' gradient rides in the tail of the Adam gradient buffer only as long as `.grad` IS a view of that
+    tail.  `grad_in_adam_tail` is evaluated at every read, so a rebound gradient (zero_grad(set_to_none=True) in a foreign
+    wrapper, `p.grad = ...`) sends the data-parallel sync down the explicit all-reduce instead of stepping on an unreduced
+    gradient; readopt_tail() moves a rebound gradient back (values kept)."""
+    import torch
+    from centroids_reid_amd.solver import CenterSGD
+    c = torch.nn.Parameter(torch.zeros(5, 3))
+    tail = torch.zeros(16)
+    opt = CenterSGD([{"params": [c], "names": ["center_loss.centers"]}], lr=0.5)
+    assert opt.grad_in_adam_tail is False
+    opt.adopt_tail(tail)
+    assert opt.grad_in_adam_tail and c.grad.data_ptr() == tail.data_ptr()
+    c.grad.fill_(2.0)
+    assert float(tail[:15].sum()) == 30.0
+    c.grad = torch.full((5, 3), 7.0)                    # rebound by user code
+    assert opt.grad_in_adam_tail is False
+    opt.readopt_tail()
+    assert opt.grad_in_adam_tail and float(tail[:15].sum()) == 105.0 and float(c.grad.sum()) == 105.0
+    c.grad = None                                        # zero_grad(set_to_none=True) of a foreign wrapper
+    assert opt.grad_in_adam_tail is False
+    opt.readopt_tail()
+    assert opt.grad_in_adam_tail and float(tail.sum()) == 0.0
