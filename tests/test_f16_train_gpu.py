@@ -90,17 +90,26 @@ def test_f16_ctl_training_trajectory_tracks_fp32():
     assert curves[torch.float16][-1] < curves[torch.float16][0] - 0.5            # and it learns
 
 
-def test_f16_step_in_a_captured_graph_survives_an_overflow():
+def test_f16_step_in_a_captured_graph_survives_an_overflow(monkeypatch):
     """The f16 step captured ONCE into a hipGraph: replays equal eager steps bit for bit, and a replay whose gradients overflow
     (the scale forced to 2^24 on the device) skips its update, halves the scale and the following replays train on -- no host
     involvement between replays."""
+    from centroids_reid_amd import ops
     from centroids_reid_amd.bench_train import CAPTURE_MODE
+    monkeypatch.setattr(ops, "_DETERMINISTIC", True)          # single-pass classifier GEMMs: bit-reproducible steps
     P, K, H, W = 8, 4, 128, 64
     batches = _batches(P, K, H, W, 6)
-    eager = _model(torch.float16)
+    def fresh():
+        m = _model(torch.float16)
+        # GradScaler's start value (65536) is meant to overflow and back off during the first steps of a run; a settled scale keeps
+        # this test about the mechanism: no step below is skipped unless the test forces it
+        m.loss_scaler.state.copy_(torch.tensor([1024.0, 1.0 / 1024.0]))
+        return m
+    eager = fresh()
     for s in range(5):
         eager.training_step(batches[s], s)
-    model = _model(torch.float16)
+    assert eager.optimizers()[0].step_count == 5 and eager.loss_scaler.get_scale() == 1024.0
+    model = fresh()
     sx, sl = batches[0][0].clone(), batches[0][1].clone()
     static = (sx, sl, batches[0][2], batches[0][3])
     side = torch.cuda.Stream()
@@ -118,13 +127,8 @@ def test_f16_step_in_a_captured_graph_survives_an_overflow():
         sx.copy_(batches[s][0]); sl.copy_(batches[s][1])
         graph.replay()
     torch.cuda.synchronize()
-    import os
-    if os.environ.get("CREID_DETERMINISTIC", "0") == "1":
-        for (n, a), (_, b) in zip(eager.named_parameters(), model.named_parameters()):
-            assert torch.equal(a, b), n
-    else:
-        for (n, a), (_, b) in zip(eager.named_parameters(), model.named_parameters()):
-            assert torch.allclose(a, b, rtol=1e-3, atol=1e-5), n
+    for (n, a), (_, b) in zip(eager.named_parameters(), model.named_parameters()):
+        assert torch.equal(a, b), n
     # force an overflow: with a scale of 2^30 the very first f16 gradient tensor saturates
     sc = model.loss_scaler
     sc.state.copy_(torch.tensor([2.0 ** 30, 2.0 ** -30]))
@@ -133,6 +137,6 @@ def test_f16_step_in_a_captured_graph_survives_an_overflow():
     sx.copy_(batches[5][0]); sl.copy_(batches[5][1])
     graph.replay(); torch.cuda.synchronize()
     assert torch.equal(opt.flat, before) and opt.step_count == n0 and sc.get_scale() == 16777216.0    # halved, then clamped to 2^24
-    sc.state.copy_(torch.tensor([65536.0, 1.0 / 65536.0]))
+    sc.state.copy_(torch.tensor([1024.0, 1.0 / 1024.0]))
     graph.replay(); torch.cuda.synchronize()
     assert not torch.equal(opt.flat, before) and opt.step_count == n0 + 1 and np.isfinite(float(out["loss"]))

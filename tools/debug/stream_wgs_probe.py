@@ -13,7 +13,7 @@ from bench import time_kernel                      # noqa: E402
 
 L = rm.L
 lib = L.lib()
-out = [f"CREID_STREAM_WGS={os.environ.get('CREID_STREAM_WGS', '512 (default)')}"]
+out = [f"CREID_STREAM_WGS={os.environ.get('CREID_STREAM_WGS', '512 (default)')} CREID_STREAM_TPER={os.environ.get('CREID_STREAM_TPER', '8 (default)')}"]
 for nq, ng, npid in ((2228, 17661, 702), (3000, 15000, 702), (6250, 200_000, 50_000)):
     D = 2048
     gen = torch.Generator(device="cuda").manual_seed(4)

@@ -35,14 +35,25 @@ def blocks(B, H, W):
     return out
 
 
-def work(B, shape, what):
+def work(B, shape, what, role=None, bi=None):
+    """(FLOPs, algorithmic bytes) of one launch.  The data gradients carry fused passes whose operands count as their bytes:
+    c3 / c2: the column sums of the NEXT BatchNorm backward (bn2 / bn1: that layer's raw output + its ReLU bits, once);
+    c1: the block's incoming gradient added through the ReLU bits (residual branch; the compact downsample gradient in a
+    downsample block) and, except in the first block, the column sums of the previous block's bn3."""
     cin, cout, k, st, h, w = shape
     ho, wo = (h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1
     fl = 2.0 * B * ho * wo * cout * cin * k * k
     x, y = B * h * w * cin * 2, B * ho * wo * cout * 2
     if what == "dgrad" and st == 2 and k == 1:
         x = B * ho * wo * cin * 2                      # computed compact on the output grid, scatter-added by the c1 data gradient
-    return fl, x + y
+    extra = 0
+    if what == "dgrad" and role in ("c3", "c2"):
+        extra = x + x // 16                            # bn2 / bn1 statistics: raw conv output of the producing layer + mask bits
+    elif what == "dgrad" and role == "c1":
+        extra = x + x // 16                            # residual-branch gradient (+ bits)
+        if bi:
+            extra += x + x // 16                       # previous block's bn3: raw output + bits
+    return fl, x + y + extra
 
 
 def main(path, B=64, H=256, W=128):
@@ -92,7 +103,7 @@ def main(path, B=64, H=256, W=128):
             if what not in e:
                 continue
             kern, t = e[what]
-            fl, by = work(B, e["shape"], what)
+            fl, by = work(B, e["shape"], what, role, bi)
             if role == "stem":
                 fl = 2.0 * B * (H // 2) * (W // 2) * 64 * 147
                 by = B * (H + 8) * (W + 6) * 4 * 2 + B * (H // 2) * (W // 2) * 64 * 2
