@@ -109,6 +109,7 @@ SIGNATURES = {
     "creid_col_stats": (C.c_int, [_p, _i64, _i64, C.c_int, _p, _p]),
     "creid_bn2d_apply": (C.c_int, [_p, _p, _p, C.c_int, _i64, _i64, C.c_int, _p, _p]),
     "creid_bn2d_apply_mask": (C.c_int, [_p, _p, _p, C.c_int, _i64, _i64, C.c_int, _p, _p, _p]),
+    "creid_bn2d_finalize_apply_mask": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int, _p]),
     "creid_bn2d_apply_dual_mask": (C.c_int, [_p, _p, _p, _p, C.c_int, _i64, _i64, C.c_int, _p, _p, _p]),
     "creid_bn2d_bwd_rows": (_i64, [_i64]),
     "creid_bn2d_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),

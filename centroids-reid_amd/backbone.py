@@ -310,6 +310,11 @@ class BackboneEngine:
         # bit 1 their backward apply launches -- the upper bound of what fusing those passes into the consuming / producing
         # convolutions could save (profiles/r03_bn_fusion_bound.md)
         self.dual_apply = os.environ.get("CREID_DUAL_APPLY", "1") == "1"     # A/B knob: 0 = separate downsample-BN apply launch
+        # training forward: BatchNorm finalize + apply as ONE launch on layers with at most this many statistic rows (M <= 8192 by
+        # default: 24 launches less per B = 64 step at the same step time, bit-identical -- profiles/r05_fin_apply.md; 0 = never);
+        # CREID_FIN_APPLY_RB = row blocks of that launch (0 = library rule)
+        self.fin_apply_rows = int(os.environ.get("CREID_FIN_APPLY", "64"))
+        self.fin_apply_rb = int(os.environ.get("CREID_FIN_APPLY_RB", "64"))
         self._apply_dry = int(os.environ.get("CREID_BN_APPLY_DRY", "0"))
         if self._apply_dry:
             import sys
@@ -596,6 +601,20 @@ class BackboneEngine:
         mean = self._empty(u.cout, dtype=torch.float32)
         invstd = self._empty(u.cout, dtype=torch.float32)
         ss = self._empty(2, u.cout, dtype=torch.float32)
+        if (self.fin_apply_rows and training and apply and residual_ss is None and rows <= self.fin_apply_rows
+                and u.cout % (32 if self.dtype == torch.float32 else 64) == 0 and not self._apply_dry):
+            # finalize + apply in ONE launch (CREID_FIN_APPLY=<max statistic rows>; profiles/r05_fin_apply.md)
+            a = self._empty(M, u.cout)
+            mask = None
+            if relu and self.relu_bitmask:
+                mask = torch.empty(M * u.cout // 8, dtype=torch.uint8, device=self.device)
+            L.check(lib.creid_bn2d_finalize_apply_mask(L.ptr(part), rows, u.cout, M, L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                                       bn.momentum, bn.eps, L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(mean), L.ptr(invstd),
+                                                       L.ptr(ss), L.ptr(x), L.ptr(residual), 1 if relu else 0, self.dt, L.ptr(a),
+                                                       L.ptr(mask), self.fin_apply_rb, st), "bn2d_finalize_apply")
+            if mask is not None:
+                a._relu_mask = mask
+            return a, mean, invstd
         L.check(lib.creid_bn2d_finalize(L.ptr(part), rows, u.cout, M, L.ptr(bn.running_mean), L.ptr(bn.running_var),
                                         1 if training else 0, bn.momentum, bn.eps, L.ptr(bn.weight), L.ptr(bn.bias),
                                         L.ptr(mean), L.ptr(invstd), L.ptr(ss), st), "bn2d_finalize")

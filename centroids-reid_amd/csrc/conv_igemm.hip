@@ -1236,7 +1236,8 @@ static int launch_igemm(const IGemmGeom& g_in, const void* src, const void* wgt,
   {
     const char* pe = CREID_KNOB_ENV("CREID_IGEMM_PP");                     // read per call: tests and the tuner toggle it
     const int force_pp = pe ? (int)strtol(pe, nullptr, 0) : 0;
-    if (creid_is16(dtype) && !bnred.x && !wred.ws && g.log2span >= 6 && (force_pp || tuned_pp >= 0)) {
+    const bool pp_off = pe && force_pp == 0;                              // CREID_IGEMM_PP=0: never, not even where a plan selects it
+    if (creid_is16(dtype) && !bnred.x && !wred.ws && g.log2span >= 6 && !pp_off && (force_pp || tuned_pp >= 0)) {
       const int rc = launch_igemm_pp(g, src, wgt, out, add_src, bn_part, force_pp ? (force_pp & 0xfff) : tuned_pp, dtype, s);
       if (rc != CREID_E_SHAPE) return rc;
     }

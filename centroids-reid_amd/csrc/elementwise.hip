@@ -235,6 +235,115 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x
   }
 }
 
+// ------------------------------------------------------------------ training-mode BN: finalize + apply in ONE launch
+// (round 5).  For layers with few statistic rows (M <= 32768: <= 256 partial rows) every apply workgroup
+// derives the coefficients of ITS OWN channel strip itself -- no finalize launch in front of it, no grid-wide wait, no atomics:
+//   grid (C / (8 V) strips, row blocks), 256 threads = 8 chunk lanes (16 bytes = V channels each) x 32 row lanes;
+//   head: the strip's (sum, sum of squares) partial rows summed in fp64 (32 row lanes -> three wave shuffles -> the four waves
+//         meet in LDS), then mean / invstd / (scale, shift) exactly as bn2d_finalize_kernel evaluates them (same fp64 expressions,
+//         same conversions; a sum of <= 256 fp32 addends is exact in fp64, hence independent of the association);
+//   body: y = max(x * scale + shift (+ residual), 0) over the workgroup's row range of the strip, ReLU bits as bn2d_apply_kernel.
+// The row-block-0 workgroups also publish mean / invstd / scale_shift (the backward reads them) and update the running
+// statistics.  What is redundant is the head: row_blocks x the partial rows of a strip, served by L2 -- (row blocks / 64) of the
+// tensor's own traffic, which is why the launcher keeps the row blocks few.
+template <typename T>
+__global__ __launch_bounds__(256) void bn2d_fin_apply_kernel(const T* __restrict__ x, const float* __restrict__ partial, int rows,
+                                                             int C, int64_t M, double count, float* __restrict__ rmean,
+                                                             float* __restrict__ rvar, float momentum, float eps,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                             float* __restrict__ scale_shift, const T* __restrict__ res, int relu,
+                                                             T* __restrict__ y, uint8_t* __restrict__ mask_out,
+                                                             int rows_per_block) {
+  constexpr int V = Vec16<T>::N, SW = 8 * V;                     // strip width in channels (64 / 32)
+  constexpr int RL = 256 / SW;                                   // row lanes of the head (4 / 8)
+  __shared__ double red[RL][2][SW];
+  __shared__ float coef[2][SW];
+  const int tc = threadIdx.x & 7, tr = threadIdx.x >> 3;
+  const int cbase = (int)blockIdx.x * SW, c0 = cbase + tc * V;
+  // head, one channel per lane: lane (ch, rl) sums rows rl, rl + RL, ... of its channel's two statistic columns (coalesced SW-float
+  // rows, eight independent loads in flight), the RL row lanes meet in LDS, lane (ch, 0) evaluates ONE channel's coefficients
+  const int ch = threadIdx.x % SW, rl = threadIdx.x / SW;
+  double s1 = 0.0, s2 = 0.0;
+  {
+    const float* p = partial + cbase + ch;
+    int r = rl;
+    for (; r + 3 * RL < rows; r += 4 * RL) {
+      const float a0 = p[((int64_t)r * 2) * C], b0 = p[((int64_t)r * 2 + 1) * C];
+      const float a1 = p[((int64_t)(r + RL) * 2) * C], b1 = p[((int64_t)(r + RL) * 2 + 1) * C];
+      const float a2 = p[((int64_t)(r + 2 * RL) * 2) * C], b2 = p[((int64_t)(r + 2 * RL) * 2 + 1) * C];
+      const float a3 = p[((int64_t)(r + 3 * RL) * 2) * C], b3 = p[((int64_t)(r + 3 * RL) * 2 + 1) * C];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; r < rows; r += RL) { s1 += (double)p[((int64_t)r * 2) * C]; s2 += (double)p[((int64_t)r * 2 + 1) * C]; }
+  }
+  red[rl][0][ch] = s1; red[rl][1][ch] = s2;
+  float p_gamma = 1.f, p_beta = 0.f, p_rm = 0.f, p_rv = 0.f;
+  const bool publish = blockIdx.y == 0;
+  if (rl == 0) {
+    if (gamma) p_gamma = gamma[cbase + ch];
+    if (beta) p_beta = beta[cbase + ch];
+    if (publish && rmean) p_rm = rmean[cbase + ch];
+    if (publish && rvar) p_rv = rvar[cbase + ch];
+  }
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  __syncthreads();
+  if (rl == 0) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < RL; ++q) { t1 += red[q][0][ch]; t2 += red[q][1][ch]; }
+    const double mean = t1 / count;
+    double var = t2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)mean, is = (float)(1.0 / sqrt(var + (double)eps));
+    const float scv = is * p_gamma, shv = p_beta - mu * scv;
+    coef[0][ch] = scv; coef[1][ch] = shv;
+    if (publish) {
+      const int c = cbase + ch;
+      mean_out[c] = mu; invstd_out[c] = is;
+      scale_shift[c] = scv; scale_shift[C + c] = shv;
+      if (rmean) rmean[c] = (1.f - momentum) * p_rm + momentum * (float)mean;
+      if (rvar) rvar[c] = (1.f - momentum) * p_rv + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+    }
+  }
+  __syncthreads();
+  float sc[V], sh[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { sc[k] = coef[0][tc * V + k]; sh[k] = coef[1][tc * V + k]; }
+  // body: four independent rows in flight per thread
+  for (int64_t r = r0 + tr; r < r1; r += 128) {
+    float v[4][V], rv[4][V];
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t rr = r + 32 * u;
+      on[u] = rr < r1;
+      if (on[u]) {
+        Vec16<T>::load(x + rr * C + c0, v[u]);
+        if (res) Vec16<T>::load(res + rr * C + c0, rv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!on[u]) continue;
+      const int64_t rr = r + 32 * u;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        v[u][k] = fmaf(v[u][k], sc[k], sh[k]) + (res ? rv[u][k] : 0.f);
+        if (relu) v[u][k] = fmaxf(v[u][k], 0.f);
+      }
+      Vec16<T>::store(y + rr * C + c0, v[u]);
+      if (mask_out) {
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) m |= (v[u][k] > 0.f ? 1u : 0u) << k;
+        mask_out[(rr * C + c0) / V] = (uint8_t)m;
+      }
+    }
+  }
+}
+
 // Gradient of the max-pool at input pixel (b, iy, ix), channels [cc*V, cc*V+V): the (up to four) windows that contain the
 // pixel, each contributing where its saved argmax tap points here -- maxpool_bwd_kernel's gather as a device function, so
 // that the stem's BatchNorm backward can consume the pooled gradient without the full-resolution copy being written.
@@ -949,6 +1058,36 @@ int creid_bn2d_apply_mask(const void* x, const float* scale_shift, const void* r
              hipLaunchKernelGGL(bn2d_apply_kernel<_Float16>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const _Float16*)x, scale_shift, (const _Float16*)residual, relu, M,
                                 (int)C, (_Float16*)y, mask_out, (const float*)nullptr));
+  CREID_LAUNCH_RET();
+}
+
+int creid_bn2d_finalize_apply_mask(const float* partial, int64_t rows, int64_t C, int64_t M, float* running_mean,
+                                   float* running_var, float momentum, float eps, const float* gamma, const float* beta,
+                                   float* mean_out, float* invstd_out, float* scale_shift, const void* x, const void* residual,
+                                   int relu, int dtype, void* y, uint8_t* mask_out, int row_blocks, void* stream) {
+  CREID_CHECK_ARG(partial && rows > 0 && C > 0 && M > 0 && mean_out && invstd_out && scale_shift && x && y);
+  if (mask_out && dtype == CREID_F32) return CREID_E_DTYPE;
+  const int64_t strip = dtype == CREID_F32 ? 32 : 64;            // 8 chunk lanes x 16 bytes
+  if (C % strip != 0 || rows > 1024) return CREID_E_SHAPE;
+  const int strips = (int)(C / strip);
+  // few row blocks: the head (the strip's partial rows) is re-read by every row block; ~512 workgroups where that is cheap
+  int rb = row_blocks > 0 ? row_blocks : (512 + strips - 1) / strips;
+  if (row_blocks <= 0) { if (rb > 32) rb = 32; if (rb < 4) rb = 4; }
+  int64_t rpb = ((M + rb - 1) / rb + 31) / 32 * 32;
+  rb = (int)((M + rpb - 1) / rpb);
+  hipStream_t s = as_stream(stream);
+  const dim3 grid((unsigned)strips, (unsigned)rb);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn2d_fin_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, (int)rows, (int)C, M,
+                                (double)M, running_mean, running_var, momentum, eps, gamma, beta, mean_out, invstd_out, scale_shift,
+                                (const float*)residual, relu, (float*)y, (uint8_t*)nullptr, (int)rpb),
+             hipLaunchKernelGGL(bn2d_fin_apply_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)x, partial,
+                                (int)rows, (int)C, M, (double)M, running_mean, running_var, momentum, eps, gamma, beta, mean_out,
+                                invstd_out, scale_shift, (const unsigned short*)residual, relu, (unsigned short*)y, mask_out,
+                                (int)rpb),
+             hipLaunchKernelGGL(bn2d_fin_apply_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)x, partial, (int)rows,
+                                (int)C, M, (double)M, running_mean, running_var, momentum, eps, gamma, beta, mean_out, invstd_out,
+                                scale_shift, (const _Float16*)residual, relu, (_Float16*)y, mask_out, (int)rpb));
   CREID_LAUNCH_RET();
 }
 

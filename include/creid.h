@@ -523,6 +523,15 @@ int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residu
  * re-reading y (modelling/backbones/resnet.py:71,75,85 -- the three ReLUs of a Bottleneck). */
 int creid_bn2d_apply_mask(const void* x, const float* scale_shift, const void* residual, int relu, int64_t M,
                           int64_t C, int dtype, void* y, uint8_t* mask_out, void* stream);
+/* Training-mode creid_bn2d_finalize + creid_bn2d_apply_mask in ONE launch (round 5), for layers with few statistic rows
+ * (rows <= 1024; meant for M <= 32768): every apply workgroup sums the partial rows of its own 64-channel strip in fp64 (the
+ * finalize's expressions, so mean / invstd / scale_shift / the running statistics / y / mask_out come out bit-identical to the
+ * two launches), the row-block-0 workgroups publish the statistics.  count = M (the statistics cover every row of x).
+ * row_blocks <= 0: chosen by the library.  C % 64 == 0 (bf16 / f16) or % 32 (f32), else CREID_E_SHAPE (use the two calls). */
+int creid_bn2d_finalize_apply_mask(const float* partial, int64_t rows, int64_t C, int64_t M, float* running_mean,
+                                   float* running_var, float momentum, float eps, const float* gamma, const float* beta,
+                                   float* mean_out, float* invstd_out, float* scale_shift, const void* x, const void* residual,
+                                   int relu, int dtype, void* y, uint8_t* mask_out, int row_blocks, void* stream);
 /* bn3 + downsample BatchNorm + add + ReLU of a block with a downsample branch (resnet.py:80-85) in ONE pass:
  * y = act(x * scale + shift + (x_res * scale_res + shift_res)); x_res is the RAW downsample convolution output -- its
  * normalised tensor is never written (fp32: bit-identical to creid_bn2d_apply twice; bf16: one rounding fewer). */

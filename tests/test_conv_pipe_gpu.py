@@ -90,3 +90,47 @@ def test_pipe_kernel_rejects_uncovered_launches(monkeypatch):
         y = ly.conv2d_fwd(x, krsc, 1, 0)
         ref = torch.einsum("bhwc,oc->bhwo", x.float(), krsc.view(cout, cin).float())
         np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+# the shapes the kernel actually runs in production (tuned_plans.json kind 5): the B = 64 training forward and the B = 128 / 256
+# eval-mode forward -- full grids (every CU busy, persistent workgroups walking several tiles each, XCD-aware tile order), M = 8192
+# ... 409 600 rows; small M above covers the edges, these cover the schedule the benchmark depends on
+PROD_CASES = [  # B, H, W, cin, cout, k, stride, variant
+    (64, 16, 8, 512, 2048, 1, 1, vword(256, 256, 1, 0)),      # layer4 conv3, training batch: M = 8192, 256 tiles of 256 x 256
+    (64, 16, 8, 1024, 2048, 1, 1, vword(256, 256, 1, 0)),     # layer4 downsample
+    (64, 16, 8, 256, 1024, 1, 1, vword(128, 128, 1, 2)),      # layer3 conv3: 512 tiles, free-running form
+    (64, 32, 16, 512, 256, 1, 1, vword(128, 128, 1, 2)),      # layer3.0 conv1: M = 32768
+    (64, 32, 16, 512, 1024, 1, 2, vword(128, 128, 2, 0)),     # layer3.0 downsample, stride 2
+    (128, 16, 8, 512, 512, 3, 1, vword(128, 256, 1, 0)),      # layer4 conv2 at the embedding batch: M = 16384, 72 k-tiles
+    (128, 64, 32, 256, 128, 1, 1, vword(128, 128, 1, 2)),     # layer2.0 conv1 at the embedding batch: M = 262144, 2048 row tiles
+    (256, 40, 40, 256, 512, 1, 2, vword(128, 128, 1, 2)),     # configs[3] embedding batch, 80 x 80 -> 40 x 40 maps: M = 102400 (ragged tiles)
+]
+
+
+@pytest.mark.parametrize("case", PROD_CASES)
+def test_pipe_kernel_matches_tile_kernels_at_production_shapes(case, monkeypatch):
+    """bit-identity of the persistent kernel with the tile kernels at the shapes and grids of the benchmark
+    (training forward with BatchNorm partials, folded eval-mode affine with the residual), not only at M <= 1152."""
+    from centroids_reid_amd import layers as ly
+    B, H, W, cin, cout, k, stride, variant = case
+    pad = k // 2
+    gen = torch.Generator(device="cuda").manual_seed(sum(int(c) for c in case))
+    x = torch.randn((B, H, W, cin), generator=gen, device="cuda").to(torch.bfloat16)
+    w = torch.randn((cout, cin, k, k), generator=gen, device="cuda") / float(np.sqrt(cin * k * k))
+    krsc, _ = ly.weight_prep(w, torch.bfloat16)
+    ss = torch.stack([torch.rand(cout, generator=gen, device="cuda") + 0.5, torch.randn(cout, generator=gen, device="cuda") * 0.3])
+    monkeypatch.setenv("CREID_IGEMM_PP", "0")                   # the tile kernels, even where a plan would pick the persistent one
+    y0, p0 = ly.conv2d_fwd(x, krsc, stride, pad, with_stats=True)
+    res = torch.randn(tuple(y0.shape), generator=gen, device="cuda").to(torch.bfloat16)
+    a0 = ly.conv2d_fwd_affine(x, krsc, stride, pad, ss, res, True)
+    monkeypatch.setenv("CREID_IGEMM_PP", hex(0x1000 | variant))
+    y1, p1 = ly.conv2d_fwd(x, krsc, stride, pad, with_stats=True)
+    a1 = ly.conv2d_fwd_affine(x, krsc, stride, pad, ss, res, True)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1), "training forward differs"
+    assert torch.equal(a0, a1), "folded eval-mode forward (affine + residual + ReLU) differs"
+    np.testing.assert_allclose(p1.sum(0).cpu().numpy(), p0.sum(0).cpu().numpy(), rtol=2e-5, atol=1e-2)
+    # and a slice against fp32 arithmetic on the same bf16 operands
+    import torch.nn.functional as F
+    ref = F.conv2d(x[:2].float().permute(0, 3, 1, 2), krsc.float().permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(y1[:2].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)

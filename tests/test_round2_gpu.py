@@ -183,3 +183,46 @@ def test_standalone_baseline_returns_base_out_like_the_reference(dtype):
     with torch.no_grad():
         base_out, _ = model.backbone(x)
     assert base_out is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,with_res,rb", [(8192, 256, False, 0), (8192, 1024, True, 64), (4096, 2048, True, 7), (1000, 128, False, 3),
+                                             (32768, 512, True, 16)])
+def test_bn_finalize_apply_one_launch_is_bit_identical_to_two(M, C, with_res, rb, dtype):
+    """creid_bn2d_finalize_apply_mask (round 5): training-mode BatchNorm finalize + apply in one launch --
+    every apply workgroup sums the partial rows of its own channel strip -- against creid_bn2d_finalize + creid_bn2d_apply_mask:
+    output, ReLU bits, mean, invstd, (scale, shift) and the running statistics identical BIT FOR BIT, incl. ragged row blocks."""
+    from centroids_reid_amd import _lib as L
+    lib = L.lib()
+    gen = torch.Generator(device="cuda").manual_seed(M + C)
+    rows = (M + 127) // 128
+    x = torch.randn((M, C), generator=gen, device="cuda").to(dtype)
+    res = torch.randn((M, C), generator=gen, device="cuda").to(dtype) if with_res else None
+    pad = rows * 128 - M
+    xf = torch.cat([x.float(), torch.zeros((pad, C), device="cuda")]).view(rows, 128, C)
+    part = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).contiguous()
+    gamma = torch.rand(C, generator=gen, device="cuda") + 0.5
+    beta = torch.randn(C, generator=gen, device="cuda") * 0.1
+    use_mask = dtype != torch.float32
+
+    def run(fused):
+        o = dict(rm=torch.linspace(-0.1, 0.1, C, device="cuda"), rv=torch.linspace(0.5, 1.5, C, device="cuda"),
+                 mean=torch.empty(C, device="cuda"), inv=torch.empty(C, device="cuda"), ss=torch.empty((2, C), device="cuda"),
+                 y=torch.empty_like(x), mask=torch.zeros(M * C // 8, dtype=torch.uint8, device="cuda"))
+        mk = L.ptr(o["mask"]) if use_mask else None
+        if fused:
+            L.check(lib.creid_bn2d_finalize_apply_mask(L.ptr(part), rows, C, M, L.ptr(o["rm"]), L.ptr(o["rv"]), 0.1, 1e-5, L.ptr(gamma),
+                                                       L.ptr(beta), L.ptr(o["mean"]), L.ptr(o["inv"]), L.ptr(o["ss"]), L.ptr(x), L.ptr(res),
+                                                       1, L._DT[dtype], L.ptr(o["y"]), mk, rb, L.stream()), "fused")
+        else:
+            L.check(lib.creid_bn2d_finalize(L.ptr(part), rows, C, M, L.ptr(o["rm"]), L.ptr(o["rv"]), 1, 0.1, 1e-5, L.ptr(gamma),
+                                            L.ptr(beta), L.ptr(o["mean"]), L.ptr(o["inv"]), L.ptr(o["ss"]), L.stream()), "fin")
+            L.check(lib.creid_bn2d_apply_mask(L.ptr(x), L.ptr(o["ss"]), L.ptr(res), 1, M, C, L._DT[dtype], L.ptr(o["y"]), mk, L.stream()),
+                    "apply")
+        return o
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    ref = torch.relu((x.float() - x.float().mean(0)) * torch.rsqrt(x.float().var(0, unbiased=False) + 1e-5) * gamma + beta
+                     + (res.float() if with_res else 0.0))
+    np.testing.assert_allclose(b["y"].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
