@@ -174,7 +174,12 @@ class ModelBase(_Base):
         def plain(d):
             return {k: plain(v) if isinstance(v, dict) else v for k, v in d.items()}
         opts = self._optimizers if pl is None else None
+        extra = {}
+        if getattr(self, "loss_scaler", None) is not None:
+            # precision=16 runs: pytorch-lightning 1.1.4 stores GradScaler.state_dict() under this key (same fields)
+            extra["native_amp_scaling_state"] = self.loss_scaler.state_dict()
         return {
+            **extra,
             "epoch": epoch, "global_step": global_step, "pytorch-lightning_version": "1.1.4",
             "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
             "hparams_name": "kwargs", "hyper_parameters": plain(dict(self.hparams)),

@@ -140,3 +140,25 @@ def test_f16_step_in_a_captured_graph_survives_an_overflow(monkeypatch):
     sc.state.copy_(torch.tensor([1024.0, 1.0 / 1024.0]))
     graph.replay(); torch.cuda.synchronize()
     assert not torch.equal(opt.flat, before) and opt.step_count == n0 + 1 and np.isfinite(float(out["loss"]))
+
+
+def test_f16_ibn_a_step_and_checkpoint_scaler_state():
+    """ResNet50-IBN-a (the Street2Shop / DukeMTMC canonical configs turn precision=16 on for it) trains in f16 too: three full steps
+    are finite and applied; the checkpoint carries the loss-scale state under pytorch-lightning's key and a reloaded scaler resumes
+    from it."""
+    from centroids_reid_amd.bench_train import make_model
+    from centroids_reid_amd.solver import LossScaler
+    torch.manual_seed(0)
+    model = make_model(num_classes=64, dtype=torch.float16, arch="resnet50_ibn_a")
+    model.loss_scaler.state.copy_(torch.tensor([1024.0, 1.0 / 1024.0]))
+    for s, b in enumerate(_batches(8, 4, 128, 64, 3)):
+        out = model.training_step(b, s)
+        assert np.isfinite(float(out["loss"]))
+    opt, _ = model.optimizers()
+    assert opt.step_count == 3 and all(torch.isfinite(p).all() for p in model.parameters())
+    ck = model.checkpoint_dict()
+    st = ck["native_amp_scaling_state"]
+    assert st["scale"] == 1024.0 and st["growth_interval"] == 2000 and st["_growth_tracker"] == 3
+    sc = LossScaler("cuda")
+    sc.load_state_dict(st)
+    assert sc.get_scale() == 1024.0 and int(sc.flags[1]) == 3 and int(sc.flags[0]) == 0

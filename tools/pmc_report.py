@@ -1,8 +1,8 @@
-"""Turn the gpurun_out/pmc_*.json passes (tools/pmc_run.sh) into profiles/<round>_pmc_traffic.json + profiles/<round>_pmc_summary.md (CREID_ROUND, default r04)."""
+"""Turn the gpurun_out/pmc_*.json passes (tools/pmc_run.sh) into profiles/<round>_pmc_traffic.json + profiles/<round>_pmc_summary.md (CREID_ROUND, default r05)."""
 import json
 import os
 
-RND = os.environ.get("CREID_ROUND", "r04")
+RND = os.environ.get("CREID_ROUND", "r05")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
