@@ -453,10 +453,10 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
   static const int target = [] { const char* e = getenv("CREID_STREAM_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   // timing ablation only (CREID_STREAM_NOEPI=1: contraction without the count epilogue -- results are then wrong)
   static const int skip_count = creid_ablation_env("CREID_STREAM_NOEPI");
-  // ... and never MORE than `tper_max` gallery tiles per workgroup: the workgroups of one XCD walk the same gallery slice and stay in
-  // step on it only for a few tiles (a 256-row tile is 2 MB, the XCD's L2 4 MB); on long slices they drift apart and every one of
-  // them streams its own copy of the gallery from the fabric (6250 x 200 000: 131 tiles per workgroup 66.0 ms, 10 tiles 47.1 ms --
-  // profiles/r05_stream_grid.md)
+  // ... and never MORE than `tper_max` gallery tiles per workgroup: the grid overshoots the 512 slots by up to tiles_m - 1
+  // workgroups, which start when the first ones finish -- harmless when a workgroup is 5 tiles long, a whole second round on an
+  // idle chip when it is 131 (6250 x 200 000: 588 workgroups, 66.0 ms; with <= 8 tiles per workgroup 46.1 ms; HBM-side traffic by
+  // the counters the same under both rules -- profiles/r05_stream_grid.md)
   static const int tper_max = [] { const char* e = getenv("CREID_STREAM_TPER"); int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
   int nsplit = (target + tiles_m - 1) / tiles_m;
   if (nsplit < (tiles_n + tper_max - 1) / tper_max) nsplit = (tiles_n + tper_max - 1) / tper_max;
