@@ -13,7 +13,7 @@ torch-CPU fp32 with an explicit rounding function at every place where the HIP f
 
 Same clustered-identity recipe as bench_train.map_delta_bf16 (images from a CPU generator, so the absolute mAP differs
 from the GPU recipe's; the deltas are what is read).  Uses oracle/ as a checker -- this is a measurement tool, not product.
-    python tools/debug/f16_hi_emul.py [noise ...]      (default 0.3 0.6 0.9)"""
+    python tests/probes/f16_hi_emul.py [noise ...]      (default 0.3 0.6 0.9)"""
 import sys
 import time
 

@@ -167,7 +167,7 @@ def test_f16_training_forward_backward_close_to_fp32():
         assert r16 < rbf, (name, table)
     # training-mode features: batch statistics divide by the spread of a stored (rounded) convolution output whose per-channel
     # mean is several times that spread in a randomly initialised network, which amplifies the storage rounding ~50 x over the
-    # eval-mode forward (measured, tools/debug/f16_fwd_check.py: bf16 1.3e-1 / 2.7e-3, f16 2.6e-2 / 3.1e-4 train / eval) -- the same
+    # eval-mode forward (measured, tests/probes/f16_fwd_check.py: bf16 1.3e-1 / 2.7e-3, f16 2.6e-2 / 3.1e-4 train / eval) -- the same
     # for any 16-bit storage of pre-BatchNorm activations, the reference's autocast included; f16 sits 5 x closer than bf16
     f32 = feats[torch.float32]
     e16 = float(((feats[torch.float16] - f32).norm(dim=1) / f32.norm(dim=1)).max())
