@@ -612,8 +612,9 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
     if os.environ.get("CREID_BENCH_P"):                        # side measurement: another batch size (P identities x K = 4)
         P = int(os.environ["CREID_BENCH_P"])
     f32 = os.environ.get("CREID_BENCH_DTYPE", "bf16") == "f32"   # side measurement: the exact-f32 parity mode
+    f16 = os.environ.get("CREID_BENCH_DTYPE", "bf16") == "f16"   # side measurement: f16 + device-resident loss scale (precision=16)
     torch.manual_seed(int(os.environ.get("CREID_BENCH_SEED", "0")))   # random-init weights: the same ones in every run
-    model = make_model(arch=arch, dtype=torch.float32 if f32 else torch.bfloat16)
+    model = make_model(arch=arch, dtype=torch.float32 if f32 else (torch.float16 if f16 else torch.bfloat16))
     ddp = world > 1 or (dist.is_available() and dist.is_initialized())      # CREID_FORCE_DIST=1: one-rank RCCL group
     overlap = False
     if ddp:
@@ -719,6 +720,9 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
         loss = float(out["loss"])
         assert np.isfinite(loss), "non-finite loss in the benchmark"
         res["final_loss"] = loss
+        if f16:
+            opt0, _ = model.optimizers()
+            res["f16_state"] = {"loss_scale": model.loss_scaler.get_scale(), "adam_steps_applied": opt0.step_count}
         res["host_enqueue_ms_per_step"] = t_host / args.steps * 1e3
         res["hip_graph"] = bool(use_graph)
         ms = dt / args.steps * 1e3
@@ -728,7 +732,7 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
         from . import _lib as L
         res["plans"] = "tuned" if (L.lib() and L.N_PLANS > 0) else "rules"   # tuned_plans.json covers the configs[1] / [3] shapes only
         tf, ig_ms, slow, fast = igemm_roofline(P * K, H, W, time_kernel)
-        headline = world == 1 and arch == "resnet50" and not f32 and (H, W) == (256, 128) and P == 16
+        headline = world == 1 and arch == "resnet50" and not f32 and not f16 and (H, W) == (256, 128) and P == 16
         insitu = insitu_trace() if headline else None
         roof = {"kernel": "convolution forward + data-gradient kernels (igemm_bf16_{dma,ws,pp}, igemm1x1_stream2, conv3x3_c64; stem fwd; 105 launches/step, real layer mix)",
                 "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_TFLOPS,
@@ -784,12 +788,12 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
                 "resnet50_ibn_a", 256, 320, 320, steps=5, warmup=2,
                 label="ResNet50-IBN-a 320x320 eval-mode embedding forward, batch 256 (embedding half of BASELINE configs[3], "
                       "TEST.IMS_PER_BATCH 256)")
-    if ddp and arch == "resnet50" and not f32 and (H, W) == (256, 128) and os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
+    if ddp and arch == "resnet50" and not f32 and not f16 and (H, W) == (256, 128) and os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
         er = run_embed_ranks(world, barrier_sync)            # every rank takes part; rank 0 reports
         if rank == 0:
             res["embed_ranks" if "embed" in res else "embed"] = er
     return {"metric": "train_images_per_sec", "value": imgs / dt, "unit": "images/s",
-            "ms_per_step": dt / args.steps * 1e3, "dtype": "f32" if f32 else "bf16",
+            "ms_per_step": dt / args.steps * 1e3, "dtype": "f32" if f32 else ("f16" if f16 else "bf16"),
             "config": {"workload": ("ResNet50" if arch == "resnet50" else arch) +
                                    f" {H}x{W} CTL training step: fwd+bwd, centroid-triplet + center + xent, "
                                    "Adam + center SGD (BASELINE configs[1])" if (H, W) == (256, 128) else

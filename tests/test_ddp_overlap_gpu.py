@@ -120,3 +120,27 @@ def test_bench_gpus_8_contract_eight_ranks_one_gpu():
     emb = line.get("embed_ranks") or line["embed"]
     assert emb["config"]["parallelism"] == "dp8" and emb["value"] > 0
     assert line["eval"]["config"]["parallelism"] == "query-shard x8, gallery all-gather" and 0 < line["eval"]["mAP"] < 1
+
+
+def test_f16_training_data_parallel_two_ranks_one_gpu():
+    """f16 training (the reference's precision=16) on the overlapped data-parallel path: two gloo ranks on one GPU, the step as
+    hipGraph segments with the bucketed gradient all-reduce between them, the loss-scale kernels inside the optimiser segment.
+    The ranks need no collective of their own for the overflow decision (a non-finite gradient reaches every rank through the
+    SUM all-reduce before the unscale + check runs): the run must finish, with a finite loss and every step either applied or
+    skipped on the scale's way down from 65536."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CREID_DIST_BACKEND="gloo", CREID_SINGLE_DEVICE="1",
+               CREID_BENCH_NO_INSITU="1", CREID_BENCH_NO_EVAL="1", CREID_BENCH_DTYPE="f16")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["dtype"] == "f16" and line["n_gpus"] == 2 and np.isfinite(line["final_loss"])
+    st = line["f16_state"]
+    assert 1.0 <= st["loss_scale"] <= 65536.0 and st["adam_steps_applied"] >= 1
