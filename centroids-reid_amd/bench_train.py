@@ -784,6 +784,13 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
             ef = run_embed("resnet50", 128, 256, 128, steps=20, warmup=3, dtype=torch.float16)
             res["embed"]["f16"] = {"value": ef["value"], "unit": ef["unit"], "ms_per_step": ef["ms_per_step"], "dtype": "f16",
                                    "vs_bf16": ef["value"] / res["embed"]["value"], "roofline_frac_whole_forward": ef["roofline"]["frac"]}
+            # the same forward at the batches inference.run_inference's macro-batching (and TEST.IMS_PER_BATCH 256 of the reference's
+            # large configs) runs it at: from two tiles per persistent workgroup on the convolution kernels pipeline across tiles
+            for bb_ in (256, 512):
+                eb = run_embed("resnet50", bb_, 256, 128, steps=10, warmup=3)
+                res["embed"][f"batch{bb_}"] = {"value": eb["value"], "unit": eb["unit"], "ms_per_step": eb["ms_per_step"], "batch": bb_,
+                                                "vs_batch128": eb["value"] / res["embed"]["value"],
+                                                "roofline_frac_whole_forward": eb["roofline"]["frac"]}
             res["embed"]["configs3_embedding_half"] = run_embed(
                 "resnet50_ibn_a", 256, 320, 320, steps=5, warmup=2,
                 label="ResNet50-IBN-a 320x320 eval-mode embedding forward, batch 256 (embedding half of BASELINE configs[3], "

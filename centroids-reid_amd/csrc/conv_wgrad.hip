@@ -990,7 +990,9 @@ static int conv_wgrad_phases(const creid_conv_desc* d, const void* x, const void
 }
 
 size_t creid_stem_conv_wgrad_workspace_bytes(int64_t batch, int64_t H, int64_t W, int dtype) {
-  const WgradPlan p = plan_wgrad((int)(batch * (H / 2) * (W / 2)), 64, 256, dtype);
+  // (stride 2: the launch looks its plan up with the stem geometry's stride -- with the default of 1 a measured plan of a 1 x 1
+  // layer that happens to share (M, 64, 256) at another batch size answered here but not there: workspace too small)
+  const WgradPlan p = plan_wgrad((int)(batch * (H / 2) * (W / 2)), 64, 256, dtype, 2);
   return (size_t)p.splits * 64 * 256 * sizeof(float);
 }
 

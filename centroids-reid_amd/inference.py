@@ -42,10 +42,17 @@ def _inference(model, batch, use_cuda=True, normalize_with_bn=True, transform=No
         return global_feat, filename
 
 
-def run_inference(model, val_loader, cfg=None, print_freq=0, use_cuda=True, transform=None):
+def run_inference(model, val_loader, cfg=None, print_freq=0, use_cuda=True, transform=None, macro_batch=512):
     """inference_utils.py:116-131 -> (embeddings float32 [N, D] ndarray, paths ndarray); the embeddings are
     also kept on the device in `run_inference.last_device_embeddings` for a following get_similar().  A loader of uint8
-    [B, H, W, 3] batches is normalised on the device (`transform`, or the test transform built from `cfg`)."""
+    [B, H, W, 3] batches is normalised on the device (`transform`, or the test transform built from `cfg`).
+
+    macro_batch (round 5): consecutive loader batches are concatenated until at least this many images are waiting and embedded
+    with ONE forward -- the eval-mode forward treats every image independently (BatchNorm folded to running statistics, eval-mode
+    BNNeck), and every kernel variant the library may pick for another batch size produces the same bits, so the embeddings are
+    IDENTICAL to the per-batch ones (tests/test_centroid_eval_gpu.py), while a forward of 512 images runs at 78 k images/s against
+    65 k for the reference's TEST.IMS_PER_BATCH = 128 (profiles/r05_embed_batch_sweep.md: the persistent convolution kernels
+    only pipeline across tiles when a workgroup owns more than one).  0 / None: one forward per loader batch, as the reference."""
     embs, paths = [], []
     if transform is None and cfg is not None:
         # built lazily: a float loader never touches cfg.INPUT.* (a partial cfg without those keys stays usable)
@@ -58,10 +65,27 @@ def run_inference(model, val_loader, cfg=None, print_freq=0, use_cuda=True, tran
             return built["t"]
         _lazy._lazy_cfg = cfg
         transform = _lazy
-    for batch in val_loader:
-        e, p = _inference(model, batch, use_cuda, transform=transform)
+    pend, npend = [], 0
+
+    def flush():
+        nonlocal pend, npend
+        if not pend:
+            return
+        data = pend[0][0] if len(pend) == 1 else torch.cat([b[0] for b in pend])
+        names = [n for b in pend for n in list(b[2])]
+        e, p = _inference(model, (data, None, names), use_cuda, transform=transform)
         embs.append(e.float())
         paths.extend(list(p))
+        pend, npend = [], 0
+    for batch in val_loader:
+        data = batch[0]
+        if pend and (data.dtype != pend[0][0].dtype or data.shape[1:] != pend[0][0].shape[1:] or data.device != pend[0][0].device):
+            flush()                                              # batches that cannot be concatenated go separately
+        pend.append(batch)
+        npend += data.shape[0]
+        if not macro_batch or npend >= macro_batch:
+            flush()
+    flush()
     dev = torch.cat(embs)
     run_inference.last_device_embeddings = dev
     return dev.cpu().numpy(), np.array(paths)

@@ -170,3 +170,24 @@ def test_inference_golden(golden):
     cents, keys = inf.calculate_centroids(f[nq:], index)
     assert list(keys) == list(g["centroid_keys"]) and keys.dtype == g["centroid_keys"].dtype
     np.testing.assert_allclose(cents, g["centroids"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_run_inference_macro_batches_are_bit_identical_to_per_batch(dtype):
+    """inference.run_inference(macro_batch=...) (round 5): consecutive loader batches concatenated into one eval-mode forward give
+    EXACTLY the embeddings of one forward per batch -- every image is independent in eval mode and every kernel variant another
+    batch size may select produces the same bits -- for a real CTLModel, ragged last batch included, uint8 loaders too."""
+    from centroids_reid_amd import inference as inf
+    from centroids_reid_amd.bench_train import make_model
+    torch.manual_seed(3)
+    model = make_model(num_classes=16, dtype=dtype).eval()
+    gen = torch.Generator().manual_seed(5)
+    sizes = [40, 40, 40, 23]
+    loader = [(torch.randn((n, 3, 128, 64), generator=gen), None, [f"img_{i}_{j}.jpg" for j in range(n)]) for i, n in enumerate(sizes)]
+    e0, p0 = inf.run_inference(model, loader, macro_batch=0)
+    assert e0.shape == (sum(sizes), 2048)
+    for mb in (64, 100, 512):
+        e1, p1 = inf.run_inference(model, loader, macro_batch=mb)
+        assert list(p1) == list(p0)
+        np.testing.assert_array_equal(e1, e0)
+    assert np.isfinite(e0).all() and np.abs(e0).max() > 0
