@@ -795,6 +795,11 @@ def run(args, rank, world, barrier_sync, time_kernel, cpu_baseline_fn=None, mini
                 "resnet50_ibn_a", 256, 320, 320, steps=5, warmup=2,
                 label="ResNet50-IBN-a 320x320 eval-mode embedding forward, batch 256 (embedding half of BASELINE configs[3], "
                       "TEST.IMS_PER_BATCH 256)")
+            e5 = run_embed("resnet50_ibn_a", 512, 320, 320, steps=4, warmup=2)
+            res["embed"]["configs3_embedding_half"]["batch512"] = {
+                "value": e5["value"], "unit": e5["unit"], "ms_per_step": e5["ms_per_step"], "batch": 512,
+                "vs_batch256": e5["value"] / res["embed"]["configs3_embedding_half"]["value"],
+                "note": "two loader batches per forward (inference.run_inference macro_batch)"}
     if ddp and arch == "resnet50" and not f32 and not f16 and (H, W) == (256, 128) and os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
         er = run_embed_ranks(world, barrier_sync)            # every rank takes part; rank 0 reports
         if rank == 0:
