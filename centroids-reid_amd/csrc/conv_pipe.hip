@@ -485,10 +485,10 @@ int launch_igemm_pp(const IGemmGeom& g, const void* src, const void* wgt, void* 
 #define CREID_PP_LAUNCH(BM_, BN_, WN_, KPH_, GLM_)                                                          \
   do {                                                                                                      \
     if (dtype == CREID_F16) {                                                                               \
-      /* f16: the eval-mode forward (folded affine) and the plain forward; statistics / gradients run the tile kernels */ \
+      /* f16: eval-mode forward (folded affine), plain forward and (round 5: f16 training) the forward with BatchNorm partials */ \
       if (epi == 2) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 2, F16T>), grid, block, 0, s, g, pa); \
-      else if (epi == 0) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 0, F16T>), grid, block, 0, s, g, pa); \
-      else return CREID_E_SHAPE;                                                                            \
+      else if (epi == 1) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 1, F16T>), grid, block, 0, s, g, pa); \
+      else hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 0, F16T>), grid, block, 0, s, g, pa);        \
     }                                                                                                       \
     else if (epi == 2) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 2, Bf16T>), grid, block, 0, s, g, pa); \
     else if (epi == 1) hipLaunchKernelGGL((igemm_bf16_pp_kernel<BM_, BN_, WN_, KPH_, GLM_, 1, Bf16T>), grid, block, 0, s, g, pa); \

@@ -107,21 +107,23 @@ PROD_CASES = [  # B, H, W, cin, cout, k, stride, variant
 ]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", PROD_CASES)
-def test_pipe_kernel_matches_tile_kernels_at_production_shapes(case, monkeypatch):
+def test_pipe_kernel_matches_tile_kernels_at_production_shapes(case, dtype, monkeypatch):
     """bit-identity of the persistent kernel with the tile kernels at the shapes and grids of the benchmark
-    (training forward with BatchNorm partials, folded eval-mode affine with the residual), not only at M <= 1152."""
+    (training forward with BatchNorm partials, folded eval-mode affine with the residual), not only at M <= 1152 -- in bf16 and in
+    f16 (round 5: the f16 training forward takes the persistent kernel with the statistics epilogue too)."""
     from centroids_reid_amd import layers as ly
     B, H, W, cin, cout, k, stride, variant = case
     pad = k // 2
     gen = torch.Generator(device="cuda").manual_seed(sum(int(c) for c in case))
-    x = torch.randn((B, H, W, cin), generator=gen, device="cuda").to(torch.bfloat16)
+    x = torch.randn((B, H, W, cin), generator=gen, device="cuda").to(dtype)
     w = torch.randn((cout, cin, k, k), generator=gen, device="cuda") / float(np.sqrt(cin * k * k))
-    krsc, _ = ly.weight_prep(w, torch.bfloat16)
+    krsc, _ = ly.weight_prep(w, dtype)
     ss = torch.stack([torch.rand(cout, generator=gen, device="cuda") + 0.5, torch.randn(cout, generator=gen, device="cuda") * 0.3])
     monkeypatch.setenv("CREID_IGEMM_PP", "0")                   # the tile kernels, even where a plan would pick the persistent one
     y0, p0 = ly.conv2d_fwd(x, krsc, stride, pad, with_stats=True)
-    res = torch.randn(tuple(y0.shape), generator=gen, device="cuda").to(torch.bfloat16)
+    res = torch.randn(tuple(y0.shape), generator=gen, device="cuda").to(dtype)
     a0 = ly.conv2d_fwd_affine(x, krsc, stride, pad, ss, res, True)
     monkeypatch.setenv("CREID_IGEMM_PP", hex(0x1000 | variant))
     y1, p1 = ly.conv2d_fwd(x, krsc, stride, pad, with_stats=True)
@@ -133,4 +135,4 @@ def test_pipe_kernel_matches_tile_kernels_at_production_shapes(case, monkeypatch
     # and a slice against fp32 arithmetic on the same bf16 operands
     import torch.nn.functional as F
     ref = F.conv2d(x[:2].float().permute(0, 3, 1, 2), krsc.float().permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
-    np.testing.assert_allclose(y1[:2].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(y1[:2].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 4e-3, atol=2e-2 if dtype == torch.bfloat16 else 4e-3)
