@@ -364,7 +364,7 @@ def gen_ckpt_keys():
     """state_dict key/shape layout of the reference's CTLModel (R50 and R50-IBN-a) -> checkpoint contract."""
     ref = ref_import.load()
     rec = {}
-    for arch in ("resnet50", "resnet50_ibn_a"):
+    for arch in ("resnet50", "resnet50_ibn_a", "resnet101", "resnet152", "resnet101_ibn_a"):    # (the last three: round 5)
         cfg = make_cfg(ref)
         cfg.MODEL.NAME = arch
         m = ref.train_ctl_model.CTLModel(cfg, num_classes=751, num_query=10)
