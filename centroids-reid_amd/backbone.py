@@ -311,7 +311,8 @@ class BackboneEngine:
         # convolutions could save (profiles/r03_bn_fusion_bound.md)
         self.dual_apply = os.environ.get("CREID_DUAL_APPLY", "1") == "1"     # A/B knob: 0 = separate downsample-BN apply launch
         # training forward: BatchNorm finalize + apply as ONE launch on layers with at most this many statistic rows (M <= 8192 by
-        # default: 24 launches less per B = 64 step at the same step time, bit-identical -- profiles/r05_fin_apply.md; 0 = never);
+        # default: 24 launches less per B = 64 step at the same step time -- captured and eager --, bit-identical:
+        # profiles/r05_fin_apply.md; 0 = never);
         # CREID_FIN_APPLY_RB = row blocks of that launch (0 = library rule)
         self.fin_apply_rows = int(os.environ.get("CREID_FIN_APPLY", "64"))
         self.fin_apply_rb = int(os.environ.get("CREID_FIN_APPLY_RB", "64"))
