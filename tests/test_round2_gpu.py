@@ -226,3 +226,27 @@ def test_bn_finalize_apply_one_launch_is_bit_identical_to_two(M, C, with_res, rb
     ref = torch.relu((x.float() - x.float().mean(0)) * torch.rsqrt(x.float().var(0, unbiased=False) + 1e-5) * gamma + beta
                      + (res.float() if with_res else 0.0))
     np.testing.assert_allclose(b["y"].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("arch", ["resnet101", "resnet101_ibn_a"])
+def test_deeper_archs_train_through_ctl_model(arch):
+    """MODEL.NAME = resnet101 / resnet101_ibn_a (modelling/baseline.py:73-81) through the whole CTLModel step in the bf16 throughput
+    mode: two steps, finite losses, every gradient-carrying parameter moves, checkpoint keys as the reference's (631 / 693)."""
+    from centroids_reid_amd.bench_train import make_model
+    torch.manual_seed(1)
+    model = make_model(num_classes=32, dtype=torch.bfloat16, arch=arch)
+    assert len(model.state_dict()) == {"resnet101": 631, "resnet101_ibn_a": 693}[arch]
+    P, K = 8, 4
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    for s in range(2):
+        x = torch.randn((P * K, 3, 128, 64), generator=gen, device="cuda")
+        labels = torch.as_tensor(np.repeat((np.arange(P) * 3 + s) % 32, K).astype(np.int64), device="cuda")
+        out = model.training_step((x, labels, torch.zeros(P * K, dtype=torch.int64), torch.ones(P * K, dtype=torch.bool)), s)
+        assert np.isfinite(float(out["loss"]))
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in model.named_parameters() if n in before)
+    assert moved >= 0.98 * len(before), (moved, len(before))
+    model.eval()
+    with torch.no_grad():
+        _, f = model.backbone(torch.randn((4, 3, 128, 64), generator=gen, device="cuda"))
+    assert f.shape == (4, 2048) and torch.isfinite(f).all()
