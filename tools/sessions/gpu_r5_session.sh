@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 GPU session A: parity suite, bench line, per-layer training table, plans "rules" vs "tuned".
-#   gpurun --timeout 1200 -- bash tools/gpu_r5_session.sh
+#   gpurun --timeout 1200 -- bash tools/sessions/gpu_r5_session.sh
 o=gpurun_out/r5b; mkdir -p $o
 timeout 700 python -m pytest tests -m gpu -q --maxfail=15 --durations=10 > $o/pytest.log 2>&1
 echo "pytest rc $?" >> $o/pytest.log; tail -25 $o/pytest.log
