@@ -80,3 +80,38 @@ def test_center_sgd_tail_adoption_is_rechecked_when_grad_is_rebound():
     assert opt.grad_in_adam_tail is False
     opt.readopt_tail()
     assert opt.grad_in_adam_tail and float(tail.sum()) == 0.0
+
+
+def test_tuned_plan_file_is_well_formed():
+    """centroids-reid_amd/tuned_plans.json (what _lib registers through creid_tune_set at load time): every (kind, key) unique -- a
+    duplicate would make the later entry silently win --, kinds / key lengths / plan words in the ranges the launchers decode
+    (csrc/tune.hpp, conv_wgrad.hip plan_wgrad, conv_igemm.hip launch_igemm), and the merge tool additive."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "centroids-reid_amd", "tuned_plans.json")
+    doc = json.load(open(path))
+    plans = doc["plans"]
+    keys = [(e["kind"], tuple(e["key"])) for e in plans]
+    assert len(keys) == len(set(keys)) and len(plans) >= 400
+    for e in plans:
+        assert e["kind"] in (0, 1) and len(e["plan"]) == 3 and all(isinstance(v, int) for v in e["key"] + e["plan"])
+        if e["kind"] == 0:                                   # weight gradient: (M, out_c, K, stride << 1) -> (tile rows, tile cols, splits | flags)
+            assert len(e["key"]) == 4 and e["plan"][0] in (64, 128) and e["plan"][1] in (64, 128) and (e["plan"][2] & 0xffff) >= 1
+        else:                                                # forward / data gradient: (M, N, K, transposed | stride << 1 | eval << 3)
+            assert len(e["key"]) == 4 and e["plan"][2] in (0, 1, 2, 3, 4, 5)
+            if e["plan"][2] != 5:
+                assert e["plan"][0] in (64, 128) and e["plan"][1] in (2, 3, 4)
+    # additive merge: a base entry is never replaced, only new keys are appended
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        base = {"plans": [{"kind": 1, "key": [1, 2, 3, 0], "plan": [64, 2, 0]}]}
+        new = {"plans": [{"kind": 1, "key": [1, 2, 3, 0], "plan": [128, 3, 1]}, {"kind": 0, "key": [9, 9, 9, 2], "plan": [64, 64, 4]}]}
+        for n, d in (("b", base), ("n", new)):
+            json.dump(d, open(os.path.join(td, n + ".json"), "w"))
+        subprocess.run([sys.executable, os.path.join(root, "tools", "merge_plans.py"), os.path.join(td, "b.json"),
+                        os.path.join(td, "n.json"), os.path.join(td, "o.json")], check=True, capture_output=True)
+        out = json.load(open(os.path.join(td, "o.json")))["plans"]
+        assert out == [base["plans"][0], new["plans"][1]]
