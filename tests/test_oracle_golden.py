@@ -117,7 +117,10 @@ def test_heads_step(golden, name):
     # Adam (lr warm-up: epoch 0 -> 0.1 * BASE_LR, train_ctl_model.py:41-49)
     lr = 0.1 * float(g["base_lr"])
     p1, _, _ = ro.adam_step(fc.detach(), fc.grad, torch.zeros_like(fc), torch.zeros_like(fc), 1, lr)
-    np.testing.assert_allclose(p1.numpy(), g["s0_fc_after"], rtol=1e-5, atol=1e-7)
+    # (atol: Adam's first step is lr * g / (|g| + eps); for the few classifier entries whose gradient is ~eps the quotient moves by
+    #  1e-2 of a step with the last bit of g, and torch-CPU's fp32 reductions differ in that bit between host CPUs -- seen on the GPU
+    #  box's host: 1 of 7680 entries off by 2.5e-7 = 0.7 % of one 3.5e-5 step)
+    np.testing.assert_allclose(p1.numpy(), g["s0_fc_after"], rtol=1e-5, atol=5e-7)
 
 
 @pytest.mark.parametrize("name", ["backbone_r50_2x256x128", "backbone_r50ibn_2x64x64", "backbone_r101_2x64x64",
