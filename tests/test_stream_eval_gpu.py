@@ -252,3 +252,35 @@ def test_streamed_speculative_capacity_is_verified():
     a = rm.R1_mAP(num_query=nq)                           # and the materialised path agrees
     ra = a.compute(f, many[0], many[1])
     np.testing.assert_array_equal(rb1[0], ra[0]); assert abs(rb1[1] - ra[1]) < 1e-12
+
+
+def test_streamed_results_do_not_depend_on_the_gallery_slicing():
+    """The grid rule of the streamed contraction (round 5: at most CREID_STREAM_TPER gallery tiles per workgroup) only changes how
+    the gallery is cut into slices; a query's histogram is summed over the slices with integer atomics, so valid / first / AP must be
+    IDENTICAL for every slicing.  The rule is read once per process: one subprocess per value, same seeded inputs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from centroids_reid_amd import reid_metric as rm\n"
+        "nq, ng, D = 333, 9000, 512\n"
+        "gen = torch.Generator(device='cuda').manual_seed(11)\n"
+        "f = torch.randn((nq + ng, D), generator=gen, device='cuda')\n"
+        "rng = np.random.default_rng(11)\n"
+        "pids = rng.integers(0, 150, nq + ng); cams = rng.integers(0, 5, nq + ng)\n"
+        "m = rm.R1_mAP(num_query=nq, streamed=True)\n"
+        "cmc, mAP, topk = m.compute(f, pids, cams)\n"
+        "h = hashlib.sha256()\n"
+        "for k in ('valid', 'ap', 'first'):\n"
+        "    h.update(m.last[k].cpu().numpy().tobytes())\n"
+        "print('RESULT', repr(mAP), h.hexdigest())\n" % root)
+    outs = []
+    for tper in ("1", "3", "1000"):
+        env = dict(os.environ, CREID_STREAM_TPER=tper)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1])
+    assert outs[0] == outs[1] == outs[2], outs
