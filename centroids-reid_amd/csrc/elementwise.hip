@@ -981,15 +981,38 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------ host
-static inline unsigned ew_blocks(int64_t total_threads_needed, int64_t mult) {
+static inline unsigned ew_blocks_cap(int64_t total_threads_needed, int64_t mult, int64_t cap) {
   int64_t b = (total_threads_needed + 255) / 256;
-  static const int64_t cap = [] { const char* e = getenv("CREID_EW_BLOCKS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 2048); }();
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   // make blocks*256 a multiple of `mult` (mult is a power of two <= 512)
   const int64_t q = mult > 256 ? mult / 256 : 1;
   b = (b + q - 1) / q * q;
   return (unsigned)b;
+}
+static inline int64_t ew_env_cap() {
+  static const int64_t cap = [] { const char* e = getenv("CREID_EW_BLOCKS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 0); }();
+  return cap;
+}
+static inline unsigned ew_blocks(int64_t total_threads_needed, int64_t mult) {
+  const int64_t e = ew_env_cap();
+  return ew_blocks_cap(total_threads_needed, mult, e > 0 ? e : 2048);
+}
+// Grid cap of a grid-stride kernel = the workgroups the chip can hold AT ONCE for THAT kernel (occupancy x compute units), asked of
+// the runtime once per kernel.  A fixed 2048 (8 per CU) is right for kernels that fit 8 waves per SIMD, but the 16-bit BatchNorm
+// apply / backward-apply kernels need 76-80 registers (6 waves per SIMD = 1536 workgroups): with 2048 the last 512 workgroups ran
+// as a second round on a quarter-full chip -- 1.5 % of the whole B = 64 training step (round 5, profiles/r05_ew_grid.md).
+template <auto KERNEL>
+static inline unsigned ew_blocks_k(int64_t total_threads_needed, int64_t mult) {
+  static const int64_t resident = [] {
+    int per_cu = 0, dev = 0, ncu = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    return (int64_t)per_cu * ncu;
+  }();
+  const int64_t e = ew_env_cap();
+  return ew_blocks_cap(total_threads_needed, mult, e > 0 ? e : resident);
 }
 
 #define DISPATCH_T(dtype, EXPR_F32, EXPR_BF16, EXPR_F16) \
@@ -1049,13 +1072,13 @@ int creid_bn2d_apply_mask(const void* x, const float* scale_shift, const void* r
   if (mask_out && dtype == CREID_F32) return CREID_E_DTYPE;    // the bit mask is defined per 8-channel (16-byte bf16/f16) chunk
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks_k<bn2d_apply_kernel<float>>(M * C / 4, C / 4)), dim3(256), 0, s,
                                 (const float*)x, scale_shift, (const float*)residual, relu, M, (int)C, (float*)y,
                                 (uint8_t*)nullptr, (const float*)nullptr),
-             hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks_k<bn2d_apply_kernel<unsigned short>>(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, (const unsigned short*)residual, relu, M,
                                 (int)C, (unsigned short*)y, mask_out, (const float*)nullptr),
-             hipLaunchKernelGGL(bn2d_apply_kernel<_Float16>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_apply_kernel<_Float16>, dim3(ew_blocks_k<bn2d_apply_kernel<_Float16>>(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const _Float16*)x, scale_shift, (const _Float16*)residual, relu, M,
                                 (int)C, (_Float16*)y, mask_out, (const float*)nullptr));
   CREID_LAUNCH_RET();
@@ -1097,13 +1120,13 @@ int creid_bn2d_apply_dual_mask(const void* x, const float* scale_shift, const vo
   if (mask_out && dtype == CREID_F32) return CREID_E_DTYPE;
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(ew_blocks_k<bn2d_apply_kernel<float>>(M * C / 4, C / 4)), dim3(256), 0, s,
                                 (const float*)x, scale_shift, (const float*)x_res, relu, M, (int)C, (float*)y,
                                 (uint8_t*)nullptr, scale_shift_res),
-             hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_apply_kernel<unsigned short>, dim3(ew_blocks_k<bn2d_apply_kernel<unsigned short>>(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, (const unsigned short*)x_res, relu, M,
                                 (int)C, (unsigned short*)y, mask_out, scale_shift_res),
-             hipLaunchKernelGGL(bn2d_apply_kernel<_Float16>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_apply_kernel<_Float16>, dim3(ew_blocks_k<bn2d_apply_kernel<_Float16>>(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const _Float16*)x, scale_shift, (const _Float16*)x_res, relu, M,
                                 (int)C, (_Float16*)y, mask_out, scale_shift_res));
   CREID_LAUNCH_RET();
@@ -1146,13 +1169,13 @@ static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const ui
                          (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   }
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks(M * C / 4, C / 4)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks_k<bn2d_bwd_apply_kernel<float>>(M * C / 4, C / 4)), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, sums, M, (int)C,
                                 (float*)dx, (float*)gm_out, (const uint8_t*)nullptr, pg),
-             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<unsigned short>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<unsigned short>, dim3(ew_blocks_k<bn2d_bwd_apply_kernel<unsigned short>>(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, sums, M,
                                 (int)C, (unsigned short*)dx, (unsigned short*)gm_out, mask, pg),
-             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<_Float16>, dim3(ew_blocks(M * C / 8, C / 8)), dim3(256), 0, s,
+             hipLaunchKernelGGL(bn2d_bwd_apply_kernel<_Float16>, dim3(ew_blocks_k<bn2d_bwd_apply_kernel<_Float16>>(M * C / 8, C / 8)), dim3(256), 0, s,
                                 (const _Float16*)x, (const _Float16*)g, (const _Float16*)act, sums, M,
                                 (int)C, (_Float16*)dx, (_Float16*)gm_out, mask, pg));
   CREID_LAUNCH_RET();
