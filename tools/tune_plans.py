@@ -163,7 +163,10 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
         if cout % tm or K % tn or cin < tn:
             continue
         tiles = (cout // tm) * (K // tn)
-        for sp in SPLITS:
+        # (round 5: besides the fixed ladder, the split counts that FILL the workgroup slots of the chip exactly -- 256 CUs x 1 ... 4
+        #  resident workgroups --: a grid a few workgroups above a full round runs a second round on an almost empty chip, tools/grid_tail.py)
+        fill = sorted({slots // tiles for slots in (256, 512, 768, 1024) if slots // tiles >= 1} - set(SPLITS))
+        for sp in SPLITS + fill:
             if not (160 <= tiles * sp <= 1600) or sp > M // 64:
                 continue
             lib.creid_tune_set(0, M, cout, K, s << 1, tm, tn, sp)
@@ -176,7 +179,8 @@ for (cin, cout, k, s, h, w), cnt in seen.items():
         if cout % tm or K % tn or cin < tn:
             continue
         tiles = (cout // tm) * (K // tn)
-        for sp in SPLITS:
+        fill = sorted({slots // tiles for slots in (256, 512) if slots // tiles >= 1} - set(SPLITS))
+        for sp in SPLITS + fill:
             if not (96 <= tiles * sp <= 800) or sp > M // 128:
                 continue
             for depth in (0, 3):
