@@ -1708,9 +1708,18 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(const T* __restrict_
 extern "C" {
 
 // workgroups per image for the IBN apply passes: ~4 vectors per thread, at most 64 per image
-static unsigned ibn_img_blocks(int64_t vecs_per_image) {
+// blocks per image of the per-image grid-stride IBN kernels (grid = (blocks, B)).  Round 5: a whole number of rounds -- with B images
+// the grid is trimmed to the largest multiple of the ~2048 workgroups the chip holds that does not exceed what was asked for
+// (configs[3] training, B = 56: 50 blocks per image = 2800 workgroups = 1.37 rounds -> 36 = 2016, one round; profiles/r05_ew_grid.md)
+static unsigned ibn_img_blocks(int64_t vecs_per_image, int64_t B = 1) {
   int64_t b = (vecs_per_image + 1023) / 1024;
-  return (unsigned)(b < 1 ? 1 : (b > 64 ? 64 : b));
+  b = b < 1 ? 1 : (b > 64 ? 64 : b);
+  const int64_t resident = 2048, total = b * B;
+  if (total > resident) {
+    const int64_t trimmed = (total / resident) * resident / B;
+    if (trimmed >= 1 && trimmed < b) b = trimmed;
+  }
+  return (unsigned)b;
 }
 
 int64_t creid_ibn_rows_per_image(int64_t HW) { int64_t r = (HW + 127) / 128; return r < 1 ? 1 : r; }
@@ -1738,11 +1747,11 @@ int creid_ibn_fwd_mask(const void* x, int64_t B, int64_t HW, int64_t C, int64_t 
                      rpi, (int)HW, (int)C, (int)c_in, in_w, in_b, bn_w, bn_b, running_mean, running_var, training, momentum,
                      eps, mean_out, invstd_out, scale_shift);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(ibn_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4), (unsigned)B), dim3(256), 0, s, (const float*)x,
+             hipLaunchKernelGGL(ibn_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4, B), (unsigned)B), dim3(256), 0, s, (const float*)x,
                                 scale_shift, relu, B * HW, (int)HW, (int)C, (float*)y, (uint8_t*)nullptr),
-             hipLaunchKernelGGL(ibn_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
+             hipLaunchKernelGGL(ibn_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8, B), (unsigned)B), dim3(256), 0, s,
                                 (const unsigned short*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (unsigned short*)y, mask_out),
-             hipLaunchKernelGGL(ibn_apply_kernel<_Float16>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
+             hipLaunchKernelGGL(ibn_apply_kernel<_Float16>, dim3(ibn_img_blocks(HW * C / 8, B), (unsigned)B), dim3(256), 0, s,
                                 (const _Float16*)x, scale_shift, relu, B * HW, (int)HW, (int)C, (_Float16*)y, mask_out));
   CREID_LAUNCH_RET();
 }
@@ -1781,12 +1790,12 @@ int creid_ibn_bwd_mask(const void* x, const void* g, const void* act, const uint
   hipLaunchKernelGGL(ibn_in_grad_kernel, dim3((unsigned)((c_in + 15) / 16)), dim3(1024), 0, s, per_img, (int)B, (int)c_in,
                      d_in_w, d_in_b);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(ibn_bwd_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4), (unsigned)B), dim3(256), 0, s,
+             hipLaunchKernelGGL(ibn_bwd_apply_kernel<float>, dim3(ibn_img_blocks(HW * C / 4, B), (unsigned)B), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, coef, B * HW, (int)HW, (int)C, (float*)dx, (const uint8_t*)nullptr),
-             hipLaunchKernelGGL(ibn_bwd_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
+             hipLaunchKernelGGL(ibn_bwd_apply_kernel<unsigned short>, dim3(ibn_img_blocks(HW * C / 8, B), (unsigned)B), dim3(256), 0, s,
                                 (const unsigned short*)x, (const unsigned short*)g, (const unsigned short*)act, coef, B * HW,
                                 (int)HW, (int)C, (unsigned short*)dx, mask),
-             hipLaunchKernelGGL(ibn_bwd_apply_kernel<_Float16>, dim3(ibn_img_blocks(HW * C / 8), (unsigned)B), dim3(256), 0, s,
+             hipLaunchKernelGGL(ibn_bwd_apply_kernel<_Float16>, dim3(ibn_img_blocks(HW * C / 8, B), (unsigned)B), dim3(256), 0, s,
                                 (const _Float16*)x, (const _Float16*)g, (const _Float16*)act, coef, B * HW,
                                 (int)HW, (int)C, (_Float16*)dx, mask));
   CREID_LAUNCH_RET();
