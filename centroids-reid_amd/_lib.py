@@ -48,6 +48,8 @@ SIGNATURES = {
     "creid_loo_emb_fwd_rows_lonely": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_triplet_fwd_batched_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _f32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "creid_ctl_round_scale": (C.c_int, [_p, _i64, _p, _p]),
+    "creid_ctl_heads_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
+    "creid_ctl_heads_fused": (C.c_int, [_p, _p]),
     "creid_ctl_step_stats_rows": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p]),
     "creid_center_loss_fwd_masked": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "creid_center_loss_bwd_masked": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _f32, _p, _p, _p]),
@@ -139,6 +141,18 @@ class ConvDesc(C.Structure):
     """creid_conv_desc of include/creid.h."""
     _fields_ = [("batch", _i64), ("in_h", _i64), ("in_w", _i64), ("in_c", _i64), ("out_h", _i64), ("out_w", _i64),
                 ("out_c", _i64), ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32)]
+
+
+class CtlHeads(C.Structure):
+    """creid_ctl_heads of include/creid.h (tests/test_abi_cpu.py compares the two field lists)."""
+    _fields_ = ([(n, _i64) for n in ("B", "P", "K", "D", "num_classes", "num_centers", "HW")] +
+                [(n, _i32) for n in ("g_dtype", "masked", "split_logits", "split_dbnf")] +
+                [(n, _f32) for n in ("margin", "xent_eps", "w_query", "w_center", "w_xent", "w_centroid", "bn_momentum", "bn_eps")] +
+                [(n, _p) for n in ("feat", "labels", "is_real", "centers", "bn_weight", "bn_bias", "bn_running_mean",
+                                   "bn_running_var", "fc_weight", "loss_weights", "amp_state", "d_centers", "d_bn_weight",
+                                   "d_bn_bias", "d_fc_weight", "bn_batches_tracked", "lonely", "stats", "g", "dfeat_out",
+                                   "workspace")] +
+                [("workspace_bytes", _sz)])
 
 
 class CreidError(RuntimeError):

@@ -845,21 +845,26 @@ class BackboneEngine:
                 "conv2d_dgrad")
         return dx, None
 
-    def backward(self, dfeat: torch.Tensor):
+    def backward(self, dfeat: torch.Tensor, g: torch.Tensor = None):
         """Accumulates parameter gradients into `.grad` (fp32, reference layouts).  `self.on_group_done(k)`, if set,
         is called after the last kernel of layer k (4, 3, 2, 1) has been enqueued -- every gradient of that layer is
-        then final in stream order (the data-parallel bucketed all-reduce hangs on it, parallel.py)."""
+        then final in stream order (the data-parallel bucketed all-reduce hangs on it, parallel.py).
+        g (optional, [B * h * w, 2048] in the compute dtype): the gradient of the final feature map, already pooled back and (f16)
+        loss-scaled -- the last launch of creid_ctl_heads_fused writes it; `dfeat` is ignored then."""
         sv = self.saved
         assert sv is not None and sv["training"], "backward() needs a training-mode forward first"
         lib, st = L.lib(), L.stream()
         self._bn_sums.clear()
         B = sv["B"]
         h, w = sv["final"]
-        dfeat = dfeat.contiguous().float()
-        if self.loss_scaler is not None and self.dtype == torch.float16:
-            dfeat = self.loss_scaler.scale_(dfeat)        # every f16 gradient tensor / backbone parameter gradient below is scaled
-        g = self._empty(B * h * w, 2048)
-        L.check(lib.creid_gap_bwd(L.ptr(dfeat), B, h * w, 2048, self.dt, L.ptr(g), st), "gap_bwd")
+        if g is None:
+            dfeat = dfeat.contiguous().float()
+            if self.loss_scaler is not None and self.dtype == torch.float16:
+                dfeat = self.loss_scaler.scale_(dfeat)        # every f16 gradient tensor / backbone parameter gradient below is scaled
+            g = self._empty(B * h * w, 2048)
+            L.check(lib.creid_gap_bwd(L.ptr(dfeat), B, h * w, 2048, self.dt, L.ptr(g), st), "gap_bwd")
+        else:
+            assert g.dtype == self.dtype and tuple(g.shape) == (B * h * w, 2048) and g.is_contiguous()
         blocks = list(zip(self.blocks, sv["blocks"]))
         part3 = None                      # bn3 partials of the CURRENT block, produced by the previous (deeper) block
         for bi in range(len(blocks) - 1, -1, -1):

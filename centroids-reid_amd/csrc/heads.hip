@@ -8,6 +8,7 @@
 // design goal is few launches, wave-level reductions (no atomics -> deterministic) and
 // features streamed once per workgroup with 16-byte loads.
 #include "common.hpp"
+#include "gemm_f32_body.hpp"
 
 // ======================================================================================
 // B2: leave-one-out centroids.  grid (P, K); centroid[i,p,:] = sum_{s!=i, real} f[p,s,:]/max(cnt,1)
@@ -62,23 +63,23 @@ __global__ __launch_bounds__(256) void loo_centroids_bwd_kernel(const float* __r
 // clamp(|1 - x.y|, 1e-12) on rows that the caller has already scaled to unit length (triplet_loss.py:44-65).
 constexpr int TM_T = 1024, TM_W = TM_T / 64;
 template <int KIND>
-__global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void triplet_mine_body(const float* __restrict__ x,
                                                            const int64_t* __restrict__ labels, int N, int D,
                                                            float* __restrict__ dist_ap, float* __restrict__ dist_an,
                                                            int32_t* __restrict__ p_idx, int32_t* __restrict__ n_idx,
                                                            float* __restrict__ dist_row_out /* nullable [N,N] */,
                                                            const uint8_t* __restrict__ exists /* nullable [N]: rows that are
-                                                           part of the problem at all (neither anchors nor candidates otherwise) */) {
+                                                           part of the problem at all (neither anchors nor candidates otherwise) */, const int bx_, const int by_) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [D] anchor row, then [N] distances
   float* xa = sm;
   float* drow = sm + D;
-  {                                                            // blockIdx.y = independent problem (centroid round)
-    const int64_t bo = (int64_t)blockIdx.y * N;
+  {                                                            // by_ = independent problem (centroid round)
+    const int64_t bo = (int64_t)by_ * N;
     x += bo * D; labels += bo; dist_ap += bo; dist_an += bo; p_idx += bo; n_idx += bo;
     if (dist_row_out) dist_row_out += bo * N;
     if (exists) exists += bo;
   }
-  const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a = bx_, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xap = x + (int64_t)a * D;
   float saa = 0.f;
   for (int d = tid; d < D; d += TM_T) { float v = xap[d]; xa[d] = v; }
@@ -128,20 +129,30 @@ __global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restr
     if (lane == 0) { dist_ap[a] = bp; dist_an[a] = bn; p_idx[a] = ip; n_idx[a] = in_; }
   }
 }
+template <int KIND>
+__global__ __launch_bounds__(TM_T) void triplet_mine_kernel(const float* __restrict__ x,
+                                                           const int64_t* __restrict__ labels, int N, int D,
+                                                           float* __restrict__ dist_ap, float* __restrict__ dist_an,
+                                                           int32_t* __restrict__ p_idx, int32_t* __restrict__ n_idx,
+                                                           float* __restrict__ dist_row_out /* nullable [N,N] */,
+                                                           const uint8_t* __restrict__ exists /* nullable [N]: rows that are
+                                                           part of the problem at all (neither anchors nor candidates otherwise) */) {
+  triplet_mine_body<KIND>(x, labels, N, D, dist_ap, dist_an, p_idx, n_idx, dist_row_out, exists, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // loss over (masked) anchors; coef[a] = d loss / d dist_ap[a] ( = - d loss / d dist_an[a]).
 // margin >= 0: MarginRankingLoss mean(max(0, ap - an + margin)); margin < 0: SoftMarginLoss.
 // out[0]=loss, out[1]=mean ap, out[2]=mean an, out[3]=#anchors.
-__global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restrict__ dist_ap,
+__device__ __forceinline__ void triplet_loss_body(const float* __restrict__ dist_ap,
                                                            const float* __restrict__ dist_an,
                                                            const uint8_t* __restrict__ mask, int N, float margin,
                                                            float* __restrict__ out, float* __restrict__ coef,
                                                            int min_anchors /* fewer anchors: the problem is skipped (a centroid
-                                                           round with <= 1 valid identity, train_ctl_model.py:113) */) {
+                                                           round with <= 1 valid identity, train_ctl_model.py:113) */, const int bx_, const int by_) {
   __shared__ float s[4][4];
   {
-    const int64_t bo = (int64_t)blockIdx.y * N;
-    dist_ap += bo; dist_an += bo; out += (int64_t)blockIdx.y * 4;
+    const int64_t bo = (int64_t)by_ * N;
+    dist_ap += bo; dist_an += bo; out += (int64_t)by_ * 4;
     if (mask) mask += bo;
     if (coef) coef += bo;
   }
@@ -186,18 +197,26 @@ __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restri
     out[3] = nm;
   }
 }
+__global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restrict__ dist_ap,
+                                                           const float* __restrict__ dist_an,
+                                                           const uint8_t* __restrict__ mask, int N, float margin,
+                                                           float* __restrict__ out, float* __restrict__ coef,
+                                                           int min_anchors /* fewer anchors: the problem is skipped (a centroid
+                                                           round with <= 1 valid identity, train_ctl_model.py:113) */) {
+  triplet_loss_body(dist_ap, dist_an, mask, N, margin, out, coef, min_anchors, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // dx[r,:] += g * sum_a coef[a] * ( [a==r]((xa-xp)/dap - (xa-xn)/dan) + [p_a==r](xp-xa)/dap - [n_a==r](xn-xa)/dan )
 // (gradient of sqrt(clamp(.)) is zero where the clamp was active: dist <= 1e-6).  One workgroup per row.
 template <int KIND>
-__global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ x, int N, int D,
+__device__ __forceinline__ void triplet_bwd_body(const float* __restrict__ x, int N, int D,
                                                           const float* __restrict__ dist_ap,
                                                           const float* __restrict__ dist_an,
                                                           const int32_t* __restrict__ p_idx,
                                                           const int32_t* __restrict__ n_idx,
                                                           const float* __restrict__ coef,
                                                           const float* __restrict__ gscale_ptr, float gscale,
-                                                          float* __restrict__ dx) {
+                                                          float* __restrict__ dx, const int bx_, const int by_) {
   // phase 1: the (few) anchors that touch this row, compacted IN ANCHOR ORDER into LDS as
   // (other row, signed coefficient) terms:  dx[r] += sum_terms w * (x[r] - x[other])
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -205,10 +224,10 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
   float* t_w = sm + 4 * N;
   __shared__ int n_terms;
   {
-    const int64_t bo = (int64_t)blockIdx.y * N;
+    const int64_t bo = (int64_t)by_ * N;
     x += bo * D; dist_ap += bo; dist_an += bo; p_idx += bo; n_idx += bo; coef += bo; dx += bo * D;
   }
-  const int r = blockIdx.x;
+  const int r = bx_;
   // one thread per anchor (all loads in flight at once; a single thread walking the N anchors spent ~10 us in dependent
   // loads), then the terms are compacted in anchor order by an exclusive scan of the per-anchor counts
   __shared__ int t_cnt[256];
@@ -278,17 +297,28 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
     out[d] += g * acc;
   }
 }
+template <int KIND>
+__global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ x, int N, int D,
+                                                          const float* __restrict__ dist_ap,
+                                                          const float* __restrict__ dist_an,
+                                                          const int32_t* __restrict__ p_idx,
+                                                          const int32_t* __restrict__ n_idx,
+                                                          const float* __restrict__ coef,
+                                                          const float* __restrict__ gscale_ptr, float gscale,
+                                                          float* __restrict__ dx) {
+  triplet_bwd_body<KIND>(x, N, D, dist_ap, dist_an, p_idx, n_idx, coef, gscale_ptr, gscale, dx, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // ======================================================================================
 // C4: center loss.  row_loss[b] = clamp(|x_b|^2 + |c_y|^2 - 2 x_b.c_y, 1e-12, 1e12) (expanded form
 // like the reference); loss = (sum_b row_loss + B*(C-1)*1e-12)/B.
 // ======================================================================================
-__global__ __launch_bounds__(256) void center_row_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void center_row_body(const float* __restrict__ x,
                                                          const int64_t* __restrict__ labels,
                                                          const float* __restrict__ centers, int D,
-                                                         float* __restrict__ row_loss) {
+                                                         float* __restrict__ row_loss, const int bx_, const int by_) {
   __shared__ float s[4][3];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = bx_, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xb = x + (int64_t)b * D;
   const float* c = centers + labels[b] * D;
   float xx = 0.f, cc = 0.f, xc = 0.f;
@@ -307,6 +337,12 @@ __global__ __launch_bounds__(256) void center_row_kernel(const float* __restrict
     row_loss[b] = dv;   // unclamped; the reduce kernel clamps (and bwd needs the clamp state)
   }
 }
+__global__ __launch_bounds__(256) void center_row_kernel(const float* __restrict__ x,
+                                                         const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ centers, int D,
+                                                         float* __restrict__ row_loss) {
+  center_row_body(x, labels, centers, D, row_loss, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // number of rows with mask != 0 (all B when mask is NULL), by every thread of a 256-thread workgroup; `sc` = 4 ints of LDS
 __device__ __forceinline__ int masked_row_count(const uint8_t* __restrict__ mask, int B, int* sc) {
@@ -321,8 +357,8 @@ __device__ __forceinline__ int masked_row_count(const uint8_t* __restrict__ mask
 }
 
 // mask (nullable, uint8 [B]): the rows the loss is taken over -- train_ctl_model.py:69-73 feeds features[isReal] only
-__global__ __launch_bounds__(256) void center_reduce_kernel(const float* __restrict__ row_loss, int B, int C,
-                                                            float* __restrict__ out, const uint8_t* __restrict__ mask) {
+__device__ __forceinline__ void center_reduce_body(const float* __restrict__ row_loss, int B, int C,
+                                                            float* __restrict__ out, const uint8_t* __restrict__ mask, const int bx_, const int by_) {
   __shared__ float s[4];
   __shared__ int sc[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -334,17 +370,21 @@ __global__ __launch_bounds__(256) void center_reduce_kernel(const float* __restr
   __syncthreads();
   if (tid == 0) out[0] = nb > 0 ? (((s[0] + s[1]) + (s[2] + s[3])) + (float)nb * (float)(C - 1) * 1e-12f) / (float)nb : 0.f;
 }
+__global__ __launch_bounds__(256) void center_reduce_kernel(const float* __restrict__ row_loss, int B, int C,
+                                                            float* __restrict__ out, const uint8_t* __restrict__ mask) {
+  center_reduce_body(row_loss, B, C, out, mask, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // dx[b] += g*(2/B)(x_b - c_y) ; dcenters[y] (+)= g*(2/B) sum_{b:y_b=y}(c_y - x_b), written once per
 // distinct label by the workgroup of its FIRST occurrence (deterministic, no atomics).
-__global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void center_bwd_body(const float* __restrict__ x,
                                                          const int64_t* __restrict__ labels,
                                                          const float* __restrict__ centers,
                                                          const float* __restrict__ row_loss, int B, int D,
                                                          const float* __restrict__ gscale_ptr, float gscale,
                                                          float* __restrict__ dx, float* __restrict__ dcenters,
-                                                         const uint8_t* __restrict__ mask) {
-  const int b = blockIdx.x;
+                                                         const uint8_t* __restrict__ mask, const int bx_, const int by_) {
+  const int b = bx_;
   const int64_t y = labels[b];
   __shared__ int sc[4];
   const int nb = masked_row_count(mask, B, sc);
@@ -391,19 +431,28 @@ __global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict
     }
   }
 }
+__global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict__ x,
+                                                         const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ centers,
+                                                         const float* __restrict__ row_loss, int B, int D,
+                                                         const float* __restrict__ gscale_ptr, float gscale,
+                                                         float* __restrict__ dx, float* __restrict__ dcenters,
+                                                         const uint8_t* __restrict__ mask) {
+  center_bwd_body(x, labels, centers, row_loss, B, D, gscale_ptr, gscale, dx, dcenters, mask, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // ======================================================================================
 // C6: label-smoothed cross entropy, fwd + bwd in one pass.  One workgroup per row.
 // row_loss[b] = -sum_c t_c logp_c, t = (1-eps) onehot + eps/C ; dlogits = (softmax - t) * g / B.
 // ======================================================================================
-__global__ __launch_bounds__(256) void xent_ls_kernel(const float* __restrict__ logits,
+__device__ __forceinline__ void xent_ls_body(const float* __restrict__ logits,
                                                       const int64_t* __restrict__ targets, int B, int C, float eps,
                                                       float* __restrict__ row_loss, float* __restrict__ dlogits,
-                                                      float gscale, const uint8_t* __restrict__ mask) {
+                                                      float gscale, const uint8_t* __restrict__ mask, const int bx_, const int by_) {
   __shared__ float s[4];
   __shared__ float bc;
   __shared__ int sc[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = bx_, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nrows = masked_row_count(mask, B, sc);     // the mean is over the real rows (train_ctl_model.py:74-77)
   if (mask && !mask[b]) {
     if (tid == 0) row_loss[b] = 0.f;
@@ -448,9 +497,15 @@ __global__ __launch_bounds__(256) void xent_ls_kernel(const float* __restrict__ 
     }
   }
 }
+__global__ __launch_bounds__(256) void xent_ls_kernel(const float* __restrict__ logits,
+                                                      const int64_t* __restrict__ targets, int B, int C, float eps,
+                                                      float* __restrict__ row_loss, float* __restrict__ dlogits,
+                                                      float gscale, const uint8_t* __restrict__ mask) {
+  xent_ls_body(logits, targets, B, C, eps, row_loss, dlogits, gscale, mask, (int)blockIdx.x, (int)blockIdx.y);
+}
 
-__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ v, int n, float scale,
-                                                        float* __restrict__ out, const uint8_t* __restrict__ mask) {
+__device__ __forceinline__ void mean_rows_body(const float* __restrict__ v, int n, float scale,
+                                                        float* __restrict__ out, const uint8_t* __restrict__ mask, const int bx_, const int by_) {
   __shared__ float s[4];
   __shared__ int sc[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -462,25 +517,29 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict_
   __syncthreads();
   if (tid == 0) out[0] = ((s[0] + s[1]) + (s[2] + s[3])) * scale;
 }
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ v, int n, float scale,
+                                                        float* __restrict__ out, const uint8_t* __restrict__ mask) {
+  mean_rows_body(v, n, scale, out, mask, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // ======================================================================================
 // A4: BNNeck = BatchNorm1d over [B, D] (B small): thread per feature, loop over rows (coalesced).
 // ======================================================================================
 // 32 channels x 8 row lanes per workgroup (the [B, D] problem is tiny: D/32 workgroups instead of D/256, B/8
 // dependent steps per thread instead of B); row-lane partials meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int B, int D,
+__device__ __forceinline__ void bn1d_fwd_body(const float* __restrict__ x, int B, int D,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        float* __restrict__ rmean, float* __restrict__ rvar,
                                                        int training, float momentum, float eps,
                                                        float* __restrict__ y, float* __restrict__ save_mean,
-                                                       float* __restrict__ save_invstd, const uint8_t* __restrict__ mask) {
+                                                       float* __restrict__ save_invstd, const uint8_t* __restrict__ mask, const int bx_, const int by_) {
   // mask (nullable, uint8 [B]): the batch the statistics are taken over -- the BNNeck sees features[isReal] only
   // (train_ctl_model.py:69-75); masked rows of y are written as 0
   __shared__ float red[8][32];
   __shared__ float s_mean[32], s_inv[32];
   __shared__ int sc[4];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int d = blockIdx.x * 32 + cl;
+  const int d = bx_ * 32 + cl;
   const bool live = d < D;
   const int nb = masked_row_count(mask, B, sc);
   if (training) {
@@ -519,17 +578,25 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
   for (int b = rl; b < B; b += 8)
     y[(int64_t)b * D + d] = (!mask || mask[b]) ? (x[(int64_t)b * D + d] - mean) * invstd * g + be : 0.f;
 }
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int B, int D,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       int training, float momentum, float eps,
+                                                       float* __restrict__ y, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_invstd, const uint8_t* __restrict__ mask) {
+  bn1d_fwd_body(x, B, D, w, bias, rmean, rvar, training, momentum, eps, y, save_mean, save_invstd, mask, (int)blockIdx.x, (int)blockIdx.y);
+}
 
-__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__device__ __forceinline__ void bn1d_bwd_body(const float* __restrict__ x, const float* __restrict__ dy,
                                                        int B, int D, const float* __restrict__ w,
                                                        const float* __restrict__ save_mean,
                                                        const float* __restrict__ save_invstd,
                                                        float* __restrict__ dx, float* __restrict__ dw,
-                                                       float* __restrict__ dbias, const uint8_t* __restrict__ mask) {
+                                                       float* __restrict__ dbias, const uint8_t* __restrict__ mask, const int bx_, const int by_) {
   __shared__ float red[8][2][32];
   __shared__ int sc[4];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int d = blockIdx.x * 32 + cl;
+  const int d = bx_ * 32 + cl;
   const bool live = d < D;
   const int nb = masked_row_count(mask, B, sc);
   const float mean = live ? save_mean[d] : 0.f, invstd = live ? save_invstd[d] : 0.f, g = (live && w) ? w[d] : 1.f;
@@ -556,6 +623,14 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
     const float xh = (x[(int64_t)b * D + d] - mean) * invstd;
     dx[(int64_t)b * D + d] += k * ((float)nb * dy[(int64_t)b * D + d] - sdy - xh * sdyx);
   }
+}
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       int B, int D, const float* __restrict__ w,
+                                                       const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_invstd,
+                                                       float* __restrict__ dx, float* __restrict__ dw,
+                                                       float* __restrict__ dbias, const uint8_t* __restrict__ mask) {
+  bn1d_bwd_body(x, dy, B, D, w, save_mean, save_invstd, dx, dw, dbias, mask, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ======================================================================================
@@ -784,14 +859,14 @@ __global__ __launch_bounds__(256) void clamp_sqrt_kernel(float* __restrict__ d, 
 // round i) = [K][2P][D], lab[i] = labels of the P identities twice.  grid (P, K): workgroup (p, i) writes the query row
 // emb[i][p] = feat[p][i], the leave-one-out centroid emb[i][P + p] (same s-order sum as loo_centroids_fwd_kernel, also to
 // cent[i][p]) and the two label slots -- what torch did with two strided copies, a cat and a contiguous().
-__global__ __launch_bounds__(256) void loo_emb_fwd_kernel(const float* __restrict__ feat, const uint8_t* __restrict__ is_real,
+__device__ __forceinline__ void loo_emb_fwd_body(const float* __restrict__ feat, const uint8_t* __restrict__ is_real,
                                                           const int64_t* __restrict__ labels, int P, int K, int D,
                                                           float* __restrict__ cent, int32_t* __restrict__ valid,
                                                           float* __restrict__ emb, int64_t* __restrict__ lab,
                                                           float* __restrict__ cnorm, uint8_t* __restrict__ exists,
-                                                          int32_t* __restrict__ lonely = nullptr) {
+                                                          int32_t* __restrict__ lonely, const int bx_, const int by_) {
   __shared__ float wsum[4];
-  const int p = blockIdx.x, i = blockIdx.y;
+  const int p = bx_, i = by_;
   const bool qreal = is_real[p * K + i] != 0;
   int cnt = 0;
   if (qreal)
@@ -829,12 +904,20 @@ __global__ __launch_bounds__(256) void loo_emb_fwd_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x == 0) cnorm[i * P + p] = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
 }
+__global__ __launch_bounds__(256) void loo_emb_fwd_kernel(const float* __restrict__ feat, const uint8_t* __restrict__ is_real,
+                                                          const int64_t* __restrict__ labels, int P, int K, int D,
+                                                          float* __restrict__ cent, int32_t* __restrict__ valid,
+                                                          float* __restrict__ emb, int64_t* __restrict__ lab,
+                                                          float* __restrict__ cnorm, uint8_t* __restrict__ exists,
+                                                          int32_t* __restrict__ lonely = nullptr) {
+  loo_emb_fwd_body(feat, is_real, labels, P, K, D, cent, valid, emb, lab, cnorm, exists, lonely, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // dfeat[p][s] += demb[s][p]  (the round's query rows)  +  sum_{i != s, real} demb[i][P + p] / max(cnt_i, 1)  (its share of the
 // other rounds' centroids) -- in that order, i.e. the torch add_ followed by loo_centroids_bwd_kernel.  grid (P, K = s).
-__global__ __launch_bounds__(256) void loo_emb_bwd_kernel(const float* __restrict__ demb, const uint8_t* __restrict__ is_real,
-                                                          int P, int K, int D, float* __restrict__ dfeat) {
-  const int p = blockIdx.x, s = blockIdx.y;
+__device__ __forceinline__ void loo_emb_bwd_body(const float* __restrict__ demb, const uint8_t* __restrict__ is_real,
+                                                          int P, int K, int D, float* __restrict__ dfeat, const int bx_, const int by_) {
+  const int p = bx_, s = by_;
   float* out = dfeat + ((int64_t)p * K + s) * D;
   const float* dq = demb + ((int64_t)s * 2 * P + p) * D;
   const bool sreal = is_real[p * K + s] != 0;
@@ -862,13 +945,17 @@ __global__ __launch_bounds__(256) void loo_emb_bwd_kernel(const float* __restric
     out[d] = o;
   }
 }
+__global__ __launch_bounds__(256) void loo_emb_bwd_kernel(const float* __restrict__ demb, const uint8_t* __restrict__ is_real,
+                                                          int P, int K, int D, float* __restrict__ dfeat) {
+  loo_emb_bwd_body(demb, is_real, P, K, D, dfeat, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // Scalars of one training step (train_ctl_model.py:143-177) in one launch: terms = scal * w, total = sum(terms),
 // step = sum of the K round losses (terms[4], terms[8], ...), rounds = mean over the K rows of out4[1:], l2 = mean of the
 // centroid row norms (loo_emb_fwd_kernel's cnorm).  out: [n] terms, then {total, step, rounds[0..3], l2}.  One wave.
-__global__ __launch_bounds__(64) void ctl_step_stats_kernel(const float* __restrict__ scal, const float* __restrict__ w, int n,
+__device__ __forceinline__ void ctl_step_stats_body(const float* __restrict__ scal, const float* __restrict__ w, int n,
                                                             int K, const float* __restrict__ cnorm, int rows,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, const int bx_, const int by_) {
   const int lane = threadIdx.x;
   float l2 = 0.f;
   for (int r = lane; r < rows; r += 64) l2 += cnorm[r];
@@ -890,21 +977,29 @@ __global__ __launch_bounds__(64) void ctl_step_stats_kernel(const float* __restr
     out[n + 6] = l2 / (float)rows;
   }
 }
+__global__ __launch_bounds__(64) void ctl_step_stats_kernel(const float* __restrict__ scal, const float* __restrict__ w, int n,
+                                                            int K, const float* __restrict__ cnorm, int rows,
+                                                            float* __restrict__ out) {
+  ctl_step_stats_body(scal, w, n, K, cnorm, rows, out, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // Batches with padded (isReal = False) samples: a centroid round counts only if it kept >= 2 identities (out4 slot 3 = its
 // number of anchors = 2 x identities; triplet_loss_kernel zeroed the round otherwise).  inv_rounds[0] = 1 / #valid rounds
 // (0 if none) -- the device-side factor of the rounds' backward (train_ctl_model.py:143-146: mean over the valid rounds).
-__global__ void ctl_round_scale_kernel(const float* __restrict__ out4_rounds, int K, float* __restrict__ inv_rounds) {
+__device__ __forceinline__ void ctl_round_scale_body(const float* __restrict__ out4_rounds, int K, float* __restrict__ inv_rounds, const int bx_, const int by_) {
   int nv = 0;
   for (int k = 0; k < K; ++k) nv += out4_rounds[4 * k + 3] >= 4.f ? 1 : 0;
   inv_rounds[0] = nv > 0 ? 1.0f / (float)nv : 0.f;
 }
+__global__ void ctl_round_scale_kernel(const float* __restrict__ out4_rounds, int K, float* __restrict__ inv_rounds) {
+  ctl_round_scale_body(out4_rounds, K, inv_rounds, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // ctl_step_stats_kernel for such batches: w[4k] (round losses) must hold the FULL centroid weight (not weight / K); the round
 // means divide by the number of valid rounds; l2 = mean over valid rounds of the mean centroid norm of the round's kept rows.
-__global__ __launch_bounds__(64) void ctl_step_stats_rows_kernel(const float* __restrict__ scal, const float* __restrict__ w, int n,
+__device__ __forceinline__ void ctl_step_stats_rows_body(const float* __restrict__ scal, const float* __restrict__ w, int n,
                                                                  int K, int P, const float* __restrict__ cnorm,
-                                                                 const uint8_t* __restrict__ exists, float* __restrict__ out) {
+                                                                 const uint8_t* __restrict__ exists, float* __restrict__ out, const int bx_, const int by_) {
   if (threadIdx.x != 0) return;
   int nv = 0;
   for (int k = 1; k <= K; ++k) nv += scal[4 * k + 3] >= 4.f ? 1 : 0;
@@ -932,6 +1027,264 @@ __global__ __launch_bounds__(64) void ctl_step_stats_rows_kernel(const float* __
     l2 += a / (float)c;
   }
   out[n + 6] = l2 * inv;
+}
+__global__ __launch_bounds__(64) void ctl_step_stats_rows_kernel(const float* __restrict__ scal, const float* __restrict__ w, int n,
+                                                                 int K, int P, const float* __restrict__ cnorm,
+                                                                 const uint8_t* __restrict__ exists, float* __restrict__ out) {
+  ctl_step_stats_rows_body(scal, w, n, K, P, cnorm, exists, out, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ======================================================================================
+// The whole head section of one training step (train_ctl_model.py:59-152 between the backbone forward and its backward) as SIX
+// launches.  Every kernel above is latency-bound (64 x 2048 features): run back to back, the 23 launches of the hand-scheduled
+// step cost ~205 us at B = 64, almost all of it dependent-launch latency.  Four chains are independent of each other -- query
+// triplet, center loss, BNNeck -> classifier -> cross entropy, centroid rounds -- so each STAGE below is one launch whose
+// workgroups take ROLES (the bodies above, by block index); a stage boundary is a real dependency.  The accumulation order into
+// dfeat is the sequential schedule's (query triplet, center, BNNeck, centroid rounds): results are bit-identical to it.
+//   S1 zero the accumulators | mine (query) | center rows | BNNeck forward | leave-one-out centroids + round operands
+//   S2 classifier forward | query triplet loss | center reduce | mine (K rounds)
+//   S3 cross entropy (+ dlogits) | query triplet backward -> dfeat | round losses
+//   S4 classifier dgrad | classifier wgrad | center backward -> dfeat | cross-entropy mean | rounds backward (unmasked) / round count (masked)
+//   S5 BNNeck backward -> dfeat | step scalars | rounds backward (masked)
+//   S6 leave-one-out backward -> dfeat, and the global-average-pool backward of the finished dfeat rows (the backbone's incoming
+//      gradient [B * HW, D] in its compute dtype, times the f16 loss scale if one is given)
+// ======================================================================================
+struct HeadsWs {                                       // carved out of creid_ctl_heads.workspace (see heads_carve)
+  float *dfeat, *demb, *logits, *dbnf;                 // zeroed by S1 (one contiguous region of zero_count floats)
+  int64_t zero_count;
+  float *dlogits, *bnf, *save_mean, *save_invstd, *row_c, *row_x, *scal, *inv_rounds;
+  float *dap_q, *dan_q, *coef_q, *dap_r, *dan_r, *coef_r;
+  int32_t *pi_q, *ni_q, *pi_r, *ni_r, *valid;
+  float *cent, *emb, *cnorm;
+  int64_t* lab;
+  uint8_t* rows;
+};
+
+static size_t heads_carve(int64_t B, int64_t P, int64_t K, int64_t D, int64_t C, char* base, HeadsWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
+  const int64_t R = K * 2 * P;
+  // the zeroed region: sizes rounded so that every member starts 16-byte aligned and the region is one float4 sweep
+  const int64_t n_dfeat = B * D, n_demb = R * D, n_logits = (B * C + 3) / 4 * 4, n_dbnf = B * D;
+  float* z = (float*)take((size_t)(n_dfeat + n_demb + n_logits + n_dbnf) * 4);
+  HeadsWs t;
+  t.dfeat = z; t.demb = z ? z + n_dfeat : nullptr; t.logits = z ? z + n_dfeat + n_demb : nullptr;
+  t.dbnf = z ? z + n_dfeat + n_demb + n_logits : nullptr;
+  t.zero_count = n_dfeat + n_demb + n_logits + n_dbnf;
+  t.dlogits = (float*)take((size_t)B * C * 4); t.bnf = (float*)take((size_t)B * D * 4);
+  t.save_mean = (float*)take((size_t)D * 4); t.save_invstd = (float*)take((size_t)D * 4);
+  t.row_c = (float*)take((size_t)B * 4); t.row_x = (float*)take((size_t)B * 4);
+  t.scal = (float*)take((size_t)(4 * (K + 1) + 2) * 4); t.inv_rounds = (float*)take(4);
+  t.dap_q = (float*)take((size_t)B * 4); t.dan_q = (float*)take((size_t)B * 4); t.coef_q = (float*)take((size_t)B * 4);
+  t.pi_q = (int32_t*)take((size_t)B * 4); t.ni_q = (int32_t*)take((size_t)B * 4);
+  t.dap_r = (float*)take((size_t)R * 4); t.dan_r = (float*)take((size_t)R * 4); t.coef_r = (float*)take((size_t)R * 4);
+  t.pi_r = (int32_t*)take((size_t)R * 4); t.ni_r = (int32_t*)take((size_t)R * 4);
+  t.cent = (float*)take((size_t)K * P * D * 4); t.valid = (int32_t*)take((size_t)K * P * 4);
+  t.emb = (float*)take((size_t)R * D * 4); t.lab = (int64_t*)take((size_t)R * 8);
+  t.cnorm = (float*)take((size_t)K * P * 4); t.rows = (uint8_t*)take((size_t)R);
+  if (w) *w = t;
+  return off;
+}
+
+struct HeadsCtx {
+  creid_ctl_heads a;
+  HeadsWs w;
+  const uint8_t* mask;                                 // a.is_real on the masked schedule, NULL otherwise
+  int gl_tn, gl_tm, gd_tn, gd_tm, gw_tn, gw_tm;        // 64 x 64 output tiles of the three classifier GEMMs
+};
+
+constexpr int HEADS_ZERO_WGS = 48;
+
+__global__ __launch_bounds__(1024) void heads_stage1_kernel(HeadsCtx c) {
+  const creid_ctl_heads& a = c.a;
+  const int B = (int)a.B, P = (int)a.P, K = (int)a.K, D = (int)a.D;
+  int b = (int)blockIdx.x;
+  if (b < HEADS_ZERO_WGS) {
+    float4* z = reinterpret_cast<float4*>(c.w.dfeat);
+    const int64_t n4 = c.w.zero_count / 4;
+    for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < n4; i += (int64_t)HEADS_ZERO_WGS * 1024) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  b -= HEADS_ZERO_WGS;
+  if (b < B) {                                         // query triplet: distances of anchor b to every row + hardest pos / neg
+    triplet_mine_body<0>(a.feat, a.labels, B, D, c.w.dap_q, c.w.dan_q, c.w.pi_q, c.w.ni_q, nullptr, nullptr, b, 0);
+    return;
+  }
+  b -= B;
+  if (threadIdx.x >= 256) return;                      // the remaining roles are 256-thread workgroups
+  if (b < B) { center_row_body(a.feat, a.labels, a.centers, D, c.w.row_c, b, 0); return; }
+  b -= B;
+  const int nbn = (D + 31) / 32;
+  if (b < nbn) {
+    if (b == 0 && threadIdx.x == 0 && a.bn_batches_tracked) *a.bn_batches_tracked += 1;
+    bn1d_fwd_body(a.feat, B, D, a.bn_weight, a.bn_bias, a.bn_running_mean, a.bn_running_var, 1, a.bn_momentum, a.bn_eps, c.w.bnf,
+                  c.w.save_mean, c.w.save_invstd, c.mask, b, 0);
+    return;
+  }
+  b -= nbn;
+  loo_emb_fwd_body(a.feat, a.is_real, a.labels, P, K, D, c.w.cent, c.w.valid, c.w.emb, c.w.lab, c.w.cnorm,
+                   a.masked ? c.w.rows : nullptr, a.masked ? a.lonely : nullptr, b % P, b / P);
+}
+
+__global__ __launch_bounds__(1024) void heads_stage2_kernel(HeadsCtx c) {
+  const creid_ctl_heads& a = c.a;
+  const int B = (int)a.B, P = (int)a.P, K = (int)a.K, D = (int)a.D, C = (int)a.num_classes;
+  int b = (int)blockIdx.x;
+  const int R = 2 * P;
+  if (b < K * R) {                                     // the K centroid rounds: anchor b % 2P of round b / 2P
+    triplet_mine_body<0>(c.w.emb, c.w.lab, R, D, c.w.dap_r, c.w.dan_r, c.w.pi_r, c.w.ni_r, nullptr,
+                         a.masked ? c.w.rows : nullptr, b % R, b / R);
+    return;
+  }
+  b -= K * R;
+  if (threadIdx.x >= 256) return;
+  const int ngl = c.gl_tn * c.gl_tm * a.split_logits;
+  if (b < ngl) {                                       // logits = bnf . W^T   (modelling/bases.py:86 fc_query)
+    gemm_f32_body(c.w.bnf, D, 1, a.fc_weight, 1, D, c.w.logits, C, B, C, D, 1.f, 0.f, a.split_logits, b % c.gl_tn,
+                  (b / c.gl_tn) % c.gl_tm, b / (c.gl_tn * c.gl_tm));
+    return;
+  }
+  b -= ngl;
+  if (b == 0) { triplet_loss_body(c.w.dap_q, c.w.dan_q, c.mask, B, a.margin, c.w.scal, c.w.coef_q, 0, 0, 0); return; }
+  center_reduce_body(c.w.row_c, B, (int)a.num_centers, c.w.scal + 4 * (K + 1), c.mask, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void heads_stage3_kernel(HeadsCtx c) {
+  const creid_ctl_heads& a = c.a;
+  const int B = (int)a.B, P = (int)a.P, D = (int)a.D, C = (int)a.num_classes;
+  int b = (int)blockIdx.x;
+  if (b < B) { xent_ls_body(c.w.logits, a.labels, B, C, a.xent_eps, c.w.row_x, c.w.dlogits, a.w_xent, c.mask, b, 0); return; }
+  b -= B;
+  if (b < B) {
+    triplet_bwd_body<0>(a.feat, B, D, c.w.dap_q, c.w.dan_q, c.w.pi_q, c.w.ni_q, c.w.coef_q, nullptr, a.w_query, c.w.dfeat, b, 0);
+    return;
+  }
+  b -= B;                                              // round b: loss over its (kept) anchors
+  triplet_loss_body(c.w.dap_r, c.w.dan_r, a.masked ? c.w.rows : nullptr, 2 * P, a.margin, c.w.scal + 4, c.w.coef_r,
+                    a.masked ? 4 : 0, 0, b);
+}
+
+__global__ __launch_bounds__(256) void heads_stage4_kernel(HeadsCtx c) {
+  const creid_ctl_heads& a = c.a;
+  const int B = (int)a.B, P = (int)a.P, K = (int)a.K, D = (int)a.D, C = (int)a.num_classes;
+  int b = (int)blockIdx.x;
+  const int ngd = c.gd_tn * c.gd_tm * a.split_dbnf;
+  if (b < ngd) {                                       // dbnf = dlogits . W
+    gemm_f32_body(c.w.dlogits, C, 1, a.fc_weight, D, 1, c.w.dbnf, D, B, D, C, 1.f, 0.f, a.split_dbnf, b % c.gd_tn,
+                  (b / c.gd_tn) % c.gd_tm, b / (c.gd_tn * c.gd_tm));
+    return;
+  }
+  b -= ngd;
+  const int ngw = a.d_fc_weight ? c.gw_tn * c.gw_tm : 0;
+  if (b < ngw) {                                       // dW += dlogits^T . bnf
+    gemm_f32_body(c.w.dlogits, 1, C, c.w.bnf, D, 1, a.d_fc_weight, D, C, D, B, 1.f, 1.f, 1, b % c.gw_tn, b / c.gw_tn, 0);
+    return;
+  }
+  b -= ngw;
+  if (b < B) {
+    center_bwd_body(a.feat, a.labels, a.centers, c.w.row_c, B, D, nullptr, a.w_center, c.w.dfeat, a.d_centers, c.mask, b, 0);
+    return;
+  }
+  b -= B;
+  if (b == 0) {
+    mean_rows_body(c.w.row_x, B, a.masked ? 0.f : 1.0f / (float)B, c.w.scal + 4 * (K + 1) + 1, c.mask, 0, 0);
+    return;
+  }
+  b -= 1;
+  if (a.masked) { if (threadIdx.x == 0) ctl_round_scale_body(c.w.scal + 4, K, c.w.inv_rounds, 0, 0); return; }
+  const int R = 2 * P;
+  triplet_bwd_body<0>(c.w.emb, R, D, c.w.dap_r, c.w.dan_r, c.w.pi_r, c.w.ni_r, c.w.coef_r, nullptr, a.w_centroid / (float)K,
+                      c.w.demb, b % R, b / R);
+}
+
+__global__ __launch_bounds__(256) void heads_stage5_kernel(HeadsCtx c) {
+  const creid_ctl_heads& a = c.a;
+  const int B = (int)a.B, P = (int)a.P, K = (int)a.K, D = (int)a.D;
+  int b = (int)blockIdx.x;
+  const int nbn = (D + 31) / 32;
+  if (b < nbn) {
+    bn1d_bwd_body(a.feat, c.w.dbnf, B, D, a.bn_weight, c.w.save_mean, c.w.save_invstd, c.w.dfeat, a.d_bn_weight, a.d_bn_bias,
+                  c.mask, b, 0);
+    return;
+  }
+  b -= nbn;
+  const int n = 4 * (K + 1) + 2;
+  if (b == 0) {
+    if (threadIdx.x >= 64) return;
+    if (a.masked) ctl_step_stats_rows_body(c.w.scal, a.loss_weights, n, K, P, c.w.cnorm, c.w.rows, a.stats, 0, 0);
+    else ctl_step_stats_body(c.w.scal, a.loss_weights, n, K, c.w.cnorm, K * P, a.stats, 0, 0);
+    return;
+  }
+  b -= 1;                                              // (masked schedule only: the grid has no such blocks otherwise)
+  const int R = 2 * P;
+  triplet_bwd_body<0>(c.w.emb, R, D, c.w.dap_r, c.w.dan_r, c.w.pi_r, c.w.ni_r, c.w.coef_r, c.w.inv_rounds, a.w_centroid, c.w.demb,
+                      b % R, b / R);
+}
+
+// S6: grid (B, hw_parts).  Every workgroup of image b re-derives the finished dfeat row (three reads per channel from L2) and
+// writes its share of the HW copies of it / HW: creid_loo_emb_bwd + (creid_amp_scale) + creid_gap_bwd of the sequential schedule,
+// same expressions in the same order.
+template <int DT>
+__global__ __launch_bounds__(256) void heads_stage6_kernel(HeadsCtx c, int hw_parts) {
+  const creid_ctl_heads& a = c.a;
+  const int P = (int)a.P, K = (int)a.K, D = (int)a.D, HW = (int)a.HW;
+  const int b = (int)blockIdx.x / hw_parts, part = (int)blockIdx.x % hw_parts;
+  const int p = b / K, s = b % K;
+  const float* demb = c.w.demb;
+  const float* dq = demb + ((int64_t)s * 2 * P + p) * D;
+  const float* acc_in = c.w.dfeat + (int64_t)b * D;
+  const bool sreal = a.is_real[p * K + s] != 0;
+  constexpr int KMAX = 16;
+  float den[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) {
+    den[i] = 0.f;
+    if (i < K && i != s && sreal && a.is_real[p * K + i]) {
+      int cnt = 0;
+      for (int t = 0; t < K; ++t) cnt += (t != i && a.is_real[p * K + t]) ? 1 : 0;
+      den[i] = (float)max(cnt, 1);
+    }
+  }
+  const float scale = a.amp_state ? a.amp_state[0] : 1.f;
+  const float inv = 1.0f / (float)HW;
+  const int hw0 = (int)((int64_t)HW * part / hw_parts), hw1 = (int)((int64_t)HW * (part + 1) / hw_parts);
+  for (int d0 = (int)threadIdx.x * 8; d0 < D; d0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int d = d0 + k;
+      float o = acc_in[d] + dq[d];
+      if (sreal) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+          if (den[i] != 0.f) acc += demb[((int64_t)i * 2 * P + P + p) * D + d] / den[i];
+        o += acc;
+      }
+      v[k] = o;
+    }
+    if (part == 0 && a.dfeat_out) {
+      float* o = a.dfeat_out + (int64_t)b * D + d0;
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (a.amp_state) v[k] = v[k] * scale; v[k] = v[k] * inv; }
+    for (int hw = hw0; hw < hw1; ++hw) {
+      const int64_t off = ((int64_t)b * HW + hw) * D + d0;
+      if (DT == CREID_F32) {
+        float* g = reinterpret_cast<float*>(a.g) + off;
+        *reinterpret_cast<float4*>(g) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(g + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else if (DT == CREID_BF16) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.g) + off) =
+            make_uint4(Bf16T::pack2(v[0], v[1]), Bf16T::pack2(v[2], v[3]), Bf16T::pack2(v[4], v[5]), Bf16T::pack2(v[6], v[7]));
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.g) + off) =
+            make_uint4(F16T::pack2(v[0], v[1]), F16T::pack2(v[2], v[3]), F16T::pack2(v[4], v[5]), F16T::pack2(v[6], v[7]));
+      }
+    }
+  }
 }
 
 // ======================================================================================
@@ -1311,6 +1664,47 @@ int creid_sgd_scaled_step(float* p, float* g, int64_t n, float lr, float grad_mu
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(sgd_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, n, lr,
                      grad_mul);
+  CREID_LAUNCH_RET();
+}
+
+size_t creid_ctl_heads_workspace_bytes(int64_t B, int64_t P, int64_t K, int64_t D, int64_t num_classes) {
+  if (B <= 0 || P <= 0 || K <= 0 || D <= 0 || num_classes <= 0) return 0;
+  return heads_carve(B, P, K, D, num_classes, nullptr, nullptr);
+}
+
+int creid_ctl_heads_fused(const creid_ctl_heads* a, void* stream) {
+  CREID_CHECK_ARG(a && a->feat && a->labels && a->is_real && a->centers && a->bn_weight && a->bn_running_mean && a->bn_running_var &&
+                  a->fc_weight && a->loss_weights && a->stats && a->g && a->workspace);
+  CREID_CHECK_ARG(a->B > 0 && a->P >= 2 && a->K >= 2 && a->B == a->P * a->K && a->D > 0 && a->num_classes > 0 && a->num_centers > 0 &&
+                  a->HW > 0 && a->split_logits >= 1 && a->split_dbnf >= 1 && a->margin >= 0.f);
+  CREID_CHECK_ARG(!a->masked || a->lonely);
+  if (a->K > 16 || a->D % 8 != 0 || a->B > 256 || 2 * a->P > 256) return CREID_E_SHAPE;   // (loo backward slots; triplet backward: one trip)
+  if (a->g_dtype != CREID_F32 && a->g_dtype != CREID_BF16 && a->g_dtype != CREID_F16) return CREID_E_DTYPE;
+  HeadsCtx c;
+  c.a = *a;
+  if (heads_carve(a->B, a->P, a->K, a->D, a->num_classes, (char*)a->workspace, &c.w) > a->workspace_bytes) return CREID_E_WS;
+  if (((uintptr_t)a->workspace & 255) != 0) return CREID_E_ARG;
+  c.mask = a->masked ? a->is_real : nullptr;
+  const int B = (int)a->B, P = (int)a->P, K = (int)a->K, D = (int)a->D, C = (int)a->num_classes, R = 2 * P;
+  c.gl_tn = (C + 63) / 64; c.gl_tm = (B + 63) / 64;
+  c.gd_tn = (D + 63) / 64; c.gd_tm = (B + 63) / 64;
+  c.gw_tn = (D + 63) / 64; c.gw_tm = (C + 63) / 64;
+  const size_t smem_mine = (size_t)(D + (B > R ? B : R)) * sizeof(float);
+  if (smem_mine > 64 * 1024) return CREID_E_SHAPE;
+  const size_t smem_bwd = (size_t)(B > R ? B : R) * 8 * sizeof(float);
+  hipStream_t s = as_stream(stream);
+  const int nbn = (D + 31) / 32;
+  hipLaunchKernelGGL(heads_stage1_kernel, dim3((unsigned)(HEADS_ZERO_WGS + 2 * B + nbn + P * K)), dim3(1024), smem_mine, s, c);
+  hipLaunchKernelGGL(heads_stage2_kernel, dim3((unsigned)(K * R + c.gl_tn * c.gl_tm * a->split_logits + 2)), dim3(1024), smem_mine, s, c);
+  hipLaunchKernelGGL(heads_stage3_kernel, dim3((unsigned)(2 * B + K)), dim3(256), smem_bwd, s, c);
+  const int n4 = c.gd_tn * c.gd_tm * a->split_dbnf + (a->d_fc_weight ? c.gw_tn * c.gw_tm : 0) + B + 1 + (a->masked ? 1 : K * R);
+  hipLaunchKernelGGL(heads_stage4_kernel, dim3((unsigned)n4), dim3(256), smem_bwd, s, c);
+  hipLaunchKernelGGL(heads_stage5_kernel, dim3((unsigned)(nbn + 1 + (a->masked ? K * R : 0))), dim3(256), smem_bwd, s, c);
+  int hw_parts = (int)a->HW < 8 ? (int)a->HW : 8;         // 512 workgroups at B = 64: each re-derives its dfeat row once per 16 copies
+  const dim3 g6((unsigned)(B * hw_parts));
+  if (a->g_dtype == CREID_F32) hipLaunchKernelGGL(heads_stage6_kernel<CREID_F32>, g6, dim3(256), 0, s, c, hw_parts);
+  else if (a->g_dtype == CREID_BF16) hipLaunchKernelGGL(heads_stage6_kernel<CREID_BF16>, g6, dim3(256), 0, s, c, hw_parts);
+  else hipLaunchKernelGGL(heads_stage6_kernel<CREID_F16>, g6, dim3(256), 0, s, c, hw_parts);
   CREID_LAUNCH_RET();
 }
 

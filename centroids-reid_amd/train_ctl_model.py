@@ -31,6 +31,9 @@ class CTLModel(ModelBase):
         # all-real batches on the HIP backbone take a hand-scheduled head pass (same kernels, no autograd tape:
         # ~45 launches instead of ~130); CREID_FUSED_HEADS=0 keeps everything on the autograd path
         self.fused_heads = os.environ.get("CREID_FUSED_HEADS", "1") == "1"
+        # ... and that head pass as SIX multi-role launches (creid_ctl_heads_fused: the four independent chains of the heads side
+        # by side, the last launch also doing the global-average-pool backward); CREID_HEADS_ONE_CALL=0: the ~23 separate launches
+        self.heads_one_call = os.environ.get("CREID_HEADS_ONE_CALL", "1") == "1"
 
     def training_step(self, batch, batch_idx, optimizer_idx=None):
         """train_ctl_model.py:38-179 = forward_backward (everything up to manual_backward) -> optional
@@ -49,7 +52,15 @@ class CTLModel(ModelBase):
         lonely = getattr(self, "_lonely_dev", None)
         if lonely is None:
             return
-        n = int(lonely.item())
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # every rank must take the same decision: a rank that raised alone would leave the others hanging in their next
+            # collective (each rank sees only its own batches)
+            tot = lonely.clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            n = int(tot.item())
+        else:
+            n = int(lonely.item())
         if n:
             lonely.zero_()
             raise RuntimeError(f"query/centroid count mismatch in a centroid round: {n} real instance(s) without a real partner "
@@ -215,6 +226,8 @@ class CTLModel(ModelBase):
         dev = feat.device
         labels = class_labels.to(torch.int64).contiguous()
         margin = float(self.contrastive_loss.margin)
+        if self.heads_one_call and B <= 256 and D % 8 == 0 and getattr(eng, "saved", None) is not None:
+            return self._heads_one_call(eng, feat, labels, P, K, real)
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         zbuf = torch.zeros(B * D + K * 2 * P * D, **f32)                       # ONE fill for both accumulation buffers
@@ -314,9 +327,7 @@ class CTLModel(ModelBase):
             inv_rounds = torch.empty(1, **f32)
             # (the kernel also counts real instances without a real partner into a persistent device counter: the reference
             # raises on such a batch, this sync-free step cannot -- training_epoch_end / check_lonely_identities() does)
-            lonely = getattr(self, "_lonely_dev", None)
-            if lonely is None or lonely.device != dev:
-                lonely = self._lonely_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            lonely = self._lonely_counter(dev)
             L.check(lib.creid_loo_emb_fwd_rows_lonely(L.ptr(feat), L.ptr(real), L.ptr(labels), P, K, D, L.ptr(cent), L.ptr(valid),
                                                       L.ptr(emb), L.ptr(lab), L.ptr(cnorm), L.ptr(rows), L.ptr(lonely), st),
                     "creid_loo_emb_fwd_rows_lonely")
@@ -354,6 +365,79 @@ class CTLModel(ModelBase):
             self.losses_dict[name].append(val)
         log_data = {"step_dist_ap": rounds[1], "step_dist_an": rounds[2], "l2_mean_centroid": l2_mean}
         return {"loss": total_loss, "other": log_data}
+
+    def _heads_one_call(self, eng, feat, labels, P, K, real):
+        """train_ctl_model.py:59-152 after the backbone forward, through creid_ctl_heads_fused (six launches; the arithmetic and
+        the accumulation order are those of the separate calls in _forward_backward_fused: bit-identical results)."""
+        import ctypes as C
+        hp = self.hparams
+        lib = L.lib()
+        B, D = feat.shape
+        dev = feat.device
+        masked = real is not None
+        bn, W, centers = self.bn, self.fc_query.weight, self.center_loss.centers
+        C_cls = W.shape[0]
+        h, w = eng.saved["final"]
+
+        def grad_of(p):
+            if not p.requires_grad:
+                return None
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            return p.grad
+
+        n = 4 * (K + 1) + 2
+        nbytes = lib.creid_ctl_heads_workspace_bytes(B, P, K, D, C_cls)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        stats = torch.empty(n + 7, dtype=torch.float32, device=dev)
+        g = torch.empty((B * h * w, D), dtype=eng.dtype, device=dev)
+        lonely = None
+        if masked:
+            lonely = self._lonely_counter(dev)
+        a = L.CtlHeads()
+        a.B, a.P, a.K, a.D, a.num_classes, a.num_centers, a.HW = B, P, K, D, C_cls, centers.shape[0], h * w
+        a.g_dtype, a.masked = eng.dt, 1 if masked else 0
+        det = ops._DETERMINISTIC
+        a.split_logits, a.split_dbnf = (1, 1) if det else (32, 12)
+        a.margin, a.xent_eps = float(self.contrastive_loss.margin), float(self.xent.epsilon)
+        a.w_query, a.w_center = float(hp.SOLVER.QUERY_CONTRASTIVE_WEIGHT), float(hp.SOLVER.CENTER_LOSS_WEIGHT)
+        a.w_xent, a.w_centroid = float(hp.SOLVER.QUERY_XENT_WEIGHT), float(hp.SOLVER.CENTROID_CONTRASTIVE_WEIGHT)
+        a.bn_momentum, a.bn_eps = float(bn.momentum), float(bn.eps)
+        wv = self._loss_weight_vector(K, dev, full_round_weight=masked)
+        scaler = eng.loss_scaler if eng.dtype == torch.float16 else None
+        keep = (real if masked else self._all_real_u8(B, dev), grad_of(centers), grad_of(bn.weight), grad_of(bn.bias), grad_of(W))
+        for name, t in (("feat", feat), ("labels", labels), ("is_real", keep[0]), ("centers", centers), ("bn_weight", bn.weight),
+                        ("bn_bias", bn.bias), ("bn_running_mean", bn.running_mean), ("bn_running_var", bn.running_var),
+                        ("fc_weight", W), ("loss_weights", wv), ("amp_state", scaler.state if scaler is not None else None),
+                        ("d_centers", keep[1]), ("d_bn_weight", keep[2]), ("d_bn_bias", keep[3]), ("d_fc_weight", keep[4]),
+                        ("bn_batches_tracked", bn.num_batches_tracked if bn.num_batches_tracked.is_cuda else None),
+                        ("lonely", lonely), ("stats", stats), ("g", g), ("dfeat_out", None), ("workspace", ws)):
+            setattr(a, name, None if t is None else t.data_ptr())
+        a.workspace_bytes = nbytes
+        if not bn.num_batches_tracked.is_cuda:
+            bn.num_batches_tracked += 1
+        L.check(lib.creid_ctl_heads_fused(C.byref(a), L.stream()), "creid_ctl_heads_fused")
+        eng.backward(None, g=g)                                               # manual_backward (:152)
+        terms = stats[:n]
+        contrastive_loss_query = terms[0]
+        center_loss, xent_query = terms[4 * (K + 1)], terms[4 * (K + 1) + 1]
+        total_loss, contrastive_loss_step = stats[n], stats[n + 1]
+        rounds = stats[n + 2:n + 6]
+        for name, val in zip(self.losses_names, (xent_query, contrastive_loss_query, center_loss, contrastive_loss_step)):
+            self.losses_dict[name].append(val)
+        log_data = {"step_dist_ap": rounds[1], "step_dist_an": rounds[2], "l2_mean_centroid": stats[n + 6]}
+        return {"loss": total_loss, "other": log_data}
+
+    def _lonely_counter(self, dev):
+        """Persistent device counter of real instances without a real partner (see check_lonely_identities).  Created OUTSIDE
+        any hipGraph capture: a zero-fill captured with the first masked step would reset the counter on every replay."""
+        lonely = getattr(self, "_lonely_dev", None)
+        if lonely is None or lonely.device != dev:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the first masked training step must run eagerly (or call model._lonely_counter(device) before "
+                                   "capturing): the lonely-identity counter cannot be created inside a hipGraph capture")
+            lonely = self._lonely_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        return lonely
 
     def _loss_weight_vector(self, K, dev, full_round_weight=False):
         """full_round_weight: the round slots carry the whole centroid weight (the masked schedule divides by the number of

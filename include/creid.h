@@ -176,6 +176,52 @@ int creid_loo_emb_bwd(const float* demb, const uint8_t* is_real, int64_t P, int6
 int creid_ctl_step_stats(const float* scal, const float* weights, int64_t n, int64_t K, const float* cnorm,
                          int64_t rows, float* out, void* stream);
 
+/* ---- the whole head section of a training step in SIX launches (train_ctl_model.py:59-152: everything between the backbone
+ * forward and its backward).  The kernels above are latency-bound on a 64 x 2048 feature matrix and four of their chains are
+ * independent (query triplet / center loss / BNNeck -> classifier -> cross entropy / centroid rounds): each launch here runs one
+ * step of every chain side by side (workgroup roles), in the accumulation order of the sequential calls -- results are
+ * bit-identical to them (tests/test_heads_fused_gpu.py).  The last launch also performs creid_gap_bwd of the finished feature
+ * gradient, i.e. it hands the backbone its incoming gradient directly.
+ *   masked = 0: every row is real (is_real must still be given: all ones); masked = 1: the device-mask schedule below
+ *   (creid_*_masked / *_rows semantics, `lonely` required).
+ *   loss_weights [4(K+1)+2] / stats [4(K+1)+2+7]: as creid_ctl_step_stats(_rows).  w_centroid: the centroid-triplet weight
+ *   (divided by K inside for masked = 0, by the number of valid rounds on the device for masked = 1).
+ *   split_logits / split_dbnf: K-splits of the classifier forward / data-gradient GEMMs (1 = single pass, run-to-run identical;
+ *   > 1: partial products combined by fp32 atomics like creid_gemm_f32).
+ *   d_* are ACCUMULATED into (NULL = not wanted, except d_bn_weight); bn_batches_tracked (nullable) is incremented by one;
+ *   amp_state (nullable): f16 loss scale {scale, 1/scale} -- g is multiplied by scale; dfeat_out (nullable, fp32 [B, D]) receives
+ *   the unscaled feature gradient; g: [B * HW, D] in g_dtype.  workspace: creid_ctl_heads_workspace_bytes(), 256-byte aligned.
+ *   Limits: K <= 16, B <= 256, D % 8 == 0 (else CREID_E_SHAPE: use the separate calls). */
+typedef struct creid_ctl_heads {
+  int64_t B, P, K, D, num_classes, num_centers, HW;
+  int32_t g_dtype, masked, split_logits, split_dbnf;
+  float margin, xent_eps, w_query, w_center, w_xent, w_centroid, bn_momentum, bn_eps;
+  const float* feat;
+  const int64_t* labels;
+  const uint8_t* is_real;
+  const float* centers;
+  const float* bn_weight;
+  const float* bn_bias;
+  float* bn_running_mean;
+  float* bn_running_var;
+  const float* fc_weight;
+  const float* loss_weights;
+  const float* amp_state;
+  float* d_centers;
+  float* d_bn_weight;
+  float* d_bn_bias;
+  float* d_fc_weight;
+  int64_t* bn_batches_tracked;
+  int32_t* lonely;
+  float* stats;
+  void* g;
+  float* dfeat_out;
+  void* workspace;
+  size_t workspace_bytes;
+} creid_ctl_heads;
+size_t creid_ctl_heads_workspace_bytes(int64_t B, int64_t P, int64_t K, int64_t D, int64_t num_classes);
+int creid_ctl_heads_fused(const creid_ctl_heads* a, void* stream);
+
 /* ---- the same training step for batches with padded samples (isReal = False, datasets/bases.py:346-406), driven by a DEVICE
  * mask so that the step stays free of host synchronisation (hipGraph-capturable for any pattern of fakes):
  *  creid_loo_emb_fwd_rows    = creid_loo_emb_fwd + row_exists uint8 [K][2P]: identity p takes part in round i iff its i-th

@@ -60,6 +60,34 @@ def test_binding_arity_and_pointer_slots_match_header(built_lib):
                 assert a is C.c_float, (name, q, a)
 
 
+def test_ctl_heads_struct_matches_header(built_lib):
+    """creid_ctl_heads is passed by pointer: the ctypes Structure must list the header's fields in the header's order with the
+    header's widths (a stale copy would shift every pointer behind the first difference)."""
+    import ctypes as C
+    txt = open(os.path.join(ROOT, "include", "creid.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    body = re.search(r"typedef struct creid_ctl_heads \{(.*?)\} creid_ctl_heads;", txt, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ptr = "*" in decl
+        base = re.match(r"(?:const\s+)?(\w+)", decl).group(1)
+        names = [re.sub(r"[\s*]", "", q) for q in decl[decl.index(base) + len(base):].split(",")]
+        for nme in names:
+            fields.append((nme, ptr, base))
+    got = built_lib.CtlHeads._fields_
+    assert [f[0] for f in got] == [f[0] for f in fields]
+    width = {"int64_t": 8, "int32_t": 4, "float": 4, "size_t": C.sizeof(C.c_size_t)}
+    for (name, ctype), (_, ptr, base) in zip(got, fields):
+        if ptr:
+            assert ctype is C.c_void_p, name
+        else:
+            assert C.sizeof(ctype) == width[base], name
+            assert (ctype is C.c_float) == (base == "float"), name
+
+
 def test_header_is_plain_c():
     """include/creid.h is the FFI boundary: it must compile as C99 on its own (no torch / HIP / C++ types)."""
     import shutil

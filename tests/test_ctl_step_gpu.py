@@ -23,12 +23,16 @@ class EngineStub:
     def __init__(self, owner):
         self.owner = owner
         self.weights_dirty = False
+        # what creid_ctl_heads_fused needs to know about the backbone: a 1 x 1 final map (the pooled-back gradient IS the feature
+        # gradient), fp32, no loss scale
+        self.saved = {"final": (1, 1)}
+        self.dtype, self.dt, self.loss_scaler = torch.float32, 0, None
 
     def forward(self, x, training, want_base_out=False):
         return None, self.owner.feats.detach() * 1.0
 
-    def backward(self, dfeat):
-        self.owner.feats.grad.add_(dfeat)
+    def backward(self, dfeat, g=None):
+        self.owner.feats.grad.add_(dfeat if g is None else g)
 
 
 class FeatStubEngine(torch.nn.Module):
@@ -52,12 +56,13 @@ def _cfg(D, K, margin):
     return cfg
 
 
-@pytest.mark.parametrize("path", ["autograd", "fused_host_mask", "fused_device_mask"])
+@pytest.mark.parametrize("path", ["autograd", "fused_host_mask", "fused_device_mask", "one_call_host_mask", "one_call_device_mask"])
 @pytest.mark.parametrize("name", ["heads_p16k4_d128", "heads_p16k4_d128_fake1", "heads_p16k4_d128_fake2", "heads_p8k4_d2048"])
 def test_training_step_heads_golden(golden, name, path):
     """The reference's own training_step recordings (incl. batches with isReal = False samples) through the autograd path,
     the hand-scheduled step with the mask known on the host, and the same step driven by a DEVICE mask (no host
-    synchronisation: what a captured hipGraph replays for any pattern of fakes)."""
+    synchronisation: what a captured hipGraph replays for any pattern of fakes) -- the last two as separate head launches
+    (fused_*) and as the six multi-role launches of creid_ctl_heads_fused (one_call_*, the default)."""
     from centroids_reid_amd.train_ctl_model import CTLModel
     g = golden(name)
     P, K, C = int(g["P"]), int(g["K"]), int(g["C"])
@@ -71,7 +76,9 @@ def test_training_step_heads_golden(golden, name, path):
     model = model.cuda().train()
     model.configure_optimizers()
     is_real = torch.from_numpy(g["is_real"])
-    if path == "fused_device_mask":
+    model.heads_one_call = path.startswith("one_call")
+    device_mask = path.endswith("device_mask")
+    if device_mask:
         is_real = is_real.cuda()
     batch = (torch.zeros(P * K, 3, 8, 4, device="cuda"), torch.from_numpy(g["labels"]).cuda(),
              torch.zeros(P * K, dtype=torch.int64), is_real)
@@ -84,7 +91,7 @@ def test_training_step_heads_golden(golden, name, path):
         out = model.training_step(batch, s)
         if path != "autograd":            # the hand-scheduled step ran, masked iff the mask is on the device or has fakes
             assert len(calls) == s + 1
-            assert calls[-1] == (path == "fused_device_mask" or not bool(g["is_real"].all()))
+            assert calls[-1] == (device_mask or not bool(g["is_real"].all()))
         assert abs(float(out["loss"]) - float(g[f"s{s}_loss_total"])) < 3e-5
         for n in model.losses_names:
             assert abs(float(model.losses_dict[n][-1]) - float(g[f"s{s}_{n}"])) < 3e-5, n
