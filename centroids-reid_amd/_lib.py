@@ -131,6 +131,7 @@ SIGNATURES = {
     "creid_maxpool3x3s2_fwd": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_int, _p, _p, _p]),
     "creid_maxpool3x3s2_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, C.c_int, _p, _p]),
     "creid_gap_fwd": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
+    "creid_gap_fwd_count": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p, _p]),
     "creid_gap_bwd": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
     "creid_nhwc_to_nchw_f32": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p]),
     "creid_gemm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _f32, _f32, _i32, _p]),

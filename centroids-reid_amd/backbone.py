@@ -244,6 +244,8 @@ class BackboneEngine:
                 self.blocks.append(u)
         self.weights_dirty = True      # set by writers torch cannot see (our ctypes optimiser kernels)
         self._wsig = None              # (data_ptr, _version) of every conv weight at the last prep_weights()
+        self._wprep_key = None
+        self.wprep_side = os.environ.get("CREID_WPREP_SIDE", "0") == "1"   # measured r06: +0.17 ms (both branches are HBM-bound; profiles/r06_graph_branches.md)
         # nn.Module.load_state_dict copies through `param.copy_` under no_grad (bumps _version), but a post-hook makes
         # the refresh independent of how a loader writes
         net.register_load_state_dict_post_hook(lambda *_a: setattr(self, "weights_dirty", True))
@@ -357,9 +359,10 @@ class BackboneEngine:
                 if b[k] is not None:
                     yield b[k]
 
-    def prep_weights(self):
+    def prep_weights(self, side=False):
         """fp32 OIHW master weights -> compute-dtype [O][r][s][I] and [I][r][s][O] copies (ONE launch for all
-        52 non-stem convolutions through a device descriptor table, rebuilt only if a pointer moved)."""
+        52 non-stem convolutions through a device descriptor table, rebuilt only if a pointer moved).  side=True: that launch
+        goes to the side stream (the caller joins it before the first non-stem convolution); returns whether it did."""
         import numpy as np
         lib, st = L.lib(), L.stream()
         units = [u for u in self.all_units() if u is not self.stem]
@@ -370,7 +373,7 @@ class BackboneEngine:
         if self.stem.w_krsc is None:
             self.stem.w_krsc = self._empty(64, 8, 32)
         key = tuple(u.conv.weight.data_ptr() for u in units)
-        if getattr(self, "_wprep_key", None) != key:
+        if self._wprep_key != key:
             rec = np.zeros(len(units), dtype=np.dtype([("w", "<u8"), ("krsc", "<u8"), ("crsk", "<u8"), ("O", "<i4"),
                                                         ("I", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("start", "<i8")]))
             assert lib.creid_weight_prep_entry_bytes() == rec.dtype.itemsize == 48
@@ -384,12 +387,22 @@ class BackboneEngine:
             self._wprep_tiles = torch.from_numpy(tstart).to(self.device)
             self._wprep_total = tiles
             self._wprep_key = key
-        L.check(lib.creid_weight_prep_multi(L.ptr(self._wprep_tab), L.ptr(self._wprep_tiles), len(units), self._wprep_total,
-                                            self.dt, st), "weight_prep_multi")
         L.check(lib.creid_stem_weight_prep(L.ptr(self.stem.conv.weight), self.dt, L.ptr(self.stem.w_krsc), st),
                 "stem_weight_prep")
+        if side:
+            # the 52 non-stem copies (~50 us at ResNet50 size) are needed by layer1 only: inside a captured graph they run as a
+            # parallel branch beside the stem (image layout pass, 7 x 7 convolution, BatchNorm, max-pool: ~95 us that depend on the
+            # stem copy alone); forward() joins the branch in front of the first bottleneck.  One fork / join costs ~6 us of graph
+            # signalling (tools/probes/anyorder_probe.hip) against ~45 us hidden.
+            with self._fork_side():
+                L.check(lib.creid_weight_prep_multi(L.ptr(self._wprep_tab), L.ptr(self._wprep_tiles), len(units), self._wprep_total,
+                                                    self.dt, L.stream()), "weight_prep_multi")
+        else:
+            L.check(lib.creid_weight_prep_multi(L.ptr(self._wprep_tab), L.ptr(self._wprep_tiles), len(units), self._wprep_total,
+                                                self.dt, st), "weight_prep_multi")
         self.weights_dirty = False
         self._wsig = self._weight_signature()
+        return side
 
     def _weight_signature(self):
         """Changes whenever torch-visible code rewrites or re-homes a convolution weight after the compute-dtype
@@ -643,8 +656,13 @@ class BackboneEngine:
             assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3
         else:
             L.require_gpu(x_nchw.xpad)
+        wprep_pending = False
         if self.weights_dirty or self._wsig != self._weight_signature():
-            self.prep_weights()
+            # training steps replayed from a hipGraph re-derive the 16-bit weight copies every step (the optimiser has just rewritten
+            # the masters): as a graph branch beside the stem when capturing (CREID_WPREP_SIDE=0: in line)
+            side = (training and self.wprep_side and self._wprep_key is not None and torch.cuda.is_current_stream_capturing()
+                    and not (self.wgrad_stream or self.reduce_stream or self.eval_ds_side))
+            wprep_pending = self.prep_weights(side=side)
         lib, st = L.lib(), L.stream()
         B, _, H, W = x_nchw.shape
         if not training and self.eval_fold:
@@ -652,10 +670,11 @@ class BackboneEngine:
         # (f16 -- the reference's precision=16, utils/misc.py:111 -- trains like bf16; its gradients need the dynamic loss scale
         # that ModelBase.configure_optimizers attaches as `loss_scaler`: solver.LossScaler)
         sv = {"B": B, "H": H, "W": W, "training": training}
-        if training:      # one counter kernel per step instead of 53 per-layer `num_batches_tracked += 1`
-            if self._pending_steps is None:
+        if training:      # ONE device counter per step instead of 53 per-layer `num_batches_tracked += 1`; the increment itself
+            if self._pending_steps is None:          # rides in the forward's last launch (creid_gap_fwd_count)
                 self._pending_steps = torch.zeros((), dtype=torch.long, device=self.device)
-            self._pending_steps += 1
+            if self._side is None and not torch.cuda.is_current_stream_capturing():
+                self._side = torch.cuda.Stream(device=self.device)     # (the weight-copy branch of captured steps forks onto it)
         # stem
         xpad = self._stem_operand(x_nchw, B, H, W)
         H1, W1 = H // 2, W // 2
@@ -686,6 +705,8 @@ class BackboneEngine:
         sv["stem"] = (xpad, x0, y0, mean0, invstd0, idx0)
         a, h, w = p0, H2, W2
         sv["blocks"] = []
+        if wprep_pending:
+            self._join_side()                                  # the non-stem weight copies (a graph branch beside the stem)
         for b in self.blocks:
             a_in, hin, win = a, h, w
             x1, a1, m1, i1, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, training, True)
@@ -707,7 +728,10 @@ class BackboneEngine:
                                          x3=x3, a3=a3, m3=m3, i3=i3))
             a, h, w = a3, h3, w3
         feat = self._empty(B, 2048, dtype=torch.float32)
-        L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), st), "gap_fwd")
+        if training:
+            L.check(lib.creid_gap_fwd_count(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), L.ptr(self._pending_steps), st), "gap_fwd")
+        else:
+            L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), st), "gap_fwd")
         sv["final"] = (h, w)
         self.saved = sv if training else None
         base_out = None

@@ -191,6 +191,25 @@ class ModelBase(_Base):
     def save_checkpoint(self, path, epoch=0, global_step=0):
         torch.save(self.checkpoint_dict(epoch, global_step), path)
 
+    def load_training_state(self, ckpt):
+        """Resume: what pytorch-lightning 1.1.4 restores next to the weights (checkpoint_connector.restore_training_state) --
+        `optimizer_states` (Adam moments + step count into the flat buffers, FusedAdam.load_state_dict), `lr_schedulers`, and for
+        precision=16 runs `native_amp_scaling_state` (GradScaler scale + growth tracker -> the device-resident LossScaler).
+        Call after configure_optimizers(); `ckpt` is the dict load_checkpoint_file() returns (or a path)."""
+        if not isinstance(ckpt, dict):
+            ckpt = load_checkpoint_file(ckpt, "cpu")
+        opts = getattr(self, "_optimizers", None)
+        if opts is None:
+            raise RuntimeError("load_training_state() needs configure_optimizers() first")
+        for o, st in zip(opts, ckpt.get("optimizer_states", [])):
+            o.load_state_dict(st)
+        for sched, st in zip([self.lr_scheduler] if hasattr(self, "lr_scheduler") else [], ckpt.get("lr_schedulers", [])):
+            sched.load_state_dict(st)
+        amp = ckpt.get("native_amp_scaling_state")
+        if amp is not None and getattr(self, "loss_scaler", None) is not None:
+            self.loss_scaler.load_state_dict(amp)
+        return ckpt.get("epoch", 0), ckpt.get("global_step", 0)
+
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location="cpu", strict=True, **overrides):
         """pl.LightningModule.load_from_checkpoint as the reference uses it (utils/misc.py:128-147,

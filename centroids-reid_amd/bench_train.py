@@ -292,7 +292,7 @@ def hbm_stage_rates(time_kernel, B, H, W):
     t_bwd = time_kernel(lambda: ly.bn2d_bwd(x, g, y, mean, invstd, gamma, want_gm=True), 20)
     n = 25_600_000
     p, gr, m1, v1 = (torch.zeros(n, device=dev) for _ in range(4))
-    hyper = torch.tensor([3.5e-4, 1.0, 0.1, 0.03], device=dev)
+    hyper = torch.tensor([3.5e-4, 1.0, 0.1, 0.03, 0.0, 0.0, 0.0, 0.0], device=dev)      # float[8]: {lr, step, bc1, bc2s, ticket, reserved}
     t_adam = time_kernel(lambda: L.check(lib.creid_adam_step_dev(L.ptr(p), L.ptr(gr), L.ptr(m1), L.ptr(v1), n, L.ptr(hyper),
                                                                     0.9, 0.999, 1e-8, 5e-4, 1.0, L.stream()), "adam"), 10)
     # input transforms (flip, pad-crop, ToTensor, Normalize, RandomErasing) of a uint8 batch, written straight into the stem's

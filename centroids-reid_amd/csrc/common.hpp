@@ -30,7 +30,11 @@ static inline bool creid_knobs_live() {
   static const bool v = [] { const char* e = getenv("CREID_DEBUG_KNOBS"); return e && atoi(e) != 0; }();
   return v;
 }
-#define CREID_KNOB_ENV(NAME) ([]() -> const char* { static const char* once_ = getenv(NAME); return creid_knobs_live() ? getenv(NAME) : once_; }())
+// (the once-read value is an OWNED copy: a later putenv() with a caller-owned buffer or another libc may free or rewrite the
+// string getenv() pointed into)
+#include <string.h>
+static inline const char* creid_env_copy(const char* name) { const char* e = getenv(name); return e ? strdup(e) : nullptr; }
+#define CREID_KNOB_ENV(NAME) ([]() -> const char* { static const char* once_ = creid_env_copy(NAME); return creid_knobs_live() ? getenv(NAME) : once_; }())
 
 typedef float  f32x4  __attribute__((ext_vector_type(4)));
 typedef float  f32x16 __attribute__((ext_vector_type(16)));

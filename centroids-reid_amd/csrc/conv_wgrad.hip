@@ -831,7 +831,10 @@ static int run_wgrad(const IGemmGeom& g, const void* dy, const void* x, int NCO,
   }
   const WgradPlan p = plan_wgrad(g.M, NCO, g.K, dtype, g.stride);
   if (dtype == CREID_F16 && (phases & 1)) {
-    const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0;
+    // (the same predicate launch_wgrad_t routes by, CREID_STEM_DMA included: with the stem's DMA path switched off an f16 stem has
+    // no kernel at all -- refuse it here instead of summing an unwritten workspace into dw)
+    static const int stem_dma = [] { const char* e = getenv("CREID_STEM_DMA"); return e ? atoi(e) : 1; }();
+    const bool stem_geom = g.log2span == 5 && !g.check_bounds && g.kw == 1 && g.stride == 2 && g.pad == 0 && stem_dma;
     if (!((1 << g.log2span) >= p.tn || stem_geom)) return CREID_E_SHAPE;
   }
   const size_t need = (size_t)p.splits * NCO * g.K * sizeof(float);

@@ -732,9 +732,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // 32 channel vectors x 8 row lanes per workgroup; grid (C/V/32, B): HW/8 dependent loads per thread and
 // B*C/(32V) workgroups instead of HW loads and B workgroups; lane partials meet in LDS in a fixed order.
 template <typename T>
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ out,
+                                                      int64_t* __restrict__ counter) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[8][32][V + 1];
+  if (counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *counter += 1;   // creid_gap_fwd_count
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int b = blockIdx.y, cc = blockIdx.x * 32 + cl;
   const bool live = cc * V < C;
@@ -1249,17 +1251,27 @@ int creid_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, int64_t B, int64_
   CREID_LAUNCH_RET();
 }
 
-int creid_gap_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* feat, void* stream) {
+static int gap_fwd_impl(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* feat, int64_t* counter, void* stream) {
   CREID_CHECK_ARG(x && feat && B > 0 && HW > 0 && C % 8 == 0);
   hipStream_t s = as_stream(stream);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((unsigned)((C / 4 + 31) / 32), (unsigned)B), dim3(256), 0, s,
-                                (const float*)x, (int)HW, (int)C, feat),
+                                (const float*)x, (int)HW, (int)C, feat, counter),
              hipLaunchKernelGGL(gap_fwd_kernel<unsigned short>, dim3((unsigned)((C / 8 + 31) / 32), (unsigned)B),
-                                dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, feat),
+                                dim3(256), 0, s, (const unsigned short*)x, (int)HW, (int)C, feat, counter),
              hipLaunchKernelGGL(gap_fwd_kernel<_Float16>, dim3((unsigned)((C / 8 + 31) / 32), (unsigned)B),
-                                dim3(256), 0, s, (const _Float16*)x, (int)HW, (int)C, feat));
+                                dim3(256), 0, s, (const _Float16*)x, (int)HW, (int)C, feat, counter));
   CREID_LAUNCH_RET();
+}
+
+int creid_gap_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* feat, void* stream) {
+  return gap_fwd_impl(x, B, HW, C, dtype, feat, nullptr, stream);
+}
+
+int creid_gap_fwd_count(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* feat, int64_t* forward_counter,
+                        void* stream) {
+  CREID_CHECK_ARG(forward_counter);
+  return gap_fwd_impl(x, B, HW, C, dtype, feat, forward_counter, stream);
 }
 
 int creid_gap_bwd(const float* dfeat, int64_t B, int64_t HW, int64_t C, int dtype, void* dx, void* stream) {

@@ -677,12 +677,18 @@ __global__ void adam_advance_kernel(float* __restrict__ hyper, float b1, float b
   hyper[3] = sqrtf(1.0f - powf(b2, step));
 }
 
+// The kernel ADVANCES the device-resident step itself: every workgroup derives step = hyper[1] + 1 and the bias corrections
+// from the not-yet-advanced counter, and the LAST workgroup to finish (a ticket in hyper[4]: by then every other one has read
+// hyper[1]) writes {step, bc1, bc2s} back and clears the ticket -- the separate one-thread launch in front of every Adam step
+// (adam_advance_kernel, ~5 us of dependent launch) is gone.  A skipped (overflow) step returns before the ticket: the counter
+// does not advance (GradScaler.step skips optimizer.step).
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                       const float* __restrict__ hyper, float b1, float b2, float eps,
+                                                       float* __restrict__ hyper, float b1, float b2, float eps,
                                                        float wd, float gscale, const int32_t* __restrict__ skip = nullptr) {
   if (skip && skip[0]) return;                                // f16 training: a non-finite gradient skips the whole step
-  const float lr = hyper[0], bc1 = hyper[2], bc2s = hyper[3];
+  const float step = hyper[1] + 1.0f;
+  const float lr = hyper[0], bc1 = 1.0f - powf(b1, step), bc2s = sqrtf(1.0f - powf(b2, step));
   const float step_size = lr / bc1;
   const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   const int64_t stride = (int64_t)gridDim.x * 1024;
@@ -699,6 +705,14 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
     }
     *reinterpret_cast<float4*>(p + i) = pv; *reinterpret_cast<float4*>(m + i) = mv;
     *reinterpret_cast<float4*>(v + i) = vv;
+  }
+  __syncthreads();                                            // every thread of this workgroup has read hyper[1]
+  if (threadIdx.x == 0) {
+    int* ticket = reinterpret_cast<int*>(hyper + 4);
+    if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+      hyper[1] = step; hyper[2] = bc1; hyper[3] = bc2s;
+      *ticket = 0;
+    }
   }
 }
 
@@ -718,7 +732,7 @@ __global__ __launch_bounds__(256) void sgd_scaled_kernel(float* __restrict__ p, 
 // f16 mixed-precision training (the reference's precision=16, utils/misc.py:111): dynamic loss scale RESIDENT ON THE DEVICE with
 // torch.cuda.amp.GradScaler's rule (x backoff on a non-finite gradient, x growth after `interval` clean steps), so that a
 // captured hipGraph of the step replays correctly through overflow steps -- no host synchronisation anywhere.
-//   amp_state = float[2] {scale, 1 / scale};  amp_flags = int32[2] {found_inf of the current step, clean steps in a row}
+//   amp_state = float[2] {scale, 1 / scale};  amp_flags = int32[3] {found_inf of the current step, clean steps in a row, steps skipped in total}
 // ======================================================================================
 __global__ __launch_bounds__(256) void amp_scale_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ state,
                                                         float* __restrict__ y) {
@@ -746,7 +760,7 @@ __global__ __launch_bounds__(256) void amp_unscale_check_kernel(float* __restric
 __global__ void amp_update_kernel(float* __restrict__ state, int32_t* __restrict__ flags, float growth, float backoff,
                                   int interval) {
   float s = state[0];
-  if (flags[0]) { s *= backoff; flags[1] = 0; }
+  if (flags[0]) { s *= backoff; flags[1] = 0; flags[2] += 1; }   // flags[2]: steps skipped so far (host-visible: a scale pinned at 1 with every step skipped must not pass unnoticed)
   else if (++flags[1] >= interval) { s *= growth; flags[1] = 0; }
   s = fminf(fmaxf(s, 1.0f), 16777216.0f);                     // keep 1 / scale and scale * gradient representable
   state[0] = s; state[1] = 1.0f / s;
@@ -1597,13 +1611,11 @@ int creid_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
   CREID_CHECK_ARG(p && g && m && v && hyper_dev && n >= 0);
   if (n % 4 != 0) return CREID_E_SHAPE;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, hyper_dev, beta1, beta2);
-  if (n > 0) {
-    int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper_dev, beta1, beta2,
-                       eps, weight_decay, grad_scale);
-  }
+  if (n == 0) { hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, hyper_dev, beta1, beta2); CREID_LAUNCH_RET(); }
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper_dev, beta1, beta2,
+                     eps, weight_decay, grad_scale);
   CREID_LAUNCH_RET();
 }
 
@@ -1638,13 +1650,11 @@ int creid_adam_step_dev_amp(float* p, const float* g, float* m, float* v, int64_
   CREID_CHECK_ARG(p && g && m && v && hyper_dev && skip_flag && n >= 0);
   if (n % 4 != 0) return CREID_E_SHAPE;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(adam_advance_amp_kernel, dim3(1), dim3(1), 0, s, hyper_dev, beta1, beta2, skip_flag);
-  if (n > 0) {
-    int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper_dev, beta1, beta2, eps,
-                       weight_decay, grad_scale, skip_flag);
-  }
+  if (n == 0) { hipLaunchKernelGGL(adam_advance_amp_kernel, dim3(1), dim3(1), 0, s, hyper_dev, beta1, beta2, skip_flag); CREID_LAUNCH_RET(); }
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper_dev, beta1, beta2, eps,
+                     weight_decay, grad_scale, skip_flag);
   CREID_LAUNCH_RET();
 }
 

@@ -51,7 +51,8 @@ class LossScaler:
 
     def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
         self.state = torch.tensor([init_scale, 1.0 / init_scale], dtype=torch.float32, device=device)
-        self.flags = torch.zeros(2, dtype=torch.int32, device=device)
+        self.flags = torch.zeros(3, dtype=torch.int32, device=device)     # {found_inf, clean steps in a row, steps skipped in total}
+        self._ones = torch.ones(2, dtype=torch.float32, device=device)   # 'scale 1' for the check-only pass
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
 
     def scale_(self, x):
@@ -63,6 +64,17 @@ class LossScaler:
         L.check(L.lib().creid_amp_unscale_check(L.ptr(g), g.numel(), L.ptr(self.state), L.ptr(self.flags), L.stream()),
                 "creid_amp_unscale_check")
 
+    def check_(self, g):
+        """Non-finite check WITHOUT unscaling (gradients that never saw the loss scale: BNNeck, classifier, centers).
+        GradScaler.step looks at every parameter of the optimiser; so does this, into the same flag."""
+        if g.numel():
+            L.check(L.lib().creid_amp_unscale_check(L.ptr(g), g.numel(), L.ptr(self._ones), L.ptr(self.flags), L.stream()),
+                    "creid_amp_unscale_check")
+
+    @property
+    def skipped_steps(self):            # (host read-back: diagnostics / logging)
+        return int(self.flags[2].item())
+
     def update(self):
         L.check(L.lib().creid_amp_update(L.ptr(self.state), L.ptr(self.flags), self.growth_factor, self.backoff_factor,
                                          self.growth_interval, L.stream()), "creid_amp_update")
@@ -72,12 +84,13 @@ class LossScaler:
 
     def state_dict(self):
         return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
-                "growth_interval": self.growth_interval, "_growth_tracker": int(self.flags[1].item())}
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self.flags[1].item()),
+                "_skipped_steps": int(self.flags[2].item())}
 
     def load_state_dict(self, sd):
         s = float(sd["scale"])
         self.state.copy_(torch.tensor([s, 1.0 / s], dtype=torch.float32))
-        self.flags.copy_(torch.tensor([0, int(sd.get("_growth_tracker", 0))], dtype=torch.int32))
+        self.flags.copy_(torch.tensor([0, int(sd.get("_growth_tracker", 0)), int(sd.get("_skipped_steps", 0))], dtype=torch.int32))
         self.growth_factor, self.backoff_factor = float(sd.get("growth_factor", 2.0)), float(sd.get("backoff_factor", 0.5))
         self.growth_interval = int(sd.get("growth_interval", 2000))
 
@@ -96,7 +109,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = 1.0
         self.scaler, self.n_scaled = None, 0       # f16 training: LossScaler + length of the loss-scaled prefix of gflat
         # device-resident {lr, step, bc1, bc2s}: keeps a captured hipGraph of the step valid
-        self.hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=self.flat.device)   # [4]: the kernel's ticket (int32 0)
         self._lr_on_device = None
         self._params = params
         self._offsets, _ = flat_offsets(params)
@@ -166,6 +179,7 @@ class FusedAdam(torch.optim.Optimizer):
             # (after the data-parallel all-reduce: a non-finite value on any rank has reached every rank's buffer by now, so all
             # ranks skip the same steps without a collective of their own)
             self.scaler.unscale_check_(self.gflat[:self.n_scaled])
+            self.scaler.check_(self.gflat[self.n_scaled:])        # heads + the centers' gradient in the tail: checked, not unscaled
             L.check(L.lib().creid_adam_step_dev_amp(L.ptr(self.flat), L.ptr(self.gflat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                                     self.flat.numel(), L.ptr(self.hyper), b1, b2, g["eps"], g["weight_decay"],
                                                     float(self.grad_scale), L.ptr(self.scaler.flags), L.stream()),

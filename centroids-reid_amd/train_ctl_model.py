@@ -102,7 +102,8 @@ class CTLModel(ModelBase):
         if not (self.backbone.training and self.bn.training):
             raise RuntimeError("training_step with backbone / BNNeck in eval mode (validation_step leaves them there, "
                                "modelling/bases.py:170-171): call model.train() first, as the PL trainer does")
-        opt_center.zero_grad()
+        if not getattr(opt_center, "grad_in_adam_tail", False):
+            opt_center.zero_grad()        # (in the tail of Adam's flat gradient buffer: the one fill below covers it)
         opt.zero_grad()
 
         x, class_labels, camid, isReal = batch

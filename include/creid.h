@@ -358,10 +358,11 @@ int creid_gather_mean_rows(const float* emb, const int64_t* order, const int64_t
 int creid_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                     void* stream);
-/* Same update with the step-dependent scalars resident on the device: hyper_dev = float[4]
- * {lr, step, 1-beta1^step, sqrt(1-beta2^step)}; the call first advances step (+1) and the bias
- * corrections, so a captured hipGraph replays correctly; the host only rewrites hyper_dev[0] when
- * the learning rate changes.  n % 4 == 0. */
+/* Same update with the step-dependent scalars resident on the device: hyper_dev = float[8]
+ * {lr, step, 1-beta1^step, sqrt(1-beta2^step), ticket (int32, must be 0 between calls), 3 reserved}; the
+ * call uses step + 1 and its bias corrections and leaves them in hyper_dev (written by the last
+ * workgroup of the one launch), so a captured hipGraph replays correctly; the host only rewrites
+ * hyper_dev[0] when the learning rate changes.  n % 4 == 0. */
 int creid_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev,
                         float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                         void* stream);
@@ -371,7 +372,8 @@ int creid_sgd_scaled_step(float* p, float* g, int64_t n, float lr, float grad_mu
 /* f16 mixed-precision training -- the reference's own mixed precision (utils/misc.py:111 `precision=16`, i.e. native AMP with
  * torch.cuda.amp.GradScaler under pytorch-lightning 1.1.4) -- with the dynamic loss scale RESIDENT ON THE DEVICE, so that the
  * step contains no host synchronisation and a captured hipGraph replays through overflow steps:
- *   amp_state = float[2] {scale, 1 / scale}; amp_flags = int32[2] {found_inf of this step, clean steps in a row}.
+ *   amp_state = float[2] {scale, 1 / scale}; amp_flags = int32[3] {found_inf of this step, clean steps in a row, steps
+ *   skipped in total}.
  * creid_amp_scale          y = x * scale (the head gradient entering the f16 backbone backward);
  * creid_amp_unscale_check  g *= 1 / scale in place over n (% 4 == 0) floats, any non-finite element sets amp_flags[0];
  * creid_adam_step_dev_amp / creid_sgd_scaled_step_amp  = the plain steps, skipped entirely (Adam's step counter included) while
@@ -642,6 +644,10 @@ int creid_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, int64_t B, int64_
                            int dtype, void* dx, void* stream);
 /* nn.AdaptiveAvgPool2d(1) (modelling/baseline.py:89,93): feat fp32 [B, C]. */
 int creid_gap_fwd(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* feat, void* stream);
+/* creid_gap_fwd that also adds 1 to *forward_counter (int64 on the device): the training forward's count of batches seen, folded
+ * into every BatchNorm2d.num_batches_tracked before a state_dict (one counter per step instead of 53 increments). */
+int creid_gap_fwd_count(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* feat, int64_t* forward_counter,
+                        void* stream);
 int creid_gap_bwd(const float* dfeat, int64_t B, int64_t HW, int64_t C, int dtype, void* dx, void* stream);
 /* NHWC compute dtype -> NCHW fp32 (to return `base_out` in the reference's layout). */
 int creid_nhwc_to_nchw_f32(const void* x, int64_t B, int64_t HW, int64_t C, int dtype, float* y, void* stream);

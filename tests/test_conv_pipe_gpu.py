@@ -136,3 +136,45 @@ def test_pipe_kernel_matches_tile_kernels_at_production_shapes(case, dtype, monk
     import torch.nn.functional as F
     ref = F.conv2d(x[:2].float().permute(0, 3, 1, 2), krsc.float().permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
     np.testing.assert_allclose(y1[:2].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 4e-3, atol=2e-2 if dtype == torch.bfloat16 else 4e-3)
+
+
+def test_knobs_are_read_once_in_production_mode():
+    """csrc/common.hpp CREID_KNOB_ENV outside the test suite's CREID_DEBUG_KNOBS=1: every knob is read ONCE (an owned copy of the
+    environment string), so (a) CREID_IGEMM_PP=0 set before the first launch keeps the plan-selected persistent kernels off for the
+    whole process and (b) flipping a knob later has no effect -- the results are those of the first reading.  The persistent and
+    the tile kernels are bit-identical, so the observable is: every output equals the default run, nothing crashes, and the run
+    that was started with a forced variant keeps it after the variable has been removed (same bits again)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+from centroids_reid_amd import layers as ly
+rng = np.random.default_rng(0)
+x = torch.from_numpy(rng.standard_normal((4, 16, 8, 512)).astype(np.float32)).to(torch.bfloat16).cuda()
+w = torch.from_numpy((rng.standard_normal((2048, 512, 1, 1)) / 23.0).astype(np.float32)).cuda()
+krsc, crsk = ly.weight_prep(w, torch.bfloat16)
+def digest():
+    y, p = ly.conv2d_fwd(x, krsc, 1, 0, with_stats=True)
+    d = ly.conv2d_dgrad(y, crsk, (16, 8), 1, 0)
+    torch.cuda.synchronize()
+    return hashlib.sha1(y.view(torch.int16).cpu().numpy().tobytes() + d.view(torch.int16).cpu().numpy().tobytes()).hexdigest()
+a = digest()
+os.environ["CREID_IGEMM_PP"] = "0x1015" if os.environ.get("CREID_IGEMM_PP") is None else "0"     # flipped AFTER the first launch
+os.environ["CREID_IGEMM_DMA"] = "0"
+b = digest()
+print(a, b)
+''' % root
+    outs = []
+    for pp in (None, "0", hex(0x1000 | vword(256, 256, 1, 0))):
+        env = {k: v for k, v in os.environ.items() if k not in ("CREID_DEBUG_KNOBS", "CREID_IGEMM_PP", "CREID_IGEMM_DMA")}
+        if pp is not None:
+            env["CREID_IGEMM_PP"] = pp
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        a, b = r.stdout.split()[-2:]
+        assert a == b, "a knob flipped after the first launch changed the result in production mode"
+        outs.append(a)
+    assert outs[0] == outs[1] == outs[2], outs

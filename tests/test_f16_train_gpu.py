@@ -162,3 +162,30 @@ def test_f16_ibn_a_step_and_checkpoint_scaler_state():
     sc = LossScaler("cuda")
     sc.load_state_dict(st)
     assert sc.get_scale() == 1024.0 and int(sc.flags[1]) == 3 and int(sc.flags[0]) == 0
+    # resume (what pytorch-lightning's restore_training_state does): a fresh module + load_training_state continues from the same
+    # Adam step, moments, loss scale and growth tracker (the scaler state used to be written but never read back)
+    model2 = make_model(num_classes=64, dtype=torch.float16, arch="resnet50_ibn_a")
+    model2.load_state_dict(ck["state_dict"])
+    model2.load_training_state(ck)
+    opt2, _ = model2.optimizers()
+    assert opt2.step_count == 3 and model2.loss_scaler.get_scale() == 1024.0 and int(model2.loss_scaler.flags[1]) == 3
+    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+
+
+def test_head_gradient_overflow_skips_the_step_and_counts_it():
+    """GradScaler.step inspects EVERY parameter of the optimiser: a non-finite gradient confined to the heads (here: the
+    classifier) must skip Adam and the center SGD like a backbone overflow does, and the skipped step is visible on the host."""
+    from centroids_reid_amd.bench_train import make_model
+    torch.manual_seed(0)
+    model = make_model(num_classes=64, dtype=torch.float16)
+    model.loss_scaler.state.copy_(torch.tensor([1024.0, 1.0 / 1024.0]))
+    b = _batches(8, 4, 64, 32, 1)[0]
+    model.training_step(b, 0)
+    opt, _ = model.optimizers()
+    assert opt.step_count == 1 and model.loss_scaler.skipped_steps == 0
+    model.forward_backward(b, 1)
+    model.fc_query.weight.grad[3, 5] = float("inf")
+    flat0, centers0 = opt.flat.clone(), model.center_loss.centers.detach().clone()
+    model.apply_optimizers()
+    assert opt.step_count == 1 and torch.equal(opt.flat, flat0) and torch.equal(model.center_loss.centers.detach(), centers0)
+    assert model.loss_scaler.skipped_steps == 1 and model.loss_scaler.get_scale() == 512.0

@@ -122,7 +122,7 @@ def test_optimizer_steps_vs_oracle(mods):
     n4 = 100004
     p2 = torch.from_numpy(rng.standard_normal(n4).astype(np.float32)); g2 = torch.from_numpy(rng.standard_normal(n4).astype(np.float32))
     pa, ga, ma, va = p2.cuda(), g2.cuda(), torch.zeros(n4).cuda(), torch.zeros(n4).cuda()
-    hyper = torch.tensor([3.5e-5, 0, 0, 0], dtype=torch.float32).cuda()
+    hyper = torch.tensor([3.5e-5, 0, 0, 0, 0, 0, 0, 0], dtype=torch.float32).cuda()      # float[8] (creid.h)
     pr, mr, vr = p2.clone(), torch.zeros(n4), torch.zeros(n4)
     for step in (1, 2, 3):
         pr, mr, vr = ro.adam_step(pr, g2, mr, vr, step, 3.5e-5)
