@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest committed counter passes first
+PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest committed counter passes first (eval kernels only: the training families are measured live)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_TFLOPS = 157.3        # f32-input MFMA dense peak
 MFMA_BF16_TFLOPS = 2500.0      # bf16 MFMA dense peak
@@ -366,8 +366,8 @@ def cpu_baseline_eval(feats, pids, cams, nq, ng):
 
 
 def cpu_baseline_train(P, K, H, W):
-    """The CPU oracle (kind 'port': torch-CPU restatement of backbone + heads, autograd backward) on the host
-    cores, same synthetic shapes.  Bounded sample: five full 64-image steps after one warm-up step, on at most 32
+    """The CPU oracle (kind 'port': torch-CPU restatement of backbone + heads, autograd backward, torch.optim Adam + SGD steps)
+    on the host cores, same synthetic shapes.  Bounded sample: five full 64-image steps after one warm-up step, on at most 32
     threads (torch-CPU convolutions get slower, not faster, when oversubscribed across hundreds of cores)."""
     from oracle import backbone_oracle as bo, reid_oracle as ro
     cores = min(32, os.cpu_count() or 1)
@@ -380,13 +380,23 @@ def cpu_baseline_train(P, K, H, W):
     centers = torch.randn(C, 2048, requires_grad=True); fc = (torch.randn(C, 2048) * 0.001).requires_grad_(True)
     bw = torch.ones(2048, requires_grad=True)
 
+    # the reference's two optimisers (solver/build.py:9-47): Adam(lr 3.5e-4, weight decay 5e-4) over everything but the centers,
+    # SGD(lr 0.5) over the centers after the 1 / CENTER_LOSS_WEIGHT rescale (train_ctl_model.py:154-159) -- the GPU number
+    # includes both steps, so does this one
+    opt = torch.optim.Adam(list(params.values()) + [fc, bw], lr=3.5e-4, weight_decay=5e-4)
+    opt_c = torch.optim.SGD([centers], lr=0.5)
+
     def step(p):
         x = torch.randn(p * K, 3, H, W)
         labels = torch.as_tensor(np.repeat((np.arange(p) * 7) % C, K).astype(np.int64))
         is_real = torch.ones(p * K, dtype=torch.bool)
+        opt.zero_grad(); opt_c.zero_grad()
         _, feat = bo.backbone_forward(x, sd2, "resnet50", 1, training=True)
         o = ro.ctl_heads(feat, labels, is_real, bw, torch.zeros(2048), torch.zeros(2048), torch.ones(2048), fc, centers, p, K)
         o["total"].backward()
+        opt.step()
+        centers.grad.mul_(1.0 / 5e-4)
+        opt_c.step()
     nsteps = int(os.environ.get("CREID_CPU_BASELINE_STEPS", "5"))     # >= 5 steps after 1 warm-up
     step(P)
     t0 = time.perf_counter()
@@ -394,7 +404,7 @@ def cpu_baseline_train(P, K, H, W):
         step(P)
     dt = time.perf_counter() - t0
     return {"value": nsteps * P * K / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{nsteps} steps of {P * K} images (fwd + bwd, no optimiser) after 1 warm-up step, torch-CPU oracle; "
+            "sample": f"{nsteps} full steps of {P * K} images (fwd + bwd + Adam + center SGD, like the GPU step) after 1 warm-up step, torch-CPU oracle; "
                       f"{cores} of {os.cpu_count()} host threads: torch-CPU (oneDNN) convolutions of a 64-image batch stop scaling past "
                       "one socket's worth of cores and get SLOWER when oversubscribed across all of them, so 32 is the fastest setting "
                       "for this baseline (the eval leg, a pure GEMM + sort, uses every core)",
@@ -423,6 +433,31 @@ def cpu_baseline_embed(B=64, H=256, W=128, reps=3):
     return {"value": reps * B / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{reps} eval-mode forwards of {B} images after 1 warm-up, torch-CPU oracle ({cores} of {os.cpu_count()} host "
                       "threads, the fastest setting: see the training leg's note)", "seconds": dt}
+
+
+def vendor_yardstick(timeout_s=None):
+    """tools/vendor_step.py in a child process: the same training step / embedding forward on stock torch-ROCm modules (MIOpen,
+    hipBLASLt, channels_last, bf16 autocast), same box -- a yardstick outside the product.  None when switched off; an `error`
+    entry when the stock stack does not finish inside the budget (MIOpen's first-run kernel search can take minutes on a fresh
+    box -- nothing the product depends on)."""
+    import subprocess
+    if os.environ.get("CREID_BENCH_NO_VENDOR", "0") == "1":
+        return None
+    timeout_s = timeout_s or int(os.environ.get("CREID_BENCH_VENDOR_TIMEOUT", "150"))
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vendor_step.py"), "--steps", "10"], capture_output=True, text=True,
+                           timeout=timeout_s, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if line:
+            out = json.loads(line[-1])
+            out["seconds_incl_kernel_search"] = time.perf_counter() - t0
+            return out
+        return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"stock torch-ROCm step did not finish in {timeout_s} s (MIOpen kernel search on a fresh box)"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 # ----------------------------------------------------------------------------- main
@@ -468,6 +503,14 @@ def main():
                               None if args.no_cpu_baseline else cpu_baseline_train)
         if rank == 0 and world == 1 and "embed" in out and not args.no_cpu_baseline:
             out["embed"]["cpu_baseline"] = cpu_baseline_embed()
+        if rank == 0 and world == 1 and "embed" in out:
+            vy = vendor_yardstick()
+            if vy is not None:
+                if "step" in vy:
+                    vy["step"]["product_over_vendor"] = out["value"] / vy["step"]["images_per_s"]
+                if "embed" in vy:
+                    vy["embed"]["product_over_vendor"] = out["embed"]["value"] / vy["embed"]["images_per_s"]
+                out["extra"] = {"vendor_yardstick": vy}
         if os.environ.get("CREID_BENCH_NO_EVAL", "0") != "1":
             # the other half of BASELINE.metric (eval query x gallery dist-pairs/s) rides in the same line, timed by
             # the same invocation: 5 steps after 2 warm-up of the configs[4] workload

@@ -10,7 +10,7 @@ import sqlite3
 import sys
 
 sys.path.insert(0, ".")
-from centroids_reid_amd.bench_train import conv_shapes   # noqa: E402
+from centroids_reid_amd.bench_train import conv_shapes, conv_launch_work, conv_step_sol   # noqa: E402
 
 IS_CONV = re.compile(r"igemm_|conv3x3_c64")
 IS_WGRAD = re.compile(r"wgrad_bf16_dma_kernel|wgrad_f32|stem_wgrad|wgrad_bf16_kernel")
@@ -36,24 +36,8 @@ def blocks(B, H, W):
 
 
 def work(B, shape, what, role=None, bi=None):
-    """(FLOPs, algorithmic bytes) of one launch.  The data gradients carry fused passes whose operands count as their bytes:
-    c3 / c2: the column sums of the NEXT BatchNorm backward (bn2 / bn1: that layer's raw output + its ReLU bits, once);
-    c1: the block's incoming gradient added through the ReLU bits (residual branch; the compact downsample gradient in a
-    downsample block) and, except in the first block, the column sums of the previous block's bn3."""
-    cin, cout, k, st, h, w = shape
-    ho, wo = (h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1
-    fl = 2.0 * B * ho * wo * cout * cin * k * k
-    x, y = B * h * w * cin * 2, B * ho * wo * cout * 2
-    if what == "dgrad" and st == 2 and k == 1:
-        x = B * ho * wo * cin * 2                      # computed compact on the output grid, scatter-added by the c1 data gradient
-    extra = 0
-    if what == "dgrad" and role in ("c3", "c2"):
-        extra = x + x // 16                            # bn2 / bn1 statistics: raw conv output of the producing layer + mask bits
-    elif what == "dgrad" and role == "c1":
-        extra = x + x // 16                            # residual-branch gradient (+ bits)
-        if bi:
-            extra += x + x // 16                       # previous block's bn3: raw output + bits
-    return fl, x + y + extra
+    """(FLOPs, algorithmic bytes) of one launch: the model bench.py prices the step with (bench_train.conv_launch_work)."""
+    return conv_launch_work(B, shape, what, role, first_block=not bi)
 
 
 def main(path, B=64, H=256, W=128):
@@ -93,9 +77,10 @@ def main(path, B=64, H=256, W=128):
         table[(None, "stem")]["wgrad"] = (short(wgr[-1][0]), wgr[-1][1])
     print(f"one training step (B = {B}, {H} x {W}): {len(step)} kernels, {sum(e - s for _, s, e in step) / 1e3:.0f} us summed over a "
           f"{(step[-1][2] - step[0][1]) / 1e3:.0f} us span; {len(convs)} forward / data-gradient launches, {len(wgr)} weight gradients\n")
-    print("| block | role | shape | pass | kernel | us | TF/s | GB/s (algorithmic) | vs same-shape fwd |\n|---|---|---|---|---|---:|---:|---:|---:|")
+    print("| block | role | shape | pass | kernel | us | TF/s | GB/s (algorithmic) | vs same-shape fwd | speed of light us | x SOL |\n|---|---|---|---|---|---:|---:|---:|---:|---:|---:|")
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     ratios = []
+    soltot = {}
     for (bi, role), e in table.items():
         cin, cout, k, st, h, w = e["shape"]
         label = f"{cin}->{cout} k{k} s{st} {h}x{w}"
@@ -111,11 +96,17 @@ def main(path, B=64, H=256, W=128):
             rel = t / e["fwd"][1]
             if what != "fwd":
                 ratios.append((rel, bi, role, label, what, t, fl / t / 1e6))
+            sol = max(fl / 2.5e15, by / 6.3e12) * 1e6
+            soltot[what] = soltot.get(what, 0.0) + sol
             print(f"| {'' if bi is None else bi} | {role} | {label} | {what} | {kern} | {t:.1f} | {fl / t / 1e6:.0f} | {by / t / 1e3:.0f} | "
-                  f"{'' if what == 'fwd' else f'{rel:.2f} x'} |")
+                  f"{'' if what == 'fwd' else f'{rel:.2f} x'} | {sol:.1f} | {t / sol:.2f} |")
     print()
     for what, (fl, t) in tot.items():
         print(f"{what}: {t:.0f} us, {fl / t / 1e6:.0f} TF/s over the layer mix = {fl / t / 1e6 / 2500:.3f} of the bf16 MFMA peak")
+    print("\nspeed of light per launch = max(2MNK / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s), summed: "
+          + ", ".join(f"{k} {v:.0f} us (measured {tot[k][1]:.0f}, x {tot[k][1] / v:.2f})" for k, v in soltot.items())
+          + f"; all passes {sum(soltot.values()):.0f} us vs {sum(v[1] for v in tot.values()):.0f} us measured = "
+          f"{sum(soltot.values()) / sum(v[1] for v in tot.values()):.3f} of the attainable bound (bench.py roofline.frac_of_sol)")
     print("\nslowest relative to the forward of the same shape:")
     for rel, bi, role, label, what, t, tf in sorted(ratios, reverse=True)[:8]:
         print(f"  block {bi} {role} {label} {what}: {t:.1f} us ({tf:.0f} TF/s) = {rel:.2f} x its forward")
