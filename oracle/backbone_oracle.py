@@ -102,7 +102,9 @@ def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
 
 def _ibn(x, sd, name, training):
     half = sd[name + ".IN.weight"].shape[0]
-    a = F.instance_norm(x[:, :half].float().contiguous(), None, None, sd[name + ".IN.weight"],
+    xin = x[:, :half]
+    xin = xin if xin.dtype == torch.float64 else xin.float()             # (fp64: the yardstick evaluation of the noise-floor tests)
+    a = F.instance_norm(xin.contiguous(), None, None, sd[name + ".IN.weight"],
                         sd[name + ".IN.bias"], True, 0.1, 1e-5)        # resnet_ibn_a.py:24,29
     b = _bn(x[:, half:].contiguous(), sd, name + ".BN", training)
     return torch.cat([a, b], 1)

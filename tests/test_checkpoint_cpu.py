@@ -153,3 +153,25 @@ def test_backbone_load_param_prefix_rules(tmp_path):
     for k, v in idst.state_dict().items():
         if not k.startswith("fc."):
             assert torch.equal(v, isrc.state_dict()[k]), k
+
+
+def test_config_tree_has_exactly_the_reference_keys_and_defaults():
+    """north_star: "config/defaults.py keys ... stay intact".  tests/golden/config_keys.json is the reference's own tree
+    (config/defaults.py:13-181, recorded by tools/gen_golden.py config): same dotted key set, same defaults."""
+    import json
+    import os
+    from centroids_reid_amd.config import get_cfg_defaults
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref = json.load(open(os.path.join(here, "golden", "config_keys.json")))["keys"]
+
+    def flat(node, prefix, out):
+        for k, v in node.items():
+            if isinstance(v, dict):
+                flat(v, prefix + k + ".", out)
+            else:
+                out[prefix + k] = list(v) if isinstance(v, tuple) else v
+        return out
+    own = flat(get_cfg_defaults(), "", {})
+    assert sorted(own) == sorted(ref), (sorted(set(ref) - set(own)), sorted(set(own) - set(ref)))
+    diff = {k: (own[k], ref[k]) for k in ref if own[k] != ref[k]}
+    assert not diff, diff

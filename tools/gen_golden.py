@@ -552,3 +552,32 @@ def gen_transforms():
 
 if __name__ == "__main__" and "transforms" in sys.argv[1:]:
     gen_transforms()
+
+
+def gen_config_keys():
+    """The reference's whole configuration tree (config/defaults.py:13-181: every key and its default), flattened to dotted
+    names, as DATA: tests/golden/config_keys.json.  tests/test_checkpoint_cpu.py compares the product's config.get_cfg_defaults()
+    against it key by key (the drop-in contract of north_star: "config/defaults.py keys ... stay intact")."""
+    import importlib
+    import json
+    ref_import.install_stubs(); ref_import.ref_path_first()
+    for m in [k for k in sys.modules if k == "config" or k.startswith("config.")]:
+        del sys.modules[m]
+    defaults = importlib.import_module("config.defaults")
+    root = defaults._C
+
+    def flat(node, prefix, out):
+        for k, v in node.items():
+            if isinstance(v, dict):
+                flat(v, prefix + k + ".", out)
+            else:
+                out[prefix + k] = list(v) if isinstance(v, tuple) else v
+        return out
+    tree = flat(root, "", {})
+    with open(os.path.join(OUT, "config_keys.json"), "w") as f:
+        json.dump({"source": "config/defaults.py _C of the reference, flattened (tuples as lists)", "keys": tree}, f, indent=1, sort_keys=True)
+    print(f"config_keys.json: {len(tree)} keys")
+
+
+if __name__ == "__main__" and "config" in sys.argv[1:]:
+    gen_config_keys()
