@@ -40,7 +40,7 @@ __device__ __attribute__((aligned(128))) unsigned g_zero_page[32];
 
 // ------------------------------------------------------------------------------------ bf16
 template <int BN>
-__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
+__global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void igemm_bf16_kernel(IGemmGeom g, const unsigned short* __restrict__ src,
                                                          const unsigned short* __restrict__ wgt,
                                                          unsigned short* __restrict__ out,
                                                          const unsigned short* __restrict__ add_src,

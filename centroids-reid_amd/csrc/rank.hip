@@ -153,9 +153,13 @@ __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restri
   // two labels per entry from global memory (64 distinct cache lines per wave instruction: 18 us per row, measured)
   unsigned long long* bm_keep = reinterpret_cast<unsigned long long*>(idx2 + n4);
   unsigned long long* bm_match = bm_keep + ((n + 63) >> 6);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
   for (int64_t row = blockIdx.x; row < m; row += gridDim.x) {
+    // the thread index is re-derived behind an opaque copy in every row: nothing thread-dependent is hoisted out of the row
+    // loop and kept live across its ~5000 instructions (at the 128-VGPR cap of a 1024-thread workgroup two such addresses
+    // were spilled to scratch, next to 90 scalar registers parked in vector lanes)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const float* drow = dist + row * ld;
     if (ev.q_pids) {
       // (keeping all 21 label loads of a thread in flight next to the 21 distance loads costs 42 more live registers at the
@@ -241,11 +245,12 @@ __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restri
     }
     __syncthreads();
     // ---- D: rank inside the bucket by (key, index) -> final position (kept in registers) ...
-    unsigned fpos[RL_KPT], fid[RL_KPT];
+    unsigned fpk[RL_KPT];                                        // (final position << 16) | gallery index: both < RL_KPT * RT <= 65536
+    static_assert(RL_KPT * RT <= 65536, "packed (position, index) pairs");
 #pragma unroll
     for (int j = 0; j < RL_KPT; ++j) {
       const int p = tid + j * RT;
-      fpos[j] = 0; fid[j] = 0;
+      fpk[j] = 0;
       if (p < n) {
         const unsigned k = keys2[p];
         const unsigned id = idx2[p];
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restri
           r += (q + 2 >= lo && q + 2 < hi && (kq.z < k || (kq.z == k && i2 < id))) ? 1u : 0u;
           r += (q + 3 >= lo && q + 3 < hi && (kq.w < k || (kq.w == k && i3 < id))) ? 1u : 0u;
         }
-        fpos[j] = lo + r; fid[j] = id;
+        fpk[j] = ((lo + r) << 16) | id;
       }
     }
     __syncthreads();                                             // every read of keys2 / idx2 is done
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(RT) void rank_rows_lds_kernel(const float* __restri
     //      index matrix is 8 B per pair, the largest stream of the whole evaluation
 #pragma unroll
     for (int j = 0; j < RL_KPT; ++j)
-      if (tid + j * RT < n) keys2[fpos[j]] = fid[j];
+      if (tid + j * RT < n) keys2[fpk[j] >> 16] = fpk[j] & 0xffffu;
     __syncthreads();
     int64_t* orow = out_idx + row * (int64_t)n;
     if ((reinterpret_cast<uintptr_t>(orow) & 15) == 0) {
