@@ -153,7 +153,8 @@ class CtlHeads(C.Structure):
                                    "bn_running_var", "fc_weight", "loss_weights", "amp_state", "d_centers", "d_bn_weight",
                                    "d_bn_bias", "d_fc_weight", "bn_batches_tracked", "lonely", "stats", "g", "dfeat_out",
                                    "workspace")] +
-                [("workspace_bytes", _sz)])
+                [("workspace_bytes", _sz)] +
+                [(n, _p) for n in ("bn_x", "bn_mask", "bn_mean", "bn_invstd", "bn_partial")])
 
 
 class CreidError(RuntimeError):

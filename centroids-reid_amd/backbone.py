@@ -869,12 +869,30 @@ class BackboneEngine:
                 "conv2d_dgrad")
         return dx, None
 
-    def backward(self, dfeat: torch.Tensor, g: torch.Tensor = None):
+    def first_bn_bwd_operands(self):
+        """What creid_ctl_heads_fused needs to produce the column sums of the FIRST BatchNorm backward (the last bottleneck's bn3)
+        while it writes g: (x3, ReLU bits of the block output, mean, invstd, partial-rows buffer), or None when that reduction
+        keeps its own launch (fp32 engine, no mask bits, 128-row tiles that straddle images in the general case are fine)."""
+        sv = self.saved
+        if sv is None or not sv.get("training") or not (self.fuse_bn_reduce and self.drop_gm and self.relu_bitmask):
+            return None
+        if os.environ.get("CREID_HEADS_BNRED", "1") != "1":
+            return None
+        s = sv["blocks"][-1]
+        mask = getattr(s["a3"], "_relu_mask", None)
+        if mask is None or s["x3"].shape[1] % 256 != 0:
+            return None
+        M = s["x3"].shape[0]
+        part = self._empty(L.lib().creid_bn2d_bwd_rows(M) * 2, s["x3"].shape[1], dtype=torch.float32)
+        return s["x3"], mask, s["m3"], s["i3"], part
+
+    def backward(self, dfeat: torch.Tensor, g: torch.Tensor = None, part3: torch.Tensor = None):
         """Accumulates parameter gradients into `.grad` (fp32, reference layouts).  `self.on_group_done(k)`, if set,
         is called after the last kernel of layer k (4, 3, 2, 1) has been enqueued -- every gradient of that layer is
         then final in stream order (the data-parallel bucketed all-reduce hangs on it, parallel.py).
         g (optional, [B * h * w, 2048] in the compute dtype): the gradient of the final feature map, already pooled back and (f16)
-        loss-scaled -- the last launch of creid_ctl_heads_fused writes it; `dfeat` is ignored then."""
+        loss-scaled -- the last launch of creid_ctl_heads_fused writes it; `dfeat` is ignored then.  part3 (optional): the column
+        sums of the deepest bn3 backward, produced by that same launch."""
         sv = self.saved
         assert sv is not None and sv["training"], "backward() needs a training-mode forward first"
         lib, st = L.lib(), L.stream()
@@ -890,7 +908,8 @@ class BackboneEngine:
         else:
             assert g.dtype == self.dtype and tuple(g.shape) == (B * h * w, 2048) and g.is_contiguous()
         blocks = list(zip(self.blocks, sv["blocks"]))
-        part3 = None                      # bn3 partials of the CURRENT block, produced by the previous (deeper) block
+        # part3: bn3 partials of the CURRENT block, produced by the previous (deeper) block -- for the deepest block by the heads'
+        # last launch when the caller hands them in (first_bn_bwd_operands)
         for bi in range(len(blocks) - 1, -1, -1):
             b, s = blocks[bi]
             prev = blocks[bi - 1] if bi > 0 else None          # the block whose output gradient we produce

@@ -1301,6 +1301,101 @@ __global__ __launch_bounds__(256) void heads_stage6_kernel(HeadsCtx c, int hw_pa
   }
 }
 
+// S6 with the column sums of the LAST bottleneck's bn3 backward folded in (16-bit compute types): the first thing the backbone's
+// backward does with g is bn2d_bwd_reduce_kernel -- read g, the raw conv3 output and the ReLU bits again, only to sum
+// (g', g' * xhat) per channel.  Here the workgroup that writes a 128-row x 256-channel piece of g holds exactly the values
+// that kernel would load (the 16-bit-rounded g), so it accumulates the same sums over the same (row lane, channel octet) thread
+// map, in the same order, into the same partial-row layout: the partials are BIT-IDENTICAL to the stand-alone reduction and one
+// launch + one read of g are gone.  grid (C / 256, ceil(M / 128)); thread = (octet cch of 32, row lane rl of 8).
+template <typename ET>
+__global__ __launch_bounds__(256) void heads_stage6r_kernel(HeadsCtx c) {
+  const creid_ctl_heads& a = c.a;
+  const int P = (int)a.P, K = (int)a.K, D = (int)a.D, HW = (int)a.HW;
+  const int64_t M = a.B * a.HW;
+  __shared__ float red[2][256 * 8];
+  const int cch = (int)threadIdx.x & 31, rl = (int)threadIdx.x >> 5;
+  const int c0 = ((int)blockIdx.x * 32 + cch) * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * 128, r1 = min(M, r0 + 128);
+  const float* demb = c.w.demb;
+  const unsigned short* xq = reinterpret_cast<const unsigned short*>(a.bn_x);
+  unsigned short* gq = reinterpret_cast<unsigned short*>(a.g);
+  float s1[8], s2[8], mu[8], is[8], v[8];
+  unsigned gw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 8; k += 4) {
+    const float4 m4 = *reinterpret_cast<const float4*>(a.bn_mean + c0 + k);
+    const float4 i4 = *reinterpret_cast<const float4*>(a.bn_invstd + c0 + k);
+    mu[k] = m4.x; mu[k + 1] = m4.y; mu[k + 2] = m4.z; mu[k + 3] = m4.w;
+    is[k] = i4.x; is[k + 1] = i4.y; is[k + 2] = i4.z; is[k + 3] = i4.w;
+  }
+  const float scale = a.amp_state ? a.amp_state[0] : 1.f;
+  const float inv = 1.0f / (float)HW;
+  int cur_b = -1;
+  for (int64_t r = r0 + rl; r < r1; r += 8) {
+    const int b = (int)(r / HW);
+    if (b != cur_b) {                                  // a new image: its finished dfeat octet (HW >= 128: once per workgroup)
+      cur_b = b;
+      const int p = b / K, s = b % K;
+      const bool sreal = a.is_real[p * K + s] != 0;
+      const float4 f0 = *reinterpret_cast<const float4*>(c.w.dfeat + (int64_t)b * D + c0);
+      const float4 f1 = *reinterpret_cast<const float4*>(c.w.dfeat + (int64_t)b * D + c0 + 4);
+      const float4 q0 = *reinterpret_cast<const float4*>(demb + ((int64_t)s * 2 * P + p) * D + c0);
+      const float4 q1 = *reinterpret_cast<const float4*>(demb + ((int64_t)s * 2 * P + p) * D + c0 + 4);
+      v[0] = f0.x + q0.x; v[1] = f0.y + q0.y; v[2] = f0.z + q0.z; v[3] = f0.w + q0.w;
+      v[4] = f1.x + q1.x; v[5] = f1.y + q1.y; v[6] = f1.z + q1.z; v[7] = f1.w + q1.w;
+      if (sreal) {
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int i = 0; i < K; ++i) {                  // same round order and divisions as loo_emb_bwd_kernel
+          if (i == s || !a.is_real[p * K + i]) continue;
+          int cnt = 0;
+          for (int t = 0; t < K; ++t) cnt += (t != i && a.is_real[p * K + t]) ? 1 : 0;
+          const float den = (float)max(cnt, 1);
+          const float4 e0 = *reinterpret_cast<const float4*>(demb + ((int64_t)i * 2 * P + P + p) * D + c0);
+          const float4 e1 = *reinterpret_cast<const float4*>(demb + ((int64_t)i * 2 * P + P + p) * D + c0 + 4);
+          acc[0] += e0.x / den; acc[1] += e0.y / den; acc[2] += e0.z / den; acc[3] += e0.w / den;
+          acc[4] += e1.x / den; acc[5] += e1.y / den; acc[6] += e1.z / den; acc[7] += e1.w / den;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += acc[k];
+      }
+      if (a.dfeat_out && r == (int64_t)b * HW) {        // (the thread that owns the image's first row publishes the fp32 row)
+        float* o = a.dfeat_out + (int64_t)b * D + c0;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { if (a.amp_state) v[k] = v[k] * scale; v[k] = v[k] * inv; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gw[k] = ET::pack2(v[2 * k], v[2 * k + 1]);
+    }
+    const int64_t off = r * D + c0;
+    *reinterpret_cast<uint4*>(gq + off) = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+    const uint4 xv = *reinterpret_cast<const uint4*>(xq + off);
+    const unsigned m = a.bn_mask[off >> 3];
+    const unsigned* xw = &xv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g0 = ((m >> (2 * k)) & 1u) ? ET::lo(gw[k]) : 0.f, g1 = ((m >> (2 * k + 1)) & 1u) ? ET::hi(gw[k]) : 0.f;
+      s1[2 * k] += g0; s2[2 * k] = fmaf(g0, (ET::lo(xw[k]) - mu[2 * k]) * is[2 * k], s2[2 * k]);
+      s1[2 * k + 1] += g1; s2[2 * k + 1] = fmaf(g1, (ET::hi(xw[k]) - mu[2 * k + 1]) * is[2 * k + 1], s2[2 * k + 1]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][(rl * 32 + cch) * 8 + k] = s1[k]; red[1][(rl * 32 + cch) * 8 + k] = s2[k]; }
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < 2 * 32 * 8; i += 256) {
+    const int which = i / (32 * 8), cl = i - which * 32 * 8;
+    float acc = 0.f;
+    for (int q = 0; q < 8; ++q) acc += red[which][q * 32 * 8 + cl];
+    const int ch = (int)blockIdx.x * 32 * 8 + cl;
+    if (ch < D) a.bn_partial[((int64_t)blockIdx.y * 2 + which) * D + ch] = acc;
+  }
+}
+
 // ======================================================================================
 extern "C" {
 
@@ -1710,6 +1805,15 @@ int creid_ctl_heads_fused(const creid_ctl_heads* a, void* stream) {
   const int n4 = c.gd_tn * c.gd_tm * a->split_dbnf + (a->d_fc_weight ? c.gw_tn * c.gw_tm : 0) + B + 1 + (a->masked ? 1 : K * R);
   hipLaunchKernelGGL(heads_stage4_kernel, dim3((unsigned)n4), dim3(256), smem_bwd, s, c);
   hipLaunchKernelGGL(heads_stage5_kernel, dim3((unsigned)(nbn + 1 + (a->masked ? K * R : 0))), dim3(256), smem_bwd, s, c);
+  if (a->bn_partial) {
+    // the last bottleneck's bn3 column sums ride in the launch that writes g (16-bit compute types, 256-channel column groups)
+    CREID_CHECK_ARG(a->bn_x && a->bn_mask && a->bn_mean && a->bn_invstd);
+    if (a->g_dtype == CREID_F32 || D % 256 != 0) return CREID_E_SHAPE;
+    const dim3 g6r((unsigned)(D / 256), (unsigned)((a->B * a->HW + 127) / 128));
+    if (a->g_dtype == CREID_BF16) hipLaunchKernelGGL(heads_stage6r_kernel<Bf16T>, g6r, dim3(256), 0, s, c);
+    else hipLaunchKernelGGL(heads_stage6r_kernel<F16T>, g6r, dim3(256), 0, s, c);
+    CREID_LAUNCH_RET();
+  }
   int hw_parts = (int)a->HW < 8 ? (int)a->HW : 8;         // 512 workgroups at B = 64: each re-derives its dfeat row once per 16 copies
   const dim3 g6((unsigned)(B * hw_parts));
   if (a->g_dtype == CREID_F32) hipLaunchKernelGGL(heads_stage6_kernel<CREID_F32>, g6, dim3(256), 0, s, c, hw_parts);

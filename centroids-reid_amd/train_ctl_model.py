@@ -415,10 +415,16 @@ class CTLModel(ModelBase):
                         ("lonely", lonely), ("stats", stats), ("g", g), ("dfeat_out", None), ("workspace", ws)):
             setattr(a, name, None if t is None else t.data_ptr())
         a.workspace_bytes = nbytes
+        bnred = eng.first_bn_bwd_operands() if hasattr(eng, "first_bn_bwd_operands") else None
+        if bnred is not None:
+            a.bn_x, a.bn_mask, a.bn_mean, a.bn_invstd, a.bn_partial = (t.data_ptr() for t in bnred)
         if not bn.num_batches_tracked.is_cuda:
             bn.num_batches_tracked += 1
         L.check(lib.creid_ctl_heads_fused(C.byref(a), L.stream()), "creid_ctl_heads_fused")
-        eng.backward(None, g=g)                                               # manual_backward (:152)
+        if bnred is not None:
+            eng.backward(None, g=g, part3=bnred[4])                           # manual_backward (:152)
+        else:
+            eng.backward(None, g=g)
         terms = stats[:n]
         contrastive_loss_query = terms[0]
         center_loss, xent_query = terms[4 * (K + 1)], terms[4 * (K + 1) + 1]

@@ -218,6 +218,15 @@ typedef struct creid_ctl_heads {
   float* dfeat_out;
   void* workspace;
   size_t workspace_bytes;
+  /* optional (all five or none; 16-bit g_dtype, D % 256 == 0): the column sums of the BatchNorm backward that consumes g first
+   * (the last bottleneck's bn3, modelling/backbones/resnet.py:81-83) are produced by the launch that writes g --
+   * bn_partial [creid_bn2d_bwd_rows(B * HW)][2][D], bit-identical to creid_bn2d_bwd's own column pass (partial_ready = 1):
+   * bn_x = that layer's raw convolution output [B * HW, D], bn_mask = the ReLU bits of its output, bn_mean / bn_invstd [D]. */
+  const void* bn_x;
+  const uint8_t* bn_mask;
+  const float* bn_mean;
+  const float* bn_invstd;
+  float* bn_partial;
 } creid_ctl_heads;
 size_t creid_ctl_heads_workspace_bytes(int64_t B, int64_t P, int64_t K, int64_t D, int64_t num_classes);
 int creid_ctl_heads_fused(const creid_ctl_heads* a, void* stream);
