@@ -116,6 +116,7 @@ SIGNATURES = {
     "creid_bn2d_bwd_rows": (_i64, [_i64]),
     "creid_bn2d_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
     "creid_bn2d_bwd_mask": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
+    "creid_bn2d_bwd_mask_reduce2": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "creid_conv2d_dgrad_bnred_nhwc": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p]),
     "creid_conv2d_dgrad_fused_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, C.c_int, _p, _sz,
                                                 C.c_int, _p]),

@@ -311,6 +311,7 @@ class BackboneEngine:
         # TIMING-ONLY ablation (results are WRONG): bit 0 skips the forward BatchNorm apply launches of bn1 / bn2 (no residual),
         # bit 1 their backward apply launches -- the upper bound of what fusing those passes into the consuming / producing
         # convolutions could save (profiles/r03_bn_fusion_bound.md)
+        self.ds_reduce2 = os.environ.get("CREID_DS_REDUCE2", "1") == "1"
         self.dual_apply = os.environ.get("CREID_DUAL_APPLY", "1") == "1"     # A/B knob: 0 = separate downsample-BN apply launch
         # training forward: BatchNorm finalize + apply as ONE launch on layers with at most this many statistic rows (M <= 8192 by
         # default: 24 launches less per B = 64 step at the same step time -- captured and eager --, bit-identical:
@@ -746,9 +747,11 @@ class BackboneEngine:
             p.grad = torch.zeros_like(p)
         return p.grad
 
-    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False, part=None, mask=None, dry=False):
+    def _bn_bwd(self, u, x, g, act, mean, invstd, M, want_gm=False, part=None, mask=None, dry=False, reduce2=None):
         """BN backward; `part` = column-reduction partials already produced by a fused dgrad epilogue; `mask` = ReLU bits
-        to apply to g (default: the ones that travel with `act`)."""
+        to apply to g (default: the ones that travel with `act`).  reduce2 = (x2, mean2, invstd2): the apply pass also produces
+        the column sums of a second BatchNorm backward over the same masked gradient (the downsample branch's); returned in
+        place of gm."""
         lib, st = L.lib(), L.stream()
         rows = lib.creid_bn2d_bwd_rows(M)
         ready = 1 if part is not None else 0
@@ -775,6 +778,14 @@ class BackboneEngine:
             mask = getattr(act, "_relu_mask", None)
         if dry and ready == 2:
             return dx, gm
+        if reduce2 is not None:
+            x2, mean2, invstd2 = reduce2
+            part2 = self._empty(rows * 2, u.cout, dtype=torch.float32)
+            L.check(lib.creid_bn2d_bwd_mask_reduce2(L.ptr(x), L.ptr(g), L.ptr(mask), L.ptr(mean), L.ptr(invstd), L.ptr(bn.weight), M,
+                                                    u.cout, self.dt, L.ptr(part), ready, L.ptr(sums), L.ptr(dgam), L.ptr(dbet),
+                                                    L.ptr(dx), L.ptr(x2), L.ptr(mean2), L.ptr(invstd2), L.ptr(part2), st),
+                    "bn2d_bwd_reduce2")
+            return dx, part2
         L.check(lib.creid_bn2d_bwd_mask(L.ptr(x), L.ptr(g), L.ptr(act), L.ptr(mask), L.ptr(mean), L.ptr(invstd),
                                         L.ptr(bn.weight), M, u.cout, self.dt, L.ptr(part), ready, L.ptr(sums), L.ptr(dgam),
                                         L.ptr(dbet), L.ptr(dx), L.ptr(gm), st), "bn2d_bwd")
@@ -918,9 +929,17 @@ class BackboneEngine:
             # downsample BN).  With the mask as bits every consumer applies it itself and the masked copy `gm` is never
             # written; otherwise bn3's backward writes it once.
             m3 = getattr(s["a3"], "_relu_mask", None) if (self.fuse_bn_reduce and self.drop_gm) else None
-            dx3, gm = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, want_gm=m3 is None, part=part3)
-            if m3 is not None:
+            # downsample blocks: bn3's apply pass also sums the columns the downsample branch's BatchNorm backward needs (same
+            # masked gradient, one read of it instead of two and one launch less; CREID_DS_REDUCE2=0: separate launches)
+            ds_part = None
+            if m3 is not None and b["ds"] is not None and self.ds_reduce2 and not self.fin_with_wred:
+                dx3, ds_part = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, part=part3,
+                                            reduce2=(s["xd"], s["md"], s["idd"]))
                 gm = g
+            else:
+                dx3, gm = self._bn_bwd(b["c3"], s["x3"], g, s["a3"], s["m3"], s["i3"], M3, want_gm=m3 is None, part=part3)
+                if m3 is not None:
+                    gm = g
             # per convolution: data gradient first (it feeds the dependent chain dgrad -> BN finalize -> BN apply -> dgrad),
             # then the weight gradient, which is off that chain and carries the finalize of the BatchNorm whose column sums
             # the data gradient just produced (and, via the pending queue, gets its own split reduction carried by the
@@ -956,7 +975,7 @@ class BackboneEngine:
             c1_first = wfirst or B * s["hin"] * s["win"] * b["c1"].cin * 2 > self.carrier_max_bytes
             wg(b["c1"], s["a_in"], dx1, s["hin"], s["win"], early=True, first=c1_first)
             if b["ds"] is not None:
-                dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3, mask=m3)
+                dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M3, mask=m3, part=ds_part)
                 dsu = b["ds"]
                 if (dsu.stride == 2 and dsu.k == 1 and nxt is not None and self.fuse_bn_reduce
                         and s["hin"] % 2 == 0 and s["win"] % 2 == 0):

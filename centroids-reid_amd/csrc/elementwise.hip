@@ -446,6 +446,69 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T* __restric
   }
 }
 
+// Downsample blocks: the block's incoming gradient g (through the output ReLU's bits) feeds TWO BatchNorm backward passes -- bn3
+// (dx = A g' + B x + C, coefficients final) and the downsample branch's BatchNorm, which first needs its column sums
+// (sum g', sum g' * xhat2).  This kernel does both in one pass over g and the bits: thread map, summation order and partial-row
+// layout are bn2d_bwd_reduce_kernel's, the dx expression is bn2d_bwd_apply_kernel's -- results bit-identical to the two launches,
+// one read of g (+ bits) and one launch less per downsample block.
+template <typename T>
+__global__ __launch_bounds__(256) void bn2d_bwd_apply_reduce2_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                                     const uint8_t* __restrict__ mask,
+                                                                     const float* __restrict__ coef, int64_t M, int C,
+                                                                     int rows_per_block, T* __restrict__ dx,
+                                                                     const T* __restrict__ x2, const float* __restrict__ mean2,
+                                                                     const float* __restrict__ invstd2,
+                                                                     float* __restrict__ partial2) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[2][256 * V];
+  const int cpr = C / V, cw = cpr < 32 ? cpr : 32, nrl = 256 / cw;
+  const int cch = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int c0 = (blockIdx.x * cw + cch) * V;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s1[V], s2[V], mu[V], is[V], ca[V], cb[V], cc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; is[k] = 0.f; }
+  if (c0 < C) {
+#pragma unroll
+    for (int k = 0; k < V; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(mean2 + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(invstd2 + c0 + k);
+      mu[k] = a.x; mu[k + 1] = a.y; mu[k + 2] = a.z; mu[k + 3] = a.w;
+      is[k] = b.x; is[k + 1] = b.y; is[k + 2] = b.z; is[k + 3] = b.w;
+      const float4 pa = *reinterpret_cast<const float4*>(coef + c0 + k);
+      const float4 pb = *reinterpret_cast<const float4*>(coef + C + c0 + k);
+      const float4 pc = *reinterpret_cast<const float4*>(coef + 2 * C + c0 + k);
+      ca[k] = pa.x; ca[k + 1] = pa.y; ca[k + 2] = pa.z; ca[k + 3] = pa.w;
+      cb[k] = pb.x; cb[k + 1] = pb.y; cb[k + 2] = pb.z; cb[k + 3] = pb.w;
+      cc[k] = pc.x; cc[k + 1] = pc.y; cc[k + 2] = pc.z; cc[k + 3] = pc.w;
+    }
+    for (int64_t r = r0 + rl; r < r1; r += nrl) {
+      float xv[V], gv[V], x2v[V], o[V];
+      Vec16<T>::load(x + r * C + c0, xv);
+      Vec16<T>::load(g + r * C + c0, gv);
+      Vec16<T>::load(x2 + r * C + c0, x2v);
+      const unsigned m = mask ? mask[(r * C + c0) / V] : 0xffu;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        gv[k] = ((m >> k) & 1u) ? gv[k] : 0.f;
+        o[k] = fmaf(ca[k], gv[k], fmaf(cb[k], xv[k], cc[k]));
+        s1[k] += gv[k]; s2[k] = fmaf(gv[k], (x2v[k] - mu[k]) * is[k], s2[k]);
+      }
+      Vec16<T>::store(dx + r * C + c0, o);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) { red[0][(rl * cw + cch) * V + k] = s1[k]; red[1][(rl * cw + cch) * V + k] = s2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * cw * V; i += 256) {
+    const int which = i / (cw * V), cl = i - which * cw * V;
+    float a = 0.f;
+    for (int q = 0; q < nrl; ++q) a += red[which][q * cw * V + cl];
+    const int c = blockIdx.x * cw * V + cl;
+    if (c < C) partial2[((int64_t)blockIdx.y * 2 + which) * C + c] = a;
+  }
+}
+
 // sums[2][C] = sum over row blocks; dgamma += sum dy*xhat ; dbeta += sum dy
 template <int CW>
 __global__ __launch_bounds__(1024) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
@@ -1141,10 +1204,12 @@ int creid_bn2d_apply(const void* x, const float* scale_shift, const void* residu
 
 int64_t creid_bn2d_bwd_rows(int64_t M) { int64_t r = (M + 127) / 128; return r < 1 ? 1 : r; }
 
+struct Reduce2 { const void* x2; const float* mean2; const float* invstd2; float* partial2; };
+
 static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const uint8_t* mask, PoolGrad pg, const float* mean,
                          const float* invstd, const float* gamma, int64_t M, int64_t C, int dtype, float* partial,
                          int partial_ready, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx, void* gm_out,
-                         void* stream) {
+                         void* stream, Reduce2 r2 = Reduce2{nullptr, nullptr, nullptr, nullptr}) {
   CREID_CHECK_ARG(x && (g || pg.dy) && mean && invstd && (partial || partial_ready == 2) && sums && dx && M > 0 && C > 0 && C % 8 == 0);
   if (mask && dtype == CREID_F32) return CREID_E_DTYPE;
   const int rows = (int)creid_bn2d_bwd_rows(M);
@@ -1170,6 +1235,19 @@ static int bn2d_bwd_impl(const void* x, const void* g, const void* act, const ui
       hipLaunchKernelGGL(bn2d_bwd_finalize_kernel<16>, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, s, partial, rows, (int)C,
                          (double)M, mean, invstd, gamma, sums, dgamma_accum, dbeta_accum);
   }
+  if (r2.x2) {
+    // apply + the column sums of a second BatchNorm over the same masked gradient (downsample blocks), one pass
+    if (act || gm_out || pg.dy || dtype == CREID_F32) return CREID_E_ARG;
+    const dim3 grid2((unsigned)((C / 8 + 31) / 32), (unsigned)rows);
+    if (dtype == CREID_BF16)
+      hipLaunchKernelGGL(bn2d_bwd_apply_reduce2_kernel<unsigned short>, grid2, dim3(256), 0, s, (const unsigned short*)x,
+                         (const unsigned short*)g, mask, sums, M, (int)C, 128, (unsigned short*)dx, (const unsigned short*)r2.x2,
+                         r2.mean2, r2.invstd2, r2.partial2);
+    else
+      hipLaunchKernelGGL(bn2d_bwd_apply_reduce2_kernel<_Float16>, grid2, dim3(256), 0, s, (const _Float16*)x, (const _Float16*)g,
+                         mask, sums, M, (int)C, 128, (_Float16*)dx, (const _Float16*)r2.x2, r2.mean2, r2.invstd2, r2.partial2);
+    CREID_LAUNCH_RET();
+  }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(ew_blocks_k<bn2d_bwd_apply_kernel<float>>(M * C / 4, C / 4)), dim3(256), 0, s,
                                 (const float*)x, (const float*)g, (const float*)act, sums, M, (int)C,
@@ -1190,6 +1268,16 @@ int creid_bn2d_bwd_mask(const void* x, const void* g, const void* act, const uin
   CREID_CHECK_ARG(g);
   return bn2d_bwd_impl(x, g, act, mask, PoolGrad{nullptr, nullptr, 0, 0}, mean, invstd, gamma, M, C, dtype, partial, partial_ready,
                        sums, dgamma_accum, dbeta_accum, dx, gm_out, stream);
+}
+
+int creid_bn2d_bwd_mask_reduce2(const void* x, const void* g, const uint8_t* mask, const float* mean, const float* invstd,
+                                const float* gamma, int64_t M, int64_t C, int dtype, float* partial, int partial_ready, float* sums,
+                                float* dgamma_accum, float* dbeta_accum, void* dx, const void* x2, const float* mean2,
+                                const float* invstd2, float* partial2, void* stream) {
+  CREID_CHECK_ARG(g && x2 && mean2 && invstd2 && partial2);
+  if (!creid_is16(dtype)) return CREID_E_DTYPE;
+  return bn2d_bwd_impl(x, g, nullptr, mask, PoolGrad{nullptr, nullptr, 0, 0}, mean, invstd, gamma, M, C, dtype, partial, partial_ready,
+                       sums, dgamma_accum, dbeta_accum, dx, nullptr, stream, Reduce2{x2, mean2, invstd2, partial2});
 }
 
 int creid_bn2d_bwd_pooled(const void* x, const void* dy_pooled, const uint8_t* idx, int64_t B, int64_t H, int64_t W,

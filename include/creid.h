@@ -603,6 +603,14 @@ int creid_bn2d_bwd_mask(const void* x, const void* g, const void* act, const uin
                         const float* invstd, const float* gamma, int64_t M, int64_t C, int dtype, float* partial,
                         int partial_ready, float* sums, float* dgamma_accum, float* dbeta_accum, void* dx,
                         void* gm_out, void* stream);
+/* creid_bn2d_bwd_mask for the bn3 of a DOWNSAMPLE block (16-bit types; no act / gm_out): the pass that writes dx also produces the
+ * column sums of the downsample branch's BatchNorm backward over the same masked gradient -- partial2
+ * [creid_bn2d_bwd_rows(M)][2][C] from that branch's raw output x2 and its (mean2, invstd2) -- bit-identical to that layer's own
+ * column pass (hand it to creid_bn2d_bwd_mask with partial_ready = 1); dx is bit-identical to creid_bn2d_bwd_mask's. */
+int creid_bn2d_bwd_mask_reduce2(const void* x, const void* g, const uint8_t* mask, const float* mean, const float* invstd,
+                                const float* gamma, int64_t M, int64_t C, int dtype, float* partial, int partial_ready, float* sums,
+                                float* dgamma_accum, float* dbeta_accum, void* dx, const void* x2, const float* mean2,
+                                const float* invstd2, float* partial2, void* stream);
 
 /* IBN of ResNet50-IBN-a (modelling/backbones/resnet_ibn_a.py:18-32): channels [0, c_in) InstanceNorm2d
  * (affine, per-(image, channel) statistics over H*W, eps 1e-5, no running stats), channels [c_in, C)

@@ -883,3 +883,24 @@ def test_weight_prep_multi_equals_single_tensor_prep(dtype):
         a, b = ly.weight_prep(ws[n], dtype)
         assert torch.equal(krsc[n], a), ("krsc", shapes[n])
         assert torch.equal(crsk[n], b), ("crsk", shapes[n])
+
+
+@pytest.mark.parametrize("arch,dtype", [("resnet50", torch.bfloat16), ("resnet50", torch.float16), ("resnet50_ibn_a", torch.bfloat16)])
+def test_downsample_bn_column_sums_in_bn3_apply_pass_are_bit_identical(arch, dtype):
+    """Round 6: in a downsample block bn3's backward apply pass also produces the column sums of the downsample branch's
+    BatchNorm backward (creid_bn2d_bwd_mask_reduce2: same masked gradient, same thread map and summation order as the stand-alone
+    column pass).  Every parameter gradient of the network must equal the two-launch schedule's bit for bit."""
+    from oracle import backbone_oracle as bo
+    x = bo.synthetic_images(8, 128, 64, seed=17).cuda()
+    coef = torch.from_numpy(np.random.default_rng(5).standard_normal((8, 2048)).astype(np.float32)).cuda()
+    grads = []
+    for fused in (True, False):
+        net, eng, _ = _build(arch, dtype, seed=99)
+        eng.ds_reduce2 = fused
+        eng.loss_scaler = None
+        _, f = eng.forward(x, training=True)
+        eng.backward(coef)
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 150
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
