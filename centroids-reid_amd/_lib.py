@@ -83,6 +83,7 @@ SIGNATURES = {
     "creid_conv2d_bn_partial_rows": (_i64, [_p]),
     "creid_conv2d_fwd_nhwc": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _p]),
     "creid_conv2d_fwd_affine_nhwc": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
+    "creid_conv1x1_bnrelu_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, C.c_int, _p]),
     "creid_bn2d_fold_entry_bytes": (_i64, []),
     "creid_bn2d_fold_multi": (C.c_int, [_p, _i64, _p]),
     "creid_stem_conv_fwd_affine": (C.c_int, [_i64, _i64, _i64, _p, _p, _p, _p, C.c_int, C.c_int, _p]),

@@ -311,6 +311,10 @@ class BackboneEngine:
         # TIMING-ONLY ablation (results are WRONG): bit 0 skips the forward BatchNorm apply launches of bn1 / bn2 (no residual),
         # bit 1 their backward apply launches -- the upper bound of what fusing those passes into the consuming / producing
         # convolutions could save (profiles/r03_bn_fusion_bound.md)
+        # training forward: bn2 + ReLU applied inside conv3's operand path (creid_conv1x1_bnrelu_fwd) for the bottlenecks whose
+        # width (conv3's input channels, 64 or 128) is listed here -- the stand-alone apply pass of bn2 disappears; "" = never.
+        # Measured (profiles/r06_bn_apply_in_conv3.md): layer2 (128) gains ~8 us per block, layer1 (64) loses ~3 us per block
+        self.c3_axf = {int(v) for v in os.environ.get("CREID_C3_AXF", "128").split(",") if v.strip()}
         self.ds_reduce2 = os.environ.get("CREID_DS_REDUCE2", "1") == "1"
         self.dual_apply = os.environ.get("CREID_DUAL_APPLY", "1") == "1"     # A/B knob: 0 = separate downsample-BN apply launch
         # training forward: BatchNorm finalize + apply as ONE launch on layers with at most this many statistic rows (M <= 8192 by
@@ -571,6 +575,22 @@ class BackboneEngine:
                 "conv2d_fwd")
         return (x,) + self._bn_tail(u, x, part, rows, M, training, relu, residual, residual_ss, apply) + (oh, ow)
 
+    def _conv3_axf(self, u, x_raw, ss, B, H, W, residual, residual_ss):
+        """conv3 of a bottleneck on conv2's RAW output: bn2 + ReLU on the operand path, the normalised tensor and its ReLU bits as
+        side outputs (what the backward reads), then bn3 as usual.  Returns (x3, a2, a3, mean3, invstd3, oh, ow)."""
+        lib, st = L.lib(), L.stream()
+        d, oh, ow = _desc(B, H, W, u.cin, u.cout, 1, 1, 0)
+        M = B * oh * ow
+        x = self._empty(M, u.cout)
+        rows = lib.creid_conv2d_bn_partial_rows(C.byref(d))
+        part = self._empty(rows * 2, u.cout, dtype=torch.float32)
+        a_in = self._empty(M, u.cin)
+        mask = torch.empty(M * u.cin // 8, dtype=torch.uint8, device=self.device)
+        L.check(lib.creid_conv1x1_bnrelu_fwd(L.ptr(x_raw), L.ptr(ss), L.ptr(u.w_krsc), M, u.cin, u.cout, L.ptr(x), L.ptr(part),
+                                             L.ptr(a_in), L.ptr(mask), self.dt, st), "conv1x1_bnrelu_fwd")
+        a_in._relu_mask = mask
+        return (x, a_in) + self._bn_tail(u, x, part, rows, M, True, True, residual, residual_ss, True) + (oh, ow)
+
     def _ibn_tail(self, u, x, B, HW, training, relu, part=None):
         lib, st = L.lib(), L.stream()
         ibn, bn = u.ibn, u.bn
@@ -711,7 +731,12 @@ class BackboneEngine:
         for b in self.blocks:
             a_in, hin, win = a, h, w
             x1, a1, m1, i1, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, training, True)
-            x2, a2, m2, i2, h2, w2 = self._conv_bn(b["c2"], a1, B, h1, w1, training, True)
+            axf = (training and self.dtype != torch.float32 and self.relu_bitmask and not self._apply_dry and b["c3"].k == 1
+                   and b["c3"].stride == 1 and b["c3"].cin in self.c3_axf and b["c3"].cin in (64, 128) and b["c2"].ibn is None)
+            if axf:      # conv2 + statistics only: bn2's (scale, shift) go to conv3, which normalises its operand itself
+                x2, ss2, m2, i2, h2, w2 = self._conv_bn(b["c2"], a1, B, h1, w1, training, True, apply=False)
+            else:
+                x2, a2, m2, i2, h2, w2 = self._conv_bn(b["c2"], a1, B, h1, w1, training, True)
             rss = None
             if b["ds"] is not None and self.dual_apply:
                 # downsample branch: conv + statistics only; its normalisation rides in bn3's apply pass (one launch and
@@ -722,7 +747,10 @@ class BackboneEngine:
                 xd, r, md, idd, _, _ = self._conv_bn(b["ds"], a_in, B, hin, win, training, False)
             else:
                 xd, r, md, idd = None, a_in, None, None
-            x3, a3, m3, i3, h3, w3 = self._conv_bn(b["c3"], a2, B, h2, w2, training, True, residual=r, residual_ss=rss)
+            if axf:
+                x3, a2, a3, m3, i3, h3, w3 = self._conv3_axf(b["c3"], x2, ss2, B, h2, w2, r, rss)
+            else:
+                x3, a3, m3, i3, h3, w3 = self._conv_bn(b["c3"], a2, B, h2, w2, training, True, residual=r, residual_ss=rss)
             if training:
                 sv["blocks"].append(dict(a_in=a_in, hin=hin, win=win, x1=x1, a1=a1, m1=m1, i1=i1, h1=h1, w1=w1,
                                          x2=x2, a2=a2, m2=m2, i2=i2, h2=h2, w2=w2, xd=xd, md=md, idd=idd,

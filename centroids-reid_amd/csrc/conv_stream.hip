@@ -257,14 +257,44 @@ int launch_stream1x1(int M, int K, int N, const void* src, const void* wgt, void
 //     with the block's residual added in the copy-out (the arithmetic of igemm_bf16_ws_kernel: identical bits).
 // K = 64 / 128 / 256 (KCH = 1, 2, 4); BN = 64 / 128 / 256 columns per workgroup; RT = 2 ring slots, or 1 where LDS allows no more
 // (K = 256 with 64-column slabs, K = 128 with 256-column slabs): the tile is then written into the slot between two barriers.
-template <int BN, int KCH, int RT, typename ET = Bf16T>
+// AXF (round 6, creid_conv1x1_bnrelu_fwd): the A operand is the RAW output of the previous convolution and its BatchNorm + ReLU
+// (y = max(x * scale[c] + shift[c], 0), the arithmetic of bn2d_apply_kernel) is applied on the way from the load registers to
+// the LDS ring -- conv3 of a Bottleneck consuming conv2's raw output (modelling/backbones/resnet.py:73-78): the stand-alone
+// apply pass (one read + one write of the tensor and a dependent launch) disappears.  The normalised tensor and its ReLU bits
+// are still written once (the weight gradient and the BatchNorm backward read them), by the column-slab-0 workgroups, from the
+// registers that feed the ring: same values, same bits as the apply kernel's.  A thread's channels are fixed (k-chunk kc,
+// 16-byte chunk lcp): their (scale, shift) live in registers for the whole launch.
+struct AXform {
+  const float* scale_shift;            // [2][K]
+  unsigned short* a_out;               // [M][K] normalised + ReLU, 16-bit
+  uint8_t* mask_out;                   // [M * K / 8] ReLU bits
+};
+
+template <typename ET>
+__device__ __forceinline__ uint4 axf_chunk(uint4 v, const float (&sc)[8], const float (&sh)[8], unsigned& bits) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  unsigned o[4];
+  bits = 0u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float lo = fmaf(ET::lo(w[q]), sc[2 * q], sh[2 * q]) + 0.f;          // (+ 0.f: bn2d_apply_kernel's "+ residual" slot)
+    float hi = fmaf(ET::hi(w[q]), sc[2 * q + 1], sh[2 * q + 1]) + 0.f;
+    lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f);
+    bits |= (lo > 0.f ? 1u : 0u) << (2 * q);
+    bits |= (hi > 0.f ? 1u : 0u) << (2 * q + 1);
+    o[q] = ET::pack2(lo, hi);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+template <int BN, int KCH, int RT, typename ET = Bf16T, bool AXF = false>
 __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned short* __restrict__ src, int M, int K, int N,
                                                                    const unsigned short* __restrict__ wgt,
                                                                    unsigned short* __restrict__ out, float* __restrict__ bn_part,
                                                                    const unsigned short* __restrict__ add_src,
                                                                    const float* __restrict__ epi_scale,
                                                                    const float* __restrict__ epi_shift, int epi_relu,
-                                                                   int tiles_m, int tiles_n, int abl) {
+                                                                   int tiles_m, int tiles_n, int abl, AXform xf = AXform{nullptr, nullptr, nullptr}) {
   constexpr int TW = BN / 64;                          // 32-column blocks per wave
   constexpr int HB = BN > 128 ? 128 : BN;              // columns staged / copied out at a time
   constexpr int NH = BN / HB;
@@ -317,16 +347,59 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
         areg[kc][u] = m < M ? v : make_uint4(0u, 0u, 0u, 0u);
       }
   };
+  // AXF: this thread's channels are kc * 64 + lcp * 8 .. + 7 for every tile
+  float xsc[AXF ? KCH : 1][8], xsh[AXF ? KCH : 1][8];
+  uint4 sreg[AXF ? KCH : 1][2];                                   // transformed chunks waiting for their global store
+  unsigned smk[AXF ? KCH : 1][2];
+  const bool side = AXF && xf.a_out != nullptr && tile_n == 0;
+  if constexpr (AXF) {
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+      for (int k = 0; k < 8; k += 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(xf.scale_shift + kc * 64 + lcp * 8 + k);
+        const float4 b4 = *reinterpret_cast<const float4*>(xf.scale_shift + K + kc * 64 + lcp * 8 + k);
+        xsc[kc][k] = a4.x; xsc[kc][k + 1] = a4.y; xsc[kc][k + 2] = a4.z; xsc[kc][k + 3] = a4.w;
+        xsh[kc][k] = b4.x; xsh[kc][k + 1] = b4.y; xsh[kc][k + 2] = b4.z; xsh[kc][k + 3] = b4.w;
+      }
+  }
   // ... and from there into ring slot it % RT (same LDS image as the DMA kernels)
   auto put_a = [&](int it) {
     unsigned short* slot = ring + (it % RT) * TILE_ELEMS;
+    const int row0 = (wg_in_group + it * groups) * 128;
 #pragma unroll
     for (int kc = 0; kc < KCH; ++kc)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int r = (wave + 8 * u) * 8 + lr8;
-        *reinterpret_cast<uint4*>(slot + kc * (128 * 64) + r * 64 + ((lcp ^ ((r >> 1) & 7)) << 3)) = areg[kc][u];
+        uint4 v = areg[kc][u];
+        if constexpr (AXF) {
+          unsigned bits;
+          const uint4 t = axf_chunk<ET>(v, xsc[kc], xsh[kc], bits);
+          v = row0 + r < M ? t : make_uint4(0u, 0u, 0u, 0u);       // rows past M stay zero rows (relu(shift) is not zero)
+          sreg[kc][u] = v; smk[kc][u] = bits;
+        }
+        *reinterpret_cast<uint4*>(slot + kc * (128 * 64) + r * 64 + ((lcp ^ ((r >> 1) & 7)) << 3)) = v;
       }
+  };
+  // the normalised tile (and its ReLU bits) leave from the same registers, issued where the finished output chunks are stored
+  auto side_store = [&](int it) {
+    if constexpr (AXF) {
+      if (side) {
+        const int row0 = (wg_in_group + it * groups) * 128;
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int m = row0 + (wave + 8 * u) * 8 + lr8;
+            if (m < M) {
+              const int64_t e = (int64_t)m * K + kc * 64 + lcp * 8;
+              *reinterpret_cast<uint4*>(xf.a_out + e) = sreg[kc][u];
+              xf.mask_out[e >> 3] = (uint8_t)smk[kc][u];
+            }
+          }
+      }
+    }
   };
   // copy-out map of one half (see igemm_bf16_ws_kernel): lane = 16 g4 + 4 q4 + t4 owns row t4 of a row quad, one column octet
   const int t4 = lane & 3, q4 = (lane >> 2) & 3, g4 = lane >> 4;
@@ -366,6 +439,7 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
   load_a(0);
   if constexpr (RT == 2) {
     put_a(0);                                                     // tile 0 is in the ring before the first barrier
+    side_store(0);
     if (n_iter > 1) load_a(1);
   }
   if (add_src) load_res(0);
@@ -401,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void igemm1x1_stream2_kernel(const unsigned
     if (it + RT < n_iter) load_a(it + RT);
     if (add_src && it + 1 < n_iter) load_res(it + 1);
     if (it > 0) store_out(it - 1);
+    if constexpr (RT == 2) { if (it + 1 < n_iter) side_store(it + 1); } else side_store(it);
     if constexpr (RT == 1) __syncthreads();                       // the slot holds tile `it`
     f32x16 acc[TW];
 #pragma unroll
@@ -539,6 +614,52 @@ int launch_stream2(int M, int K, int N, const void* src, const void* wgt, void* 
 #undef CREID_ST2_LAUNCH
 #undef CREID_ST2_LAUNCH1
   return (int)hipGetLastError();
+}
+
+// creid_conv1x1_bnrelu_fwd: the training forward of a 1 x 1 stride-1 convolution whose input is still RAW (BatchNorm + ReLU applied
+// on the operand path, the normalised tensor and its ReLU bits written as side outputs) -- see AXform above.
+static int launch_stream2_axf(int M, int K, int N, const void* src, const void* wgt, void* out, float* bn_part, AXform xf, int dtype,
+                              hipStream_t s) {
+  // K = 64 / 128 (layer1 / layer2 bottlenecks).  The transform's registers (16 coefficients and 10 pending-store registers per
+  // k-chunk) do not fit beside the 256-column accumulators at K = 128, nor beside four k-chunks at K = 256: those shapes take
+  // 128-column slabs / are refused (the caller keeps the stand-alone apply pass) rather than spill.
+  if (K != 64 && K != 128) return CREID_E_SHAPE;
+  int bn = N >= 256 ? 256 : N;
+  if (K == 128 && bn > 128) bn = 128;
+  if (bn != 64 && bn != 128 && bn != 256) return CREID_E_SHAPE;
+  if (N % bn != 0) return CREID_E_SHAPE;
+  { const char* e = CREID_KNOB_ENV("CREID_STREAM2_BN"); const int v = e ? atoi(e) : 0; if ((v == 64 || v == 128) && v < bn && N % v == 0) bn = v; }
+  const int tiles_m = (M + 127) / 128, tiles_n = N / bn;
+  int wgs = 256;
+  { const char* e = CREID_KNOB_ENV("CREID_STREAM1X1_WGS"); const int v = e ? atoi(e) : 0; if (v > 0) wgs = v; }
+  int groups = wgs / tiles_n;
+  if (groups < 1) groups = 1;
+  if (groups > tiles_m) groups = tiles_m;
+  const dim3 grid((unsigned)(groups * tiles_n)), block(512);
+#define CREID_AXF_LAUNCH1(BN_, KCH_, RT_, ET_)                                                                          \
+  hipLaunchKernelGGL((igemm1x1_stream2_kernel<BN_, KCH_, RT_, ET_, true>), grid, block, 0, s, (const unsigned short*)src, M, K, N, \
+                     (const unsigned short*)wgt, (unsigned short*)out, bn_part, (const unsigned short*)nullptr, (const float*)nullptr, \
+                     (const float*)nullptr, 0, tiles_m, tiles_n, 0, xf)
+#define CREID_AXF_LAUNCH(BN_, KCH_, RT_) \
+  do { if (dtype == CREID_F16) CREID_AXF_LAUNCH1(BN_, KCH_, RT_, F16T); else CREID_AXF_LAUNCH1(BN_, KCH_, RT_, Bf16T); } while (0)
+  if (K == 64) {
+    if (bn == 256) CREID_AXF_LAUNCH(256, 1, 2); else if (bn == 128) CREID_AXF_LAUNCH(128, 1, 2); else CREID_AXF_LAUNCH(64, 1, 2);
+  } else {
+    if (bn == 128) CREID_AXF_LAUNCH(128, 2, 2); else CREID_AXF_LAUNCH(64, 2, 2);
+  }
+#undef CREID_AXF_LAUNCH
+#undef CREID_AXF_LAUNCH1
+  return (int)hipGetLastError();
+}
+
+extern "C" int creid_conv1x1_bnrelu_fwd(const void* x_raw, const float* scale_shift, const void* w_krsc, int64_t M, int64_t K,
+                                        int64_t N, void* y, float* bn_partial, void* a_out, uint8_t* mask_out, int dtype,
+                                        void* stream) {
+  CREID_CHECK_ARG(x_raw && scale_shift && w_krsc && y && M > 0 && K > 0 && N > 0 && ((a_out == nullptr) == (mask_out == nullptr)));
+  if (!creid_is16(dtype)) return CREID_E_DTYPE;
+  if (M > 0x7fffffff) return CREID_E_SHAPE;
+  return launch_stream2_axf((int)M, (int)K, (int)N, x_raw, w_krsc, y, bn_partial, AXform{scale_shift, (unsigned short*)a_out, mask_out},
+                            dtype, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------ 3 x 3, 64 -> 64 (round 4)

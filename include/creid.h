@@ -432,6 +432,14 @@ int creid_conv2d_fwd_nhwc(const creid_conv_desc* d, const void* x, const void* w
  * passes (fp32 mode: bit-identical; bf16 mode: the conv output is rounded once, after the affine, instead of twice). */
 int creid_conv2d_fwd_affine_nhwc(const creid_conv_desc* d, const void* x, const void* w_krsc, void* y,
                                  const float* scale_shift, const void* residual, int relu, int dtype, void* stream);
+/* Training forward of a 1 x 1 stride-1 convolution whose INPUT is still the raw output of the previous convolution: that layer's
+ * training-mode BatchNorm + ReLU (scale_shift [2][K] from creid_bn2d_finalize: a = max(x * scale + shift, 0), the arithmetic of
+ * creid_bn2d_apply_mask) is applied on the operand path -- conv3 of a Bottleneck consuming conv2's raw output
+ * (modelling/backbones/resnet.py:73-78) without the stand-alone apply pass.  y [M, N] (+ bn_partial like creid_conv2d_fwd_nhwc);
+ * a_out [M, K] and mask_out [M * K / 8] (both or neither): the normalised tensor and its ReLU bits, bit-identical to
+ * creid_bn2d_apply_mask's (the backward reads them).  16-bit dtypes, K in {64, 128}, N % 64 == 0; else CREID_E_SHAPE. */
+int creid_conv1x1_bnrelu_fwd(const void* x_raw, const float* scale_shift, const void* w_krsc, int64_t M, int64_t K, int64_t N,
+                             void* y, float* bn_partial, void* a_out, uint8_t* mask_out, int dtype, void* stream);
 /* Folds MANY BatchNorm layers in one launch.  table_dev = device array of n_entries records { const float* gamma (nullable);
  * const float* beta (nullable); const float* running_mean; const float* running_var; float* out (float[2][C]); int32 C;
  * float eps } (48 bytes, creid_bn2d_fold_entry_bytes()). */

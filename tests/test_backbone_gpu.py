@@ -904,3 +904,38 @@ def test_downsample_bn_column_sums_in_bn3_apply_pass_are_bit_identical(arch, dty
     assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 150
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+@pytest.mark.parametrize("arch,dtype,hw", [("resnet50", torch.bfloat16, (128, 64)), ("resnet50", torch.float16, (128, 64)),
+                                           ("resnet50_ibn_a", torch.bfloat16, (64, 64)), ("resnet50", torch.bfloat16, (72, 40))])
+def test_bn2_relu_inside_conv3_operand_path_is_bit_identical(arch, dtype, hw, monkeypatch):
+    """Round 6: conv3 of a bottleneck reads conv2's RAW output and applies bn2 + ReLU on its operand path
+    (creid_conv1x1_bnrelu_fwd); the normalised tensor and its ReLU bits are side outputs.  Against the schedule with the
+    stand-alone apply pass, on the same convolution kernel (CREID_STREAM2=1 routes the unfused conv3 to the persistent 1 x 1
+    kernel too: same accumulation and statistics grouping), the embeddings, the BatchNorm statistics and EVERY parameter gradient
+    must be equal bit for bit -- also with ragged row tiles (72 x 40: M % 128 != 0)."""
+    from oracle import backbone_oracle as bo
+    monkeypatch.setenv("CREID_STREAM2", "1")
+    H, W = hw
+    x = bo.synthetic_images(6, H, W, seed=23).cuda()
+    coef = torch.from_numpy(np.random.default_rng(6).standard_normal((6, 2048)).astype(np.float32)).cuda()
+    res = []
+    for widths in ({64, 128}, set()):
+        net, eng, _ = _build(arch, dtype, seed=98)
+        eng.c3_axf = widths
+        eng.loss_scaler = None
+        _, f = eng.forward(x, training=True)
+        saved_masks = [blk["a2"]._relu_mask.clone() for blk in eng.saved["blocks"]]
+        saved_a2 = [blk["a2"].clone() for blk in eng.saved["blocks"]]
+        eng.backward(coef)
+        res.append((f.clone(), saved_a2, saved_masks, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                    net.layer2[1].bn3.running_var.clone()))
+    (f1, a1, m1, g1, rv1), (f0, a0, m0, g0, rv0) = res
+    for i, (p, q) in enumerate(zip(a1, a0)):
+        assert torch.equal(p, q), f"a2 of block {i}"
+    for i, (p, q) in enumerate(zip(m1, m0)):
+        assert torch.equal(p, q), f"ReLU bits of block {i}"
+    assert torch.equal(f1, f0) and torch.equal(rv1, rv0)
+    assert set(g1) == set(g0)
+    for n in g0:
+        assert torch.equal(g1[n], g0[n]), n
