@@ -178,7 +178,7 @@ def forward_flops(B, H, W, arch="resnet50"):
 
 
 _GROUPS = [("igemm", r"igemm|conv3x3_c64|stem_pool|c3_c1_kernel"), ("wgrad", r"wgrad_bf16|wgrad_f32|wgrad_reduce"), ("bn", r"bn2d_|ibn_|bn_apply|bn_bwd|bn_fold|col_stats"),
-           ("heads", r"triplet|center_|xent|bn1d|loo_|gemm_f32|ctl_step|scale_matrix"), ("optim", r"adam|sgd_scaled|amp_"),
+           ("heads", r"heads_stage|triplet|center_|xent|bn1d|loo_|gemm_f32|ctl_step|scale_matrix"), ("optim", r"adam|sgd_scaled|amp_"),
            ("pool_layout", r"maxpool|gap_|weight_prep|image_pad|nhwc")]
 
 

@@ -4,11 +4,11 @@ import re
 import sqlite3
 import sys
 
-GROUPS = [("conv fwd + dgrad (igemm)", r"igemm_|conv3x3_c64|stem_pool|c3_c1_kernel"), ("conv wgrad", r"wgrad_bf16|wgrad_f32"), ("wgrad split reduce", r"wgrad_reduce"),
+GROUPS = [("conv fwd + dgrad (igemm)", r"igemm_|igemm1x1_|conv3x3_c64|stem_pool|c3_c1_kernel"), ("conv wgrad", r"wgrad_bf16|wgrad_f32"), ("wgrad split reduce", r"wgrad_reduce"),
           ("BN backward apply", r"bn2d_bwd_apply|ibn_bwd_apply"), ("BN apply (incl. finalize + apply in one launch)", r"bn2d_apply|ibn_apply|bn2d_fin_apply"),
           ("BN finalize (fwd+bwd)", r"finalize"), ("BN reduce (unfused)", r"bwd_reduce|col_stats"),
           ("optimisers", r"adam|sgd_scaled|amp_"), ("pool / gap", r"maxpool|gap_"), ("layout", r"weight_prep|image_pad|nhwc"),
-          ("heads", r"triplet|center_|xent|bn1d|loo_|gemm_f32|mean_rows")]
+          ("heads", r"heads_stage|triplet|center_|xent|bn1d|loo_|gemm_f32|mean_rows|ctl_step")]
 
 
 def main(path):

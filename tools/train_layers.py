@@ -12,7 +12,7 @@ import sys
 sys.path.insert(0, ".")
 from centroids_reid_amd.bench_train import conv_shapes, conv_launch_work, conv_step_sol   # noqa: E402
 
-IS_CONV = re.compile(r"igemm_|conv3x3_c64")
+IS_CONV = re.compile(r"igemm_|igemm1x1_|conv3x3_c64")
 IS_WGRAD = re.compile(r"wgrad_bf16_dma_kernel|wgrad_f32|stem_wgrad|wgrad_bf16_kernel")
 
 
