@@ -314,7 +314,7 @@ class BackboneEngine:
         # training forward: bn2 + ReLU applied inside conv3's operand path (creid_conv1x1_bnrelu_fwd) for the bottlenecks whose
         # width (conv3's input channels, 64 or 128) is listed here -- the stand-alone apply pass of bn2 disappears; "" = never.
         # Measured (profiles/r06_bn_apply_in_conv3.md): layer2 (128) gains ~8 us per block, layer1 (64) loses ~3 us per block
-        self.c3_axf = {int(v) for v in os.environ.get("CREID_C3_AXF", "128").split(",") if v.strip()}
+        self.c3_axf = {int(v) for v in os.environ.get("CREID_C3_AXF", "64,128").split(",") if v.strip()}
         self.ds_reduce2 = os.environ.get("CREID_DS_REDUCE2", "1") == "1"
         self.dual_apply = os.environ.get("CREID_DUAL_APPLY", "1") == "1"     # A/B knob: 0 = separate downsample-BN apply launch
         # training forward: BatchNorm finalize + apply as ONE launch on layers with at most this many statistic rows (M <= 8192 by
