@@ -60,6 +60,20 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
 
+class BasicBlock(nn.Module):
+    """modelling/backbones/resnet.py:22-48 (resnet18 / resnet34): conv3x3(stride) - bn - relu - conv3x3 - bn, + residual, relu."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 3, stride, 1)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3, 1, 1)
+        self.bn2 = BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
 class ResNet(nn.Module):
     """Parameter tree of modelling/backbones/resnet.py:90-120 (Bottleneck, layers [3,4,6,3])."""
     arch = "resnet50"
@@ -74,6 +88,7 @@ class ResNet(nn.Module):
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
         self.layer4 = self._make_layer(block, 512, layers[3], stride=last_stride)
+        self.out_channels = 512 * block.expansion          # Baseline.in_planes: 2048, or 512 for the BasicBlock networks
 
     def _make_layer(self, block, planes, blocks, stride=1):
         downsample = None
@@ -160,6 +175,7 @@ class ResNet_IBN(ResNet):
         self.layer2 = self._make_ibn_layer(128, layers[1], stride=2)
         self.layer3 = self._make_ibn_layer(256, layers[2], stride=2)
         self.layer4 = self._make_ibn_layer(512, layers[3], stride=last_stride)
+        self.out_channels = 2048
         self.fc = _UnusedFC(512 * 4, num_classes)
 
     def _make_ibn_layer(self, planes, blocks, stride=1):
@@ -192,15 +208,18 @@ def resnet50_ibn_a(last_stride, **kwargs):
 # the deeper Bottleneck variants of MODEL.NAME (modelling/baseline.py:73-81, resnet_ibn_a.py:173-181): same kernels, same
 # engine, other block counts (the engine walks whatever blocks the parameter tree holds)
 ARCH_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3),
-               "resnet50_ibn_a": (3, 4, 6, 3), "resnet101_ibn_a": (3, 4, 23, 3)}
+               "resnet50_ibn_a": (3, 4, 6, 3), "resnet101_ibn_a": (3, 4, 23, 3),
+               "resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}          # BasicBlock networks (modelling/baseline.py:56-65), round 6
 
 
 def build_backbone(arch, last_stride):
     if arch not in ARCH_LAYERS:
-        raise NotImplementedError(f"MODEL.NAME={arch!r}: the accelerated path covers the Bottleneck ResNets {sorted(ARCH_LAYERS)} "
-                                  "(resnet18 / resnet34 are BasicBlock networks: no kernels for them here)")
+        raise NotImplementedError(f"MODEL.NAME={arch!r}: the reference's Baseline knows {sorted(ARCH_LAYERS)} (modelling/baseline.py:56-81)")
     layers = ARCH_LAYERS[arch]
-    net = ResNet_IBN(last_stride, layers) if arch.endswith("_ibn_a") else ResNet(last_stride, layers=layers)
+    if arch.endswith("_ibn_a"):
+        net = ResNet_IBN(last_stride, layers)
+    else:
+        net = ResNet(last_stride, block=BasicBlock if arch in ("resnet18", "resnet34") else Bottleneck, layers=layers)
     net.arch = arch
     return net
 
@@ -236,10 +255,14 @@ class BackboneEngine:
         self.units = []
         self.stem = _ConvUnit(net.conv1, net.bn1)
         self.blocks = []
+        # BasicBlock networks (resnet18 / resnet34, round 6): two 3 x 3 convolutions per block, no c3 -- the same kernels on a
+        # plain schedule (_forward_basic / _backward_basic: none of the bottleneck-specific carriers and fusions)
+        self.basic = isinstance(net.layer1[0], BasicBlock)
+        self.cout = int(getattr(net, "out_channels", 2048))
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             for blk in layer:
                 u = dict(c1=_ConvUnit(blk.conv1, blk.bn1), c2=_ConvUnit(blk.conv2, blk.bn2),
-                         c3=_ConvUnit(blk.conv3, blk.bn3),
+                         c3=None if self.basic else _ConvUnit(blk.conv3, blk.bn3),
                          ds=_ConvUnit(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None)
                 self.blocks.append(u)
         self.weights_dirty = True      # set by writers torch cannot see (our ctypes optimiser kernels)
@@ -499,6 +522,11 @@ class BackboneEngine:
         a1_next = None                    # conv1 output of the CURRENT block when the previous block's conv3 launch produced it
         for bi, b in enumerate(self.blocks):
             a_in, hin, win = a, h, w
+            if self.basic:                # resnet.py:33-48: two folded 3 x 3 convolutions, the residual added in the second one's epilogue
+                a1, h1, w1 = self._conv_fold(b["c1"], a_in, B, hin, win, True)
+                r = a_in if b["ds"] is None else self._conv_fold(b["ds"], a_in, B, hin, win, False)[0]
+                a, h, w = self._conv_fold(b["c2"], a1, B, h1, w1, True, residual=r)
+                continue
             side = b["ds"] is not None and self.eval_ds_side
             if side:
                 # the downsample convolution depends on the block input only: it runs on a side stream (a parallel branch of a
@@ -543,13 +571,13 @@ class BackboneEngine:
                 h, w = h2, w2
             else:
                 a, h, w = self._conv_fold(b["c3"], a2, B, h2, w2, True, residual=r)
-        feat = self._empty(B, 2048, dtype=torch.float32)
-        L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), st), "gap_fwd")
+        feat = self._empty(B, self.cout, dtype=torch.float32)
+        L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, self.cout, self.dt, L.ptr(feat), st), "gap_fwd")
         self.saved = None
         base_out = None
         if want_base_out:
-            base_out = self._empty(B, 2048, h, w, dtype=torch.float32)
-            L.check(lib.creid_nhwc_to_nchw_f32(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(base_out), st), "nhwc_to_nchw")
+            base_out = self._empty(B, self.cout, h, w, dtype=torch.float32)
+            L.check(lib.creid_nhwc_to_nchw_f32(L.ptr(a), B, h * w, self.cout, self.dt, L.ptr(base_out), st), "nhwc_to_nchw")
         return base_out, feat
 
     def _conv_bn(self, u, a_in, B, H, W, training, relu, residual=None, residual_ss=None, apply=True):
@@ -730,6 +758,21 @@ class BackboneEngine:
             self._join_side()                                  # the non-stem weight copies (a graph branch beside the stem)
         for b in self.blocks:
             a_in, hin, win = a, h, w
+            if self.basic:
+                # BasicBlock (resnet.py:33-48): conv1 -> bn1 -> relu -> conv2 -> bn2 (+ residual, through the downsample branch's
+                # BatchNorm where there is one: applied inside bn2's pass like the bottleneck's bn3) -> relu
+                x1, a1, m1, i1, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, training, True)
+                xd = md = idd = rss = None
+                r = a_in
+                if b["ds"] is not None:
+                    xd, rss, md, idd, _, _ = self._conv_bn(b["ds"], a_in, B, hin, win, training, False, apply=False)
+                    r = xd
+                x2, a2, m2, i2, h2, w2 = self._conv_bn(b["c2"], a1, B, h1, w1, training, True, residual=r, residual_ss=rss)
+                if training:
+                    sv["blocks"].append(dict(a_in=a_in, hin=hin, win=win, x1=x1, a1=a1, m1=m1, i1=i1, h1=h1, w1=w1,
+                                             x2=x2, a2=a2, m2=m2, i2=i2, h2=h2, w2=w2, xd=xd, md=md, idd=idd))
+                a, h, w = a2, h2, w2
+                continue
             x1, a1, m1, i1, h1, w1 = self._conv_bn(b["c1"], a_in, B, hin, win, training, True)
             axf = (training and self.dtype != torch.float32 and self.relu_bitmask and not self._apply_dry and b["c3"].k == 1
                    and b["c3"].stride == 1 and b["c3"].cin in self.c3_axf and b["c3"].cin in (64, 128) and b["c2"].ibn is None)
@@ -756,17 +799,17 @@ class BackboneEngine:
                                          x2=x2, a2=a2, m2=m2, i2=i2, h2=h2, w2=w2, xd=xd, md=md, idd=idd,
                                          x3=x3, a3=a3, m3=m3, i3=i3))
             a, h, w = a3, h3, w3
-        feat = self._empty(B, 2048, dtype=torch.float32)
+        feat = self._empty(B, self.cout, dtype=torch.float32)
         if training:
-            L.check(lib.creid_gap_fwd_count(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), L.ptr(self._pending_steps), st), "gap_fwd")
+            L.check(lib.creid_gap_fwd_count(L.ptr(a), B, h * w, self.cout, self.dt, L.ptr(feat), L.ptr(self._pending_steps), st), "gap_fwd")
         else:
-            L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(feat), st), "gap_fwd")
+            L.check(lib.creid_gap_fwd(L.ptr(a), B, h * w, self.cout, self.dt, L.ptr(feat), st), "gap_fwd")
         sv["final"] = (h, w)
         self.saved = sv if training else None
         base_out = None
         if want_base_out:
-            base_out = self._empty(B, 2048, h, w, dtype=torch.float32)
-            L.check(lib.creid_nhwc_to_nchw_f32(L.ptr(a), B, h * w, 2048, self.dt, L.ptr(base_out), st), "nhwc_to_nchw")
+            base_out = self._empty(B, self.cout, h, w, dtype=torch.float32)
+            L.check(lib.creid_nhwc_to_nchw_f32(L.ptr(a), B, h * w, self.cout, self.dt, L.ptr(base_out), st), "nhwc_to_nchw")
         return base_out, feat
 
     # ---- backward
@@ -913,7 +956,7 @@ class BackboneEngine:
         while it writes g: (x3, ReLU bits of the block output, mean, invstd, partial-rows buffer), or None when that reduction
         keeps its own launch (fp32 engine, no mask bits, 128-row tiles that straddle images in the general case are fine)."""
         sv = self.saved
-        if sv is None or not sv.get("training") or not (self.fuse_bn_reduce and self.drop_gm and self.relu_bitmask):
+        if self.basic or sv is None or not sv.get("training") or not (self.fuse_bn_reduce and self.drop_gm and self.relu_bitmask):
             return None
         if os.environ.get("CREID_HEADS_BNRED", "1") != "1":
             return None
@@ -942,11 +985,14 @@ class BackboneEngine:
             dfeat = dfeat.contiguous().float()
             if self.loss_scaler is not None and self.dtype == torch.float16:
                 dfeat = self.loss_scaler.scale_(dfeat)        # every f16 gradient tensor / backbone parameter gradient below is scaled
-            g = self._empty(B * h * w, 2048)
-            L.check(lib.creid_gap_bwd(L.ptr(dfeat), B, h * w, 2048, self.dt, L.ptr(g), st), "gap_bwd")
+            g = self._empty(B * h * w, self.cout)
+            L.check(lib.creid_gap_bwd(L.ptr(dfeat), B, h * w, self.cout, self.dt, L.ptr(g), st), "gap_bwd")
         else:
-            assert g.dtype == self.dtype and tuple(g.shape) == (B * h * w, 2048) and g.is_contiguous()
+            assert g.dtype == self.dtype and tuple(g.shape) == (B * h * w, self.cout) and g.is_contiguous()
         blocks = list(zip(self.blocks, sv["blocks"]))
+        if self.basic:
+            g = self._backward_basic(blocks, g, B)
+            blocks = []
         # part3: bn3 partials of the CURRENT block, produced by the previous (deeper) block -- for the deepest block by the heads'
         # last launch when the caller hands them in (first_bn_bwd_operands)
         for bi in range(len(blocks) - 1, -1, -1):
@@ -1057,6 +1103,32 @@ class BackboneEngine:
         self._flush_wred()
         self._join_side()
         self.saved = None
+
+    def _backward_basic(self, blocks, g, B):
+        """Backward of the BasicBlock networks (resnet18 / resnet34), block by block in reverse: bn2 backward (it also writes the
+        ReLU-masked gradient the shortcut needs), conv2's weight and data gradient, bn1 backward, conv1's weight gradient, the
+        downsample branch (BatchNorm backward, weight gradient, data gradient) and conv1's data gradient with the shortcut's
+        gradient added in its epilogue.  Plain launches of the same kernels as the bottleneck schedule; split reductions of the
+        weight gradients ride in the following data gradients as there.  Returns the gradient w.r.t. the max-pool output."""
+        for bi in range(len(blocks) - 1, -1, -1):
+            b, s = blocks[bi]
+            M2 = B * s["h2"] * s["w2"]
+            dx2, gm = self._bn_bwd(b["c2"], s["x2"], g, s["a2"], s["m2"], s["i2"], M2, want_gm=True)
+            self._wgrad(b["c2"], s["a1"], dx2, B, s["h1"], s["w1"])
+            da1, _ = self._dgrad(b["c2"], dx2, B, s["h1"], s["w1"])
+            dx1, _ = self._bn_bwd(b["c1"], s["x1"], da1, s["a1"], s["m1"], s["i1"], B * s["h1"] * s["w1"])
+            self._wgrad(b["c1"], s["a_in"], dx1, B, s["hin"], s["win"])
+            if b["ds"] is not None:
+                dxd, _ = self._bn_bwd(b["ds"], s["xd"], gm, None, s["md"], s["idd"], M2)
+                self._wgrad(b["ds"], s["a_in"], dxd, B, s["hin"], s["win"])
+                short, _ = self._dgrad(b["ds"], dxd, B, s["hin"], s["win"])
+            else:
+                short = gm
+            g, _ = self._dgrad(b["c1"], dx1, B, s["hin"], s["win"], add_src=short)
+            if self.on_group_done is not None and bi in self._group_first:
+                self._flush_wred()
+                self.on_group_done(self._group_first[bi])
+        return g
 
     def _flush_wred(self):
         """Split reductions that found no data-gradient launch to ride on (the last one of the backward pass and, with a

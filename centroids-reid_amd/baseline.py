@@ -21,8 +21,9 @@ class Baseline(nn.Module):
         model_name = cfg.MODEL.NAME
         self.use_mixed_precision = cfg.USE_MIXED_PRECISION
         # modelling/baseline.py:56-81: resnet50 / 101 / 152 and resnet50_ibn_a / resnet101_ibn_a (Bottleneck networks, in_planes
-        # 2048); resnet18 / resnet34 (BasicBlock, in_planes 512) raise NotImplementedError
+        # 2048); resnet18 / resnet34 (BasicBlock, in_planes 512; round 6)
         self.base = bb.build_backbone(model_name, last_stride)
+        self.in_planes = self.base.out_channels
         self.model_name = model_name
         if cfg.MODEL.PRETRAINED and not cfg.MODEL.RESUME_TRAINING and not cfg.TEST.ONLY_TEST:
             self.base.load_param(cfg.MODEL.PRETRAIN_PATH)      # modelling/baseline.py:84-87

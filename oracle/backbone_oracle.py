@@ -20,7 +20,12 @@ LAYERS = (3, 4, 6, 3)
 PLANES = (64, 128, 256, 512)
 # modelling/baseline.py:65-81 (Bottleneck variants of MODEL.NAME) + resnet_ibn_a.py:164-190
 ARCH_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3),
-               "resnet50_ibn_a": (3, 4, 6, 3), "resnet101_ibn_a": (3, 4, 23, 3)}
+               "resnet50_ibn_a": (3, 4, 6, 3), "resnet101_ibn_a": (3, 4, 23, 3),
+               "resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}        # BasicBlock networks (modelling/baseline.py:56-65)
+
+
+def is_basic(arch: str) -> bool:
+    return arch in ("resnet18", "resnet34")
 
 
 def is_ibn(arch: str) -> bool:
@@ -34,13 +39,14 @@ def layer_strides(last_stride: int = 1):
 def arch_spec(arch: str = "resnet50", last_stride: int = 1):
     """List of (prefix, inplanes, planes, stride, has_downsample, ibn) for every bottleneck."""
     ibn_arch = is_ibn(arch)
+    exp = 1 if is_basic(arch) else 4                    # resnet.py:23,52 BasicBlock.expansion / Bottleneck.expansion
     spec, inpl = [], 64
     for li, (n, pl, st) in enumerate(zip(ARCH_LAYERS[arch], PLANES, layer_strides(last_stride))):
         for b in range(n):
             s = st if b == 0 else 1
-            ds = b == 0 and (s != 1 or inpl != pl * 4)
+            ds = b == 0 and (s != 1 or inpl != pl * exp)
             spec.append((f"layer{li + 1}.{b}", inpl, pl, s, ds, ibn_arch and pl != 512))
-            inpl = pl * 4
+            inpl = pl * exp
     return spec
 
 
@@ -73,6 +79,15 @@ def make_state_dict(arch: str = "resnet50", last_stride: int = 1, seed: int = 12
     conv("conv1", 64, 3, 7)
     bn("bn1", 64)
     for pre, inpl, pl, s, ds, ibn in arch_spec(arch, last_stride):
+        if is_basic(arch):                              # resnet.py:22-48: conv3x3(stride) - bn - relu - conv3x3 - bn (+ residual) - relu
+            conv(pre + ".conv1", pl, inpl, 3)
+            bn(pre + ".bn1", pl)
+            conv(pre + ".conv2", pl, pl, 3)
+            bn(pre + ".bn2", pl, gamma=0.5)
+            if ds:
+                conv(pre + ".downsample.0", pl, inpl, 1)
+                bn(pre + ".downsample.1", pl, gamma=0.5)
+            continue
         conv(pre + ".conv1", pl, inpl, 1)
         if ibn:
             inorm(pre + ".bn1.IN", pl // 2)
@@ -125,15 +140,25 @@ def bottleneck(x, sd, pre, stride, has_ds, ibn, training):
     return F.relu(out + res)
 
 
+def basic_block(x, sd, pre, stride, has_ds, training):
+    """resnet.py:22-48 BasicBlock.forward."""
+    out = F.relu(_bn(F.conv2d(x, sd[pre + ".conv1.weight"], stride=stride, padding=1), sd, pre + ".bn1", training))
+    out = _bn(F.conv2d(out, sd[pre + ".conv2.weight"], padding=1), sd, pre + ".bn2", training)
+    res = x
+    if has_ds:
+        res = _bn(F.conv2d(x, sd[pre + ".downsample.0.weight"], stride=stride), sd, pre + ".downsample.1", training)
+    return F.relu(out + res)
+
+
 def backbone_forward(x, sd, arch="resnet50", last_stride=1, training=False):
-    """Returns (base_out [B,2048,h,w], global_feat [B,2048]) -- modelling/baseline.py:91-96.
+    """Returns (base_out [B,2048,h,w], global_feat [B,2048]) -- modelling/baseline.py:91-96 (512 channels for resnet18 / 34).
     In training mode the running stats inside `sd` are updated in place (like nn.BatchNorm2d)."""
     y = _bn(F.conv2d(x, sd["conv1.weight"], stride=2, padding=3), sd, "bn1", training)
     if is_ibn(arch):
         y = F.relu(y)                                   # resnet_ibn_a.py:129 (plain ResNets have none)
     y = F.max_pool2d(y, 3, 2, 1)
     for pre, _inpl, _pl, s, ds, ibn in arch_spec(arch, last_stride):
-        y = bottleneck(y, sd, pre, s, ds, ibn, training)
+        y = basic_block(y, sd, pre, s, ds, training) if is_basic(arch) else bottleneck(y, sd, pre, s, ds, ibn, training)
     return y, y.mean(dim=(2, 3))
 
 

@@ -941,3 +941,81 @@ def test_bn2_relu_inside_conv3_operand_path_is_bit_identical(arch, dtype, hw, mo
     assert set(g1) == set(g0)
     for n in g0:
         assert torch.equal(g1[n], g0[n]), n
+
+
+@pytest.mark.parametrize("name,arch", [("backbone_r18_2x128x64", "resnet18"), ("backbone_r34_2x128x64", "resnet34")])
+def test_basic_block_archs_fp32_golden(golden, name, arch):
+    """Round 6: MODEL.NAME = resnet18 / resnet34 (modelling/baseline.py:56-65: ResNet(block=BasicBlock), 512-wide embedding) through
+    the engine's plain two-convolution block schedule, against recordings of the reference's own module: eval and train
+    embeddings <= 1e-4, running statistics, gradients in norm."""
+    from oracle import backbone_oracle as bo
+    g = golden(name)
+    net, eng, sd = _build(arch, torch.float32)
+    assert eng.basic and eng.cout == 512 and len(net.state_dict()) == int(g["n_keys"])
+    x = bo.synthetic_images(2, 128, 64, seed=7).cuda()
+    _, feat = eng.forward(x, training=False)
+    assert tuple(feat.shape) == (2, 512)
+    np.testing.assert_allclose(feat.cpu().numpy(), g["eval_feat"], rtol=0, atol=1e-4)
+    base_out, feat2 = eng.forward(x, training=False, want_base_out=True)
+    assert tuple(base_out.shape) == (2, 512, 8, 4) and torch.equal(feat2, feat)
+    _, feat = eng.forward(x, training=True)
+    np.testing.assert_allclose(feat.cpu().numpy(), g["train_feat"], rtol=0, atol=1e-4)
+    coef = torch.from_numpy(np.random.default_rng(99).standard_normal((2, 512)).astype(np.float32)).cuda()
+    eng.backward(coef)
+    last = net.layer4[-1].bn2
+    np.testing.assert_allclose(last.running_var.cpu().numpy(), g["l4_bn2_rv"], rtol=1e-3, atol=1e-5)
+
+    def close(a, ref, rel=3e-2):
+        a = a.astype(np.float64).ravel(); ref = ref.astype(np.float64).ravel()
+        assert np.linalg.norm(a - ref) <= rel * np.linalg.norm(ref), np.linalg.norm(a - ref) / np.linalg.norm(ref)
+    close(net.conv1.weight.grad.cpu().numpy(), g["grad_conv1"])
+    close(net.layer4[-1].conv2.weight.grad[:8].cpu().numpy(), g["grad_l4_conv2_slice"])
+    close(net.layer1[0].conv1.weight.grad[:8].cpu().numpy(), g["grad_l1_conv1_slice"])
+    close(net.layer2[0].downsample[0].weight.grad[:, :, 0, 0].cpu().numpy(), g["grad_l2_ds"])
+    close(net.layer3[1].bn1.weight.grad.cpu().numpy(), g["grad_l3_bn1_w"])
+    gsum = sum(p.grad.double().abs().sum().item() for p in net.parameters() if p.grad is not None)
+    assert abs(gsum - float(g["grad_abs_sum"])) < 2e-2 * float(g["grad_abs_sum"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_resnet18_ctl_step_16bit_vs_fp32_oracle(dtype):
+    """A whole CTLModel.training_step on resnet18 (BACKBONE_EMB_SIZE 512) in the 16-bit throughput modes against the fp32 CPU
+    oracle: embeddings cosine > 0.995, losses within 5 %; eval-mode (folded) forward close to the fp32 engine's."""
+    from oracle import backbone_oracle as bo, reid_oracle as ro
+    from centroids_reid_amd.config import get_cfg_defaults
+    from centroids_reid_amd.train_ctl_model import CTLModel
+    torch.set_num_threads(16)
+    P, K, C, H, W = 8, 4, 40, 128, 64
+    cfg = get_cfg_defaults()
+    cfg.MODEL.PRETRAINED = False; cfg.MODEL.NAME = "resnet18"; cfg.MODEL.BACKBONE_EMB_SIZE = 512
+    cfg.DATALOADER.NUM_INSTANCE = K; cfg.USE_MIXED_PRECISION = True
+    model = CTLModel(cfg, num_classes=C, num_query=0, compute_dtype=dtype)
+    sd = bo.make_state_dict("resnet18", 1, seed=31)
+    model.backbone.base.load_state_dict(sd)
+    rng = np.random.default_rng(4)
+    with torch.no_grad():
+        model.center_loss.centers.copy_(torch.from_numpy(rng.standard_normal((C, 512)).astype(np.float32)) * 0.3)
+        model.fc_query.weight.copy_(torch.from_numpy((rng.standard_normal((C, 512)) * 0.01).astype(np.float32)))
+    centers0 = model.center_loss.centers.detach().clone(); fc0 = model.fc_query.weight.detach().clone()
+    model = model.cuda().train()
+    model.configure_optimizers()
+    if dtype == torch.float16:
+        model.loss_scaler.state.copy_(torch.tensor([1024.0, 1.0 / 1024.0]))
+    x = bo.synthetic_images(P * K, H, W, seed=3)
+    labels = torch.from_numpy(np.repeat((np.arange(P) * 3) % C, K).astype(np.int64))
+    is_real = torch.ones(P * K, dtype=torch.bool)
+    out = model.training_step((x.cuda(), labels.cuda(), torch.zeros(P * K, dtype=torch.int64), is_real), 0)
+    with torch.no_grad():
+        _, feat = bo.backbone_forward(x, {k: v.clone() for k, v in sd.items()}, "resnet18", 1, training=True)
+        o = ro.ctl_heads(feat, labels, is_real, torch.ones(512), torch.zeros(512), torch.zeros(512), torch.ones(512), fc0, centers0, P, K)
+    assert abs(float(out["loss"]) - float(o["total"])) < 3e-2 * abs(float(o["total"])), (float(out["loss"]), float(o["total"]))
+    for n in ("query_xent", "query_triplet", "query_center", "centroid_triplet"):
+        got, ref = float(model.losses_dict[n][-1]), float(o[n])
+        assert abs(got - ref) < 5e-2 * abs(ref) + 2e-3, (n, got, ref)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    opt, _ = model.optimizers()
+    assert opt.step_count == 1
+    model.eval()
+    with torch.no_grad():
+        e16 = model.validation_step((x.cuda(), labels, torch.zeros(P * K), torch.arange(P * K)), 0)["emb"].float().cpu()
+    assert e16.shape == (P * K, 512) and bool(torch.isfinite(e16).all())

@@ -240,3 +240,32 @@ def test_triplet_cosine_normalize_oracle(golden):
     ap, an, pi, ni = ro.hard_example_mining(torch.from_numpy(g["mine_dist"]), labels)
     np.testing.assert_array_equal(pi.numpy(), g["mine_pi"]); np.testing.assert_array_equal(ni.numpy(), g["mine_ni"])
     np.testing.assert_array_equal(ap.numpy(), g["mine_ap"]); np.testing.assert_array_equal(an.numpy(), g["mine_an"])
+
+
+@pytest.mark.parametrize("name", ["backbone_r18_2x128x64", "backbone_r34_2x128x64"])
+def test_basic_block_backbone_oracle(golden, name):
+    """resnet18 / resnet34 (modelling/baseline.py:56-65, modelling/backbones/resnet.py:22-48 BasicBlock): the oracle against
+    recordings of the reference's own ResNet(block=BasicBlock) on the same seeded weights."""
+    g = golden(name)
+    arch = str(g["arch"]); B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    torch.set_num_threads(8)
+    sd = bo.make_state_dict(arch, 1, seed=1234)
+    assert len(sd) == int(g["n_keys"])
+    x = bo.synthetic_images(B, H, W, seed=7)
+    with torch.no_grad():
+        y, feat = bo.backbone_forward(x, sd, arch, 1, training=False)
+    assert feat.shape == (B, 512)
+    np.testing.assert_allclose(feat.numpy(), g["eval_feat"], rtol=1e-4, atol=1e-5)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point
+              and not k.endswith(("running_mean", "running_var"))}
+    sd2 = {**{k: v.clone() for k, v in sd.items()}, **params}
+    y, feat = bo.backbone_forward(x, sd2, arch, 1, training=True)
+    np.testing.assert_allclose(feat.detach().numpy(), g["train_feat"], rtol=1e-4, atol=1e-5)
+    coef = torch.from_numpy(np.random.default_rng(99).standard_normal((B, 512)).astype(np.float32))
+    (feat * coef).sum().backward()
+    last = "layer4.%d.bn2" % (bo.ARCH_LAYERS[arch][3] - 1)
+    np.testing.assert_allclose(sd2[last + ".running_var"].numpy(), g["l4_bn2_rv"], rtol=1e-4, atol=1e-6)
+    gc1 = params["conv1.weight"].grad.numpy()
+    np.testing.assert_allclose(gc1, g["grad_conv1"], rtol=2e-3, atol=2e-3 * np.abs(g["grad_conv1"]).max())
+    gds = params["layer2.0.downsample.0.weight"].grad[:, :, 0, 0].numpy()
+    np.testing.assert_allclose(gds, g["grad_l2_ds"], rtol=2e-3, atol=2e-3 * np.abs(gds).max())

@@ -300,7 +300,7 @@ def gen_backbone(ref, name, arch, B, H, W):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.load()
-    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed", "transforms", "deep")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
+    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed", "transforms", "deep", "config", "basic")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
     if "eval" in which:
         gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
         gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
@@ -581,3 +581,43 @@ def gen_config_keys():
 
 if __name__ == "__main__" and "config" in sys.argv[1:]:
     gen_config_keys()
+
+
+def gen_backbone_basic(ref, name, arch, B, H, W):
+    """resnet18 / resnet34 (modelling/baseline.py:56-65: ResNet(block=BasicBlock, layers=...), 512-wide embedding): the
+    reference's own module on the oracle's PCG64-seeded weights -- eval / train embeddings, running statistics, gradients."""
+    from oracle import backbone_oracle as bo
+    sd = bo.make_state_dict(arch, 1, seed=1234)
+    net = ref.resnet.ResNet(last_stride=1, block=ref.resnet.BasicBlock, layers=list(bo.ARCH_LAYERS[arch]))
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys, missing
+    x = bo.synthetic_images(B, H, W, seed=7)
+    coef = torch.from_numpy(np.random.default_rng(99).standard_normal((B, 512)).astype(np.float32))
+    rec = {}
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+        rec["eval_feat"] = y.mean(dim=(2, 3)).numpy()
+    net.train()
+    y = net(x)
+    feat = y.mean(dim=(2, 3))
+    rec["train_feat"] = feat.detach().numpy()
+    (feat * coef).sum().backward()
+    last = net.layer4[-1].bn2
+    rec["l4_bn2_rm"] = last.running_mean.numpy().copy(); rec["l4_bn2_rv"] = last.running_var.numpy().copy()
+    rec["grad_conv1"] = net.conv1.weight.grad.numpy().copy()
+    rec["grad_l4_conv2_slice"] = net.layer4[-1].conv2.weight.grad[:8].numpy().copy()
+    rec["grad_l1_conv1_slice"] = net.layer1[0].conv1.weight.grad[:8].numpy().copy()
+    rec["grad_l2_ds"] = net.layer2[0].downsample[0].weight.grad[:, :, 0, 0].numpy().copy()
+    rec["grad_l3_bn1_w"] = net.layer3[1].bn1.weight.grad.numpy().copy()
+    gsum = sum(p.grad.double().abs().sum().item() for p in net.parameters() if p.grad is not None)
+    rec["grad_abs_sum"] = np.float64(gsum)
+    rec["n_keys"] = np.int64(len(net.state_dict()))
+    np.savez_compressed(os.path.join(OUT, name), arch=np.array(arch), B=np.int64(B), H=np.int64(H), W=np.int64(W), **rec)
+    print(f"[{name}] eval_feat std={rec['eval_feat'].std():.5f} train_feat std={rec['train_feat'].std():.5f} grad_abs_sum={gsum:.4e}")
+
+
+if __name__ == "__main__" and "basic" in sys.argv[1:]:
+    _ref = ref_import.load()
+    gen_backbone_basic(_ref, "backbone_r18_2x128x64", "resnet18", 2, 128, 64)
+    gen_backbone_basic(_ref, "backbone_r34_2x128x64", "resnet34", 2, 128, 64)
