@@ -144,3 +144,16 @@ def test_f16_training_data_parallel_two_ranks_one_gpu():
     assert line["dtype"] == "f16" and line["n_gpus"] == 2 and np.isfinite(line["final_loss"])
     st = line["f16_state"]
     assert 1.0 <= st["loss_scale"] <= 65536.0 and st["adam_steps_applied"] >= 1
+
+
+def test_lonely_identity_error_is_raised_on_every_rank_two_ranks_one_gpu():
+    """with a device isReal mask the lonely-identity error is raised late, from check_lonely_identities(); under data
+    parallelism only the rank that saw the batch has a non-zero counter, so the counter is all-reduced first and EVERY rank raises
+    (a rank raising alone would leave the others hanging in their next collective)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "debug", "lonely_ddp_check.py")]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert out.count("LONELY_DDP_OK") == 2 and "LONELY_DDP_MISMATCH" not in out, out[-3000:]

@@ -69,3 +69,48 @@ def test_one_call_heads_at_the_benchmark_shape(monkeypatch):
     assert a == b, (a, b)
     for k in ("flat", "gflat", "centers", "bn_rm", "bn_rv"):
         assert _same_bits(sa[k], sb[k]), k
+
+
+def test_fused_heads_entry_point_refuses_what_it_does_not_cover():
+    """Error behaviour of the C entry point (include/creid.h): argument errors are negative return codes, never a launch --
+    K > 16 / D % 8 != 0 -> CREID_E_SHAPE (-4), a workspace that is too small -> CREID_E_WS (-3), missing pointers or a masked
+    schedule without its lonely counter -> CREID_E_ARG (-1), the column-sum extension with an fp32 gradient -> CREID_E_SHAPE."""
+    import ctypes as C
+    from centroids_reid_amd import _lib as L
+    lib = L.lib()
+    B, P, K, D, Cc, HW = 16, 4, 4, 64, 10, 4
+    f = lambda *s: torch.zeros(s, device="cuda")                               # noqa: E731
+    feat, centers, bw, bb, rm, rv, W = f(B, D), f(Cc, D), f(D) + 1, f(D), f(D), f(D) + 1, f(Cc, D)
+    labels = torch.arange(B, device="cuda") // K
+    real = torch.ones(B, dtype=torch.uint8, device="cuda")
+    n = 4 * (K + 1) + 2
+    wv, stats, g = f(n), f(n + 7), f(B * HW, D)
+    nbytes = lib.creid_ctl_heads_workspace_bytes(B, P, K, D, Cc)
+    assert nbytes > 0 and lib.creid_ctl_heads_workspace_bytes(0, P, K, D, Cc) == 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+
+    def make(**over):
+        a = L.CtlHeads()
+        a.B, a.P, a.K, a.D, a.num_classes, a.num_centers, a.HW = B, P, K, D, Cc, Cc, HW
+        a.g_dtype, a.masked, a.split_logits, a.split_dbnf = 0, 0, 1, 1
+        a.margin, a.xent_eps, a.w_query, a.w_center, a.w_xent, a.w_centroid, a.bn_momentum, a.bn_eps = 0.5, 0.1, 1, 5e-4, 1, 1, 0.1, 1e-5
+        for name, t in (("feat", feat), ("labels", labels), ("is_real", real), ("centers", centers), ("bn_weight", bw), ("bn_bias", bb),
+                        ("bn_running_mean", rm), ("bn_running_var", rv), ("fc_weight", W), ("loss_weights", wv), ("stats", stats),
+                        ("g", g), ("workspace", ws)):
+            setattr(a, name, t.data_ptr())
+        a.workspace_bytes = nbytes
+        for k, v in over.items():
+            setattr(a, k, v)
+        return a
+
+    call = lambda a: lib.creid_ctl_heads_fused(C.byref(a), L.stream())        # noqa: E731
+    assert call(make()) == 0                                                     # the covered case runs
+    torch.cuda.synchronize()
+    assert torch.isfinite(stats).all()
+    assert call(make(K=17, P=1)) in (-1, -4)                                     # B != P * K is an argument error first
+    assert call(make(workspace_bytes=nbytes // 2)) == -3
+    assert call(make(feat=None)) == -1
+    assert call(make(masked=1)) == -1                                            # masked schedule without the lonely counter
+    assert call(make(g_dtype=7)) == -2
+    assert call(make(bn_partial=stats.data_ptr(), bn_x=feat.data_ptr(), bn_mask=real.data_ptr(), bn_mean=bw.data_ptr(),
+                     bn_invstd=bw.data_ptr())) == -4                             # column-sum extension: 16-bit gradients only
