@@ -100,22 +100,22 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const void* __restrict_
 
 // ----------------------------------------------------------------------------------------
 // fp32 distance GEMM.  128x128 tile / 256 threads (4 waves as 2x2, 64x64 per wave = 2x2
-// MFMA 32x32 tiles), BK = 16, LDS double-buffered and K-MAJOR ([k][row], LD = 130) so that the
-// per-lane MFMA operand (A[i = lane&31][k = lane>>5]) is a conflict-free ds_read_b32.
+// MFMA 32x32 tiles), BK = 16, LDS double-buffered.  Operand image of a k-tile (the same as stream_eval.hip's):
+// [kh = k & 1][half = k >> 3][row][s4 = (k >> 1) & 3] -- the per-lane MFMA operand is A[i = lane&31][k = 2 step + (lane>>5)], so
+// the values of four consecutive steps are one 16-byte unit: 8 ds_read_b128 per k-tile and lane instead of 32 ds_read_b32, and
+// a staged global float4 is two ds_write_b64.  The k order of the accumulation is unchanged (bit-identical results).
 // ----------------------------------------------------------------------------------------
 namespace {
-// DLD = 130: 4*DLD = 8 (mod 32), so the staging stores of a 32-lane group (4 k-columns x 8 rows) fall on 32 distinct banks
-// (with 129 they were ~2-way conflicted: SQ_LDS_BANK_CONFLICT = 40 % of the busy cycles, profiles/r02_pmc_summary.md);
-// the fragment reads (32 consecutive rows of one k) are conflict-free for any pitch.
-constexpr int DBM = 128, DBN = 128, DBK = 16, DLD = 130;
+// plane pitch = 4 * rows + 16 dwords: the two halves a 16-lane ds_write_b64 group touches fall on disjoint banks
+constexpr int DBM = 128, DBN = 128, DBK = 16, DPL = DBM * 4 + 16;
 }
 
 __global__ __launch_bounds__(256) void sqdist_f32_kernel(const float* __restrict__ q, const float* __restrict__ g,
                                                          const float* __restrict__ qq, const float* __restrict__ gg,
                                                          int m, int n, int D, float* __restrict__ out,
                                                          int64_t ldo, int tiles_n) {
-  __shared__ float As[2][DBK][DLD];
-  __shared__ float Bs[2][DBK][DLD];
+  __shared__ __attribute__((aligned(16))) float As[2][2][2][DPL];
+  __shared__ __attribute__((aligned(16))) float Bs[2][2][2][DPL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give
@@ -142,26 +142,26 @@ __global__ __launch_bounds__(256) void sqdist_f32_kernel(const float* __restrict
     bp[i] = g + (int64_t)rb * D + 4 * lkc;
   }
   float4 ra[2], rb[2];
-  auto gload = [&](int k0) {
+  unsigned rmask = 0u;                             // all ones while the staged k-tile lies inside D
+  auto gload = [&](int k0) {                       // branch-free (a k-tile beyond D reads k-tile 0; lstore turns it into zeros)
+    const bool in = k0 + 4 * lkc < D;
+    const int ko = in ? k0 : 0;
+    rmask = in ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (k0 + 4 * lkc < D) {
-        ra[i] = *reinterpret_cast<const float4*>(ap[i] + k0);
-        rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
-      } else {
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      ra[i] = *reinterpret_cast<const float4*>(ap[i] + ko);
+      rb[i] = *reinterpret_cast<const float4*>(bp[i] + ko);
     }
   };
+  const int sh = lkc >> 1, so = lrow * 4 + 2 * (lkc & 1);          // global k = 4 lkc + {0..3}: steps 2 lkc, 2 lkc + 1
+  auto mk = [&](float v) { return __uint_as_float(__float_as_uint(v) & rmask); };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = lrow + 64 * i;
-      As[buf][4 * lkc + 0][r] = ra[i].x; As[buf][4 * lkc + 1][r] = ra[i].y;
-      As[buf][4 * lkc + 2][r] = ra[i].z; As[buf][4 * lkc + 3][r] = ra[i].w;
-      Bs[buf][4 * lkc + 0][r] = rb[i].x; Bs[buf][4 * lkc + 1][r] = rb[i].y;
-      Bs[buf][4 * lkc + 2][r] = rb[i].z; Bs[buf][4 * lkc + 3][r] = rb[i].w;
+      *reinterpret_cast<float2*>(&As[buf][0][sh][so + 256 * i]) = make_float2(mk(ra[i].x), mk(ra[i].z));
+      *reinterpret_cast<float2*>(&As[buf][1][sh][so + 256 * i]) = make_float2(mk(ra[i].y), mk(ra[i].w));
+      *reinterpret_cast<float2*>(&Bs[buf][0][sh][so + 256 * i]) = make_float2(mk(rb[i].x), mk(rb[i].z));
+      *reinterpret_cast<float2*>(&Bs[buf][1][sh][so + 256 * i]) = make_float2(mk(rb[i].y), mk(rb[i].w));
     }
   };
 
@@ -173,28 +173,68 @@ __global__ __launch_bounds__(256) void sqdist_f32_kernel(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int fa = (wm * 64 + l31) * 4, fb = (wn * 64 + l31) * 4;
+  // The k-loop is the two-phase pipeline of stream_eval.hip's sqdist_count_f32_kernel: 16 MFMAs per phase (64 cycles each) with
+  // everything else issued in their shadow -- phase 1: second-half fragment reads + LDS writes of the next k-tile, barrier,
+  // phase 2: global loads of the k-tile after that + first-half fragment reads of the next one.
+  float4 a0[2], b0[2], a1[2], b1[2];
+  auto frag = [&](int buf, int half, float4 (&a)[2], float4 (&b)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[i] = *reinterpret_cast<const float4*>(&As[buf][kh][half][fa + 128 * i]);
+      b[i] = *reinterpret_cast<const float4*>(&Bs[buf][kh][half][fb + 128 * i]);
+    }
+  };
+  auto mma16 = [&](const float4 (&a)[2], const float4 (&b)[2]) {   // steps in k order: 4 half + s4 multiplies k = 2 step + kh
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float ac[4] = {a[i].x, a[i].y, a[i].z, a[i].w};
+        const float bc[4] = {b[i].x, b[i].y, b[i].z, b[i].w};
+        av[i] = ac[s4]; bv[i] = bc[s4];
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
+    }
+  };
   const int nk = (D + DBK - 1) / DBK;
   gload(0);
   lstore(0);
   __syncthreads();
-  const int l31 = lane & 31, kh = lane >> 5;
-  for (int t = 0; t < nk; ++t) {
+  gload(DBK);
+  frag(0, 0, a0, b0);
+  for (int t = 0; t + 1 < nk; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nk) gload((t + 1) * DBK);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(buf, 1, a1, b1);
+    lstore(buf ^ 1);
+    mma16(a0, b0);
 #pragma unroll
-    for (int kk = 0; kk < DBK; kk += 2) {
-      float a0 = As[buf][kk + kh][wm * 64 + l31];
-      float a1 = As[buf][kk + kh][wm * 64 + 32 + l31];
-      float b0 = Bs[buf][kk + kh][wn * 64 + l31];
-      float b1 = Bs[buf][kk + kh][wn * 64 + 32 + l31];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (t + 1 < nk) lstore(buf ^ 1);
+    for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    gload((t + 2) * DBK);
+    frag(buf ^ 1, 0, a0, b0);
+    mma16(a1, b1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x020, 1, 1); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  frag((nk - 1) & 1, 1, a1, b1);                   // last k-tile: nothing left to stage
+  mma16(a0, b0);
+  mma16(a1, b1);
 
   // epilogue: d = (qq + gg) - 2*dot  (-2*dot is exact, so fma == mul+add of the reference)
 #pragma unroll

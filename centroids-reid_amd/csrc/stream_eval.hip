@@ -19,7 +19,15 @@
 #include <stdlib.h>
 
 namespace {
-constexpr int SQ_TM = 64, SQ_TN = 256, SQ_BK = 16, SQ_LDA = SQ_TM + 2, SQ_LDB = SQ_TN + 2;   // pitch = 2 (mod 8): see dist.hip
+constexpr int SQ_TM = 64, SQ_TN = 256, SQ_BK = 16;
+// LDS operand image of one 16-deep k-tile: [kh = k & 1][half = k >> 3][row][s4 = (k >> 1) & 3] -- the four values a lane feeds to
+// four consecutive MFMA steps (lane >> 5 = kh; step s = 4 half + s4 multiplies k = 2 s + kh) are one 16-byte unit, so a k-tile's
+// fragments are 2 + 8 ds_read_b128 per lane instead of 8 + 32 ds_read_b32, and the staging side writes a global float4 as two
+// ds_write_b64 ((x, z) -> kh 0, (y, w) -> kh 1) instead of four ds_write_b32.  At two workgroups per CU the b32 form needed 1280
+// LDS cycles per pair of k-tiles against 1024 MFMA cycles per SIMD (MI355X_MICROARCH.md, LDS table): the contraction was LDS-bound
+// at ~80 %; this form needs ~800.  Plane pitch = 4 rows + 16 dwords: the two halves a 16-lane store group touches fall on
+// disjoint banks; a 16-lane ds_read_b128 group reads 16 distinct rows = 64 distinct banks for any pitch.
+constexpr int SQ_PA = SQ_TM * 4 + 16, SQ_PB = SQ_TN * 4 + 16;
 constexpr int PL_MAXC = 128;
 
 // float -> unsigned with the same order (negatives included; squared distances may be slightly negative)
@@ -122,9 +130,7 @@ __global__ __launch_bounds__(PL_MAXC) void stream_poslist_kernel(
 
 // ----------------------------------------------------------------------------------------
 // 2. streamed contraction + count.  Workgroup = (query tile of 64 rows, slice of the gallery); 4 waves as 2 x 2,
-//    each 32 rows x 128 columns (1 x 4 MFMA 32x32 blocks) of a 64 x 256 tile; K-major LDS operands
-//    ([k][row]: conflict-free ds_read_b32 for the A[i = lane&31][k = lane>>5] operand layout; pitch = 2 mod 8 keeps
-//    the staging stores conflict-free too).
+//    each 32 rows x 128 columns (1 x 4 MFMA 32x32 blocks) of a 64 x 256 tile; LDS operand image: see SQ_PA above.
 //    Dynamic LDS: this query tile's positive keys [64][cap] and the histogram [64][cap].
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
@@ -132,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
     int m, int n, int D, const int64_t* __restrict__ q_pids, const int64_t* __restrict__ g_pids, int cap, int log2cap,
     const unsigned* __restrict__ pos_key, const int32_t* __restrict__ pos_idx, const int32_t* __restrict__ npos,
     unsigned* __restrict__ hist_out, int tiles_m, int tiles_n, int nsplit, int skip_count) {
-  __shared__ float As[2][SQ_BK][SQ_LDA];
-  __shared__ float Bs[2][SQ_BK][SQ_LDB];
+  __shared__ __attribute__((aligned(16))) float As[2][2][2][SQ_PA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][2][2][SQ_PB];
   __shared__ float s_qq[SQ_TM];
   __shared__ long long s_qpid[SQ_TM];
   __shared__ int s_np[SQ_TM];
@@ -179,27 +185,27 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) bp[i] = g + (int64_t)min(tn * SQ_TN + lrow + 64 * i, n - 1) * D + 4 * lkc;
   };
-  auto gload = [&](int k0) {
-    if (k0 + 4 * lkc < D) {
-      ra = *reinterpret_cast<const float4*>(ap + k0);
+  unsigned rmask = 0u;                             // all ones while the staged k-tile lies inside D
+  auto gload = [&](int k0) {                       // branch-free (a k-tile beyond D reads k-tile 0; lstore turns it into zeros)
+    const bool in = k0 + 4 * lkc < D;
+    const int ko = in ? k0 : 0;
+    rmask = in ? 0xffffffffu : 0u;
+    ra = *reinterpret_cast<const float4*>(ap + ko);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
-    } else {
-      ra = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + ko);
   };
+  const int sh = lkc >> 1, so = lrow * 4 + 2 * (lkc & 1);          // global k = 4 lkc + {0..3}: steps 2 lkc, 2 lkc + 1
+  auto mk = [&](float v) { return __uint_as_float(__float_as_uint(v) & rmask); };
   auto lstore = [&](int buf) {
-    As[buf][4 * lkc + 0][lrow] = ra.x; As[buf][4 * lkc + 1][lrow] = ra.y;
-    As[buf][4 * lkc + 2][lrow] = ra.z; As[buf][4 * lkc + 3][lrow] = ra.w;
+    *reinterpret_cast<float2*>(&As[buf][0][sh][so]) = make_float2(mk(ra.x), mk(ra.z));
+    *reinterpret_cast<float2*>(&As[buf][1][sh][so]) = make_float2(mk(ra.y), mk(ra.w));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = lrow + 64 * i;
-      Bs[buf][4 * lkc + 0][r] = rb[i].x; Bs[buf][4 * lkc + 1][r] = rb[i].y;
-      Bs[buf][4 * lkc + 2][r] = rb[i].z; Bs[buf][4 * lkc + 3][r] = rb[i].w;
+      *reinterpret_cast<float2*>(&Bs[buf][0][sh][so + 256 * i]) = make_float2(mk(rb[i].x), mk(rb[i].z));
+      *reinterpret_cast<float2*>(&Bs[buf][1][sh][so + 256 * i]) = make_float2(mk(rb[i].y), mk(rb[i].w));
     }
   };
+  const int fa = (wm * 32 + l31) * 4, fb = (wn * 128 + l31) * 4;
   const int nk = (D + SQ_BK - 1) / SQ_BK;
   if (t0 < t1) { set_tile(t0); gload(0); }
   for (int tn = t0; tn < t1; ++tn) {
@@ -209,23 +215,61 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // One wave keeps the matrix pipe busy on its own: every k-tile is two phases of 16 MFMAs (64 cycles each), and everything
+    // else is issued in their shadow -- phase 1 multiplies the k-tile's first half while the second half's fragments are
+    // read and the NEXT k-tile (in registers since the previous phase 2) is written to the other LDS buffer; the barrier
+    // sits between the phases, where the second half's operands are already in registers; phase 2 multiplies the second
+    // half while the next k-tile's first-half fragments are read and the k-tile after that is fetched from global memory.
+    // (Before: reads, 32 MFMAs, writes, barrier in sequence -- the two waves of a SIMD fell into step and idled together.)
+    float4 a0, b0[4], a1, b1[4];
+    auto frag = [&](int buf, int half, float4& a, float4 (&b)[4]) {
+      a = *reinterpret_cast<const float4*>(&As[buf][kh][half][fa]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[buf][kh][half][fb + 128 * j]);
+    };
+    auto mma16 = [&](const float4& a, const float4 (&b)[4]) {      // steps in k order: 4 half + s4 multiplies k = 2 step + kh
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float bv[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4], bv[s4], acc[j], 0, 0, 0);
+        }
+    };
     __syncthreads();                               // previous tile's readers are done with both LDS buffers
     lstore(0);                                     // k-tile 0 was fetched during the previous tile's epilogue
     __syncthreads();
-    for (int t = 0; t < nk; ++t) {
+    gload(SQ_BK);                                  // k-tile 1 (zeros when there is none)
+    frag(0, 0, a0, b0);
+    for (int t = 0; t + 1 < nk; ++t) {
       const int buf = t & 1;
-      if (t + 1 < nk) gload((t + 1) * SQ_BK);
+      __builtin_amdgcn_sched_barrier(0);
+      frag(buf, 1, a1, b1);
+      lstore(buf ^ 1);
+      mma16(a0, b0);
 #pragma unroll
-      for (int kk = 0; kk < SQ_BK; kk += 2) {
-        const float a = As[buf][kk + kh][wm * 32 + l31];
-        float b[4];
+      for (int i = 0; i < 5; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kk + kh][wn * 128 + j * 32 + l31];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
-      }
-      if (t + 1 < nk) lstore(buf ^ 1);
+      for (int i = 0; i < 10; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      gload((t + 2) * SQ_BK);
+      frag(buf ^ 1, 0, a0, b0);
+      mma16(a1, b1);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x020, 1, 1); }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {                                              // last k-tile: nothing left to stage
+      frag((nk - 1) & 1, 1, a1, b1);
+      mma16(a0, b0);
+      mma16(a1, b1);
     }
     if (tn + 1 < t1) { set_tile(tn + 1); gload(0); }               // flies while the epilogue runs
     // ---- epilogue: the tile is consumed here (row-major walk: the row's metadata is read once per 4 columns)
