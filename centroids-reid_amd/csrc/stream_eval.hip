@@ -17,17 +17,16 @@
 // on identical bits and ties resolve by gallery index exactly like the stable rank kernel.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 constexpr int SQ_TM = 64, SQ_TN = 256, SQ_BK = 16;
-// LDS operand image of one 16-deep k-tile: [kh = k & 1][half = k >> 3][row][s4 = (k >> 1) & 3] -- the four values a lane feeds to
-// four consecutive MFMA steps (lane >> 5 = kh; step s = 4 half + s4 multiplies k = 2 s + kh) are one 16-byte unit, so a k-tile's
-// fragments are 2 + 8 ds_read_b128 per lane instead of 8 + 32 ds_read_b32, and the staging side writes a global float4 as two
-// ds_write_b64 ((x, z) -> kh 0, (y, w) -> kh 1) instead of four ds_write_b32.  At two workgroups per CU the b32 form needed 1280
-// LDS cycles per pair of k-tiles against 1024 MFMA cycles per SIMD (MI355X_MICROARCH.md, LDS table): the contraction was LDS-bound
-// at ~80 %; this form needs ~800.  Plane pitch = 4 rows + 16 dwords: the two halves a 16-lane store group touches fall on
-// disjoint banks; a 16-lane ds_read_b128 group reads 16 distinct rows = 64 distinct banks for any pitch.
-constexpr int SQ_PA = SQ_TM * 4 + 16, SQ_PB = SQ_TN * 4 + 16;
+// LDS operand image of one 16-deep k-tile: [kh = k & 1][quarter = k >> 2][row][e = (k >> 1) & 1] -- the per-lane MFMA operand is
+// A[i = lane & 31][k = 2 step + (lane >> 5)], so the two values a lane feeds to the two steps of a quarter are one 8-byte unit:
+// a quarter's fragments are 1 + 4 ds_read_b64 per lane (32 lanes x 8 B = one conflict-free 256-B row of banks), and the staging
+// side writes a global float4 (k = 4 q .. 4 q + 3) as two ds_write_b64: (x, z) -> kh 0, (y, w) -> kh 1.  Plane pitch = 2 rows +
+// 8 dwords: the four quarter planes a 16-lane store group touches (4 rows x 4 quarters) cover 32 distinct banks.
+constexpr int SQ_PA = SQ_TM * 2 + 8, SQ_PB = SQ_TN * 2 + 8;
 constexpr int PL_MAXC = 128;
 
 // float -> unsigned with the same order (negatives included; squared distances may be slightly negative)
@@ -133,13 +132,16 @@ __global__ __launch_bounds__(PL_MAXC) void stream_poslist_kernel(
 //    each 32 rows x 128 columns (1 x 4 MFMA 32x32 blocks) of a 64 x 256 tile; LDS operand image: see SQ_PA above.
 //    Dynamic LDS: this query tile's positive keys [64][cap] and the histogram [64][cap].
 // ----------------------------------------------------------------------------------------
+// ABL: timing ablations of the k-loop (ablation build only; results wrong): 2 no global loads, 4 no barrier, 8 no LDS writes,
+// 16 no fragment reads, 32 no MFMAs inside the loop, 64 global loads always from k-tiles 0 / 1 (cache-hot).
+template <int ABL, bool FULLK>
 __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
     const float* __restrict__ q, const float* __restrict__ g, const float* __restrict__ qq, const float* __restrict__ gg,
     int m, int n, int D, const int64_t* __restrict__ q_pids, const int64_t* __restrict__ g_pids, int cap, int log2cap,
     const unsigned* __restrict__ pos_key, const int32_t* __restrict__ pos_idx, const int32_t* __restrict__ npos,
     unsigned* __restrict__ hist_out, int tiles_m, int tiles_n, int nsplit, int skip_count) {
-  __shared__ __attribute__((aligned(16))) float As[2][2][2][SQ_PA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][2][2][SQ_PB];
+  __shared__ __attribute__((aligned(16))) float As[2][2][4][SQ_PA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][2][4][SQ_PB];
   __shared__ float s_qq[SQ_TM];
   __shared__ long long s_qpid[SQ_TM];
   __shared__ int s_np[SQ_TM];
@@ -178,36 +180,68 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
   }
 
   const int lrow = tid >> 2, lkc = tid & 3;
-  const float* ap = q + (int64_t)min(row0 + lrow, m - 1) * D + 4 * lkc;
-  const float* bp[4];
-  float4 ra, rb[4];
+  // Staging addresses: one wave-uniform base per operand (SGPRs; the k advance is scalar arithmetic) + a 32-bit byte offset per
+  // lane and row (clamped rows: at most 256 rows x D floats from the base), so a k-tile's fetch costs no vector ALU work.
+  const char* abase = reinterpret_cast<const char*>(q + (int64_t)min(row0, m - 1) * D);
+  const unsigned aoff = (unsigned)(min(row0 + lrow, m - 1) - min(row0, m - 1)) * (unsigned)D * 4u + 16u * lkc;
+  const char* bbase = nullptr;
+  unsigned boff[4];
+  // Two register sets of staged k-tiles: a k-tile is fetched ~1.5 k-tiles before it is written to LDS.
+  float4 ra[2], rb[2][4];
+  unsigned rmask[2] = {0u, 0u};                    // !FULLK: all ones while the staged k-tile lies inside D
   auto set_tile = [&](int tn) {
+    const int c0 = min(tn * SQ_TN, n - 1);
+    bbase = reinterpret_cast<const char*>(g + (int64_t)c0 * D);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bp[i] = g + (int64_t)min(tn * SQ_TN + lrow + 64 * i, n - 1) * D + 4 * lkc;
+    for (int i = 0; i < 4; ++i) boff[i] = (unsigned)(min(tn * SQ_TN + lrow + 64 * i, n - 1) - c0) * (unsigned)D * 4u + 16u * lkc;
   };
-  unsigned rmask = 0u;                             // all ones while the staged k-tile lies inside D
-  auto gload = [&](int k0) {                       // branch-free (a k-tile beyond D reads k-tile 0; lstore turns it into zeros)
-    const bool in = k0 + 4 * lkc < D;
-    const int ko = in ? k0 : 0;
-    rmask = in ? 0xffffffffu : 0u;
-    ra = *reinterpret_cast<const float4*>(ap + ko);
+  // part 0: the query row and gallery rows 0 / 1; part 1: gallery rows 2 / 3; part 2: all five (k0 is wave-uniform; branch-free)
+  auto gload = [&](auto S_, int k0, int part) {
+    constexpr int S = decltype(S_)::value;
+    const int ko = k0 < D ? k0 : 0;                // a k-tile beyond D (the pipeline fetches up to three ahead) reads k-tile 0
+    if constexpr (FULLK) {
+      const char* ab = abase + (int64_t)ko * 4;
+      const char* bb = bbase + (int64_t)ko * 4;
+      if (part != 1) ra[S] = *reinterpret_cast<const float4*>(ab + aoff);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + ko);
-  };
-  const int sh = lkc >> 1, so = lrow * 4 + 2 * (lkc & 1);          // global k = 4 lkc + {0..3}: steps 2 lkc, 2 lkc + 1
-  auto mk = [&](float v) { return __uint_as_float(__float_as_uint(v) & rmask); };
-  auto lstore = [&](int buf) {
-    *reinterpret_cast<float2*>(&As[buf][0][sh][so]) = make_float2(mk(ra.x), mk(ra.z));
-    *reinterpret_cast<float2*>(&As[buf][1][sh][so]) = make_float2(mk(ra.y), mk(ra.w));
+      for (int i = 0; i < 4; ++i)
+        if (part == 2 || (i >> 1) == part) rb[S][i] = *reinterpret_cast<const float4*>(bb + boff[i]);
+    } else {                                       // ... and a lane whose 16 bytes lie beyond D reads its row's first 16 bytes;
+      const bool in = k0 + 4 * lkc < D;            // lstore writes zeros for both
+      rmask[S] = in ? 0xffffffffu : 0u;
+      const unsigned lo = in ? (unsigned)ko * 4u : 0u - 16u * lkc;           // added to aoff / boff (which hold + 16 lkc): no wrap below 0
+      if (part != 1) ra[S] = *reinterpret_cast<const float4*>(abase + (aoff + lo));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float2*>(&Bs[buf][0][sh][so + 256 * i]) = make_float2(mk(rb[i].x), mk(rb[i].z));
-      *reinterpret_cast<float2*>(&Bs[buf][1][sh][so + 256 * i]) = make_float2(mk(rb[i].y), mk(rb[i].w));
+      for (int i = 0; i < 4; ++i)
+        if (part == 2 || (i >> 1) == part) rb[S][i] = *reinterpret_cast<const float4*>(bbase + (boff[i] + lo));
     }
   };
-  const int fa = (wm * 32 + l31) * 4, fb = (wn * 128 + l31) * 4;
+  const int so = lrow * 2;                         // global k = 4 lkc + {0..3}: quarter lkc, steps 2 lkc and 2 lkc + 1
+  // (x, z) -> kh 0 and (y, w) -> kh 1 as two 4-byte stores each: the compiler emits ds_write2_b32 straight from the load's
+  // registers (an 8-byte store would need the pair copied into adjacent registers first)
+  auto st2 = [&](float* p, float v0, float v1, unsigned mask) {
+    if constexpr (FULLK) { p[0] = v0; p[1] = v1; }
+    else { p[0] = __uint_as_float(__float_as_uint(v0) & mask); p[1] = __uint_as_float(__float_as_uint(v1) & mask); }
+  };
+  auto lstore_a = [&](auto S_, int buf) {
+    constexpr int S = decltype(S_)::value;
+    st2(&As[buf][0][lkc][so], ra[S].x, ra[S].z, rmask[S]);
+    st2(&As[buf][1][lkc][so], ra[S].y, ra[S].w, rmask[S]);
+  };
+  auto lstore_b = [&](auto S_, int buf, int i0, int i1) {
+    constexpr int S = decltype(S_)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i >= i0 && i < i1) {
+        st2(&Bs[buf][0][lkc][so + 128 * i], rb[S][i].x, rb[S][i].z, rmask[S]);
+        st2(&Bs[buf][1][lkc][so + 128 * i], rb[S][i].y, rb[S][i].w, rmask[S]);
+      }
+  };
+  const int fa = (wm * 32 + l31) * 2, fb = (wn * 128 + l31) * 2;
   const int nk = (D + SQ_BK - 1) / SQ_BK;
-  if (t0 < t1) { set_tile(t0); gload(0); }
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (t0 < t1) { set_tile(t0); gload(I0{}, 0, 2); }
   for (int tn = t0; tn < t1; ++tn) {
     const int col0 = tn * SQ_TN;
     f32x16 acc[4];
@@ -215,64 +249,78 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // One wave keeps the matrix pipe busy on its own: every k-tile is two phases of 16 MFMAs (64 cycles each), and everything
-    // else is issued in their shadow -- phase 1 multiplies the k-tile's first half while the second half's fragments are
-    // read and the NEXT k-tile (in registers since the previous phase 2) is written to the other LDS buffer; the barrier
-    // sits between the phases, where the second half's operands are already in registers; phase 2 multiplies the second
-    // half while the next k-tile's first-half fragments are read and the k-tile after that is fetched from global memory.
-    // (Before: reads, 32 MFMAs, writes, barrier in sequence -- the two waves of a SIMD fell into step and idled together.)
-    float4 a0, b0[4], a1, b1[4];
-    auto frag = [&](int buf, int half, float4& a, float4 (&b)[4]) {
-      a = *reinterpret_cast<const float4*>(&As[buf][kh][half][fa]);
+    // The k-loop keeps the matrix pipe fed from ONE wave: a k-tile is four phases of 8 MFMAs (64 cycles each), and everything
+    // else is issued in their shadow.  Phase q multiplies quarter q while quarter q + 1's fragments are read (phase 3: the
+    // next k-tile's quarter 0 from the other buffer); phases 0 / 1 write the NEXT k-tile (staged in registers since the
+    // iteration before last) to the other buffer, phase 2 refills those registers with the k-tile three ahead; the one
+    // barrier per k-tile sits between phases 2 and 3, where phase 3's operands are already on their way.
+    // (Before round 6: reads, 32 MFMAs, writes, barrier in sequence -- the two waves of a SIMD fell into step and idled together.)
+    float2 fa_[2], fb_[2][4];                      // fragment double buffer: [phase parity]
+    auto frag = [&](auto F_, int buf, int qd) {
+      constexpr int F = decltype(F_)::value;
+      fa_[F] = *reinterpret_cast<const float2*>(&As[buf][kh][qd][fa]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[buf][kh][half][fb + 128 * j]);
+      for (int j = 0; j < 4; ++j) fb_[F][j] = *reinterpret_cast<const float2*>(&Bs[buf][kh][qd][fb + 64 * j]);
     };
-    auto mma16 = [&](const float4& a, const float4 (&b)[4]) {      // steps in k order: 4 half + s4 multiplies k = 2 step + kh
-      const float av[4] = {a.x, a.y, a.z, a.w};
+    auto mma8 = [&](auto F_) {                     // steps in k order: step 2 q + e multiplies k = 2 step + kh
+      constexpr int F = decltype(F_)::value;
+      if constexpr (ABL & 32) return;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[F].x, fb_[F][j].x, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float bv[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4], bv[s4], acc[j], 0, 0, 0);
-        }
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[F].y, fb_[F][j].y, acc[j], 0, 0, 0);
+    };
+    // one MFMA, then up to `n` instructions of class `mask` (0x100 DS read, 0x200 DS write, 0x020 VMEM read), 8 MFMAs in all
+#define CREID_SQ_PHASE(sync, n1, m1, n2, m2, c2)                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < n1; ++i_) {                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, sync); __builtin_amdgcn_sched_group_barrier(m1, 1, sync); }  \
+    _Pragma("unroll") for (int i_ = 0; i_ < n2; ++i_) {                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, sync); __builtin_amdgcn_sched_group_barrier(m2, c2, sync); } \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 - n1 - n2, sync);                                          \
+    __builtin_amdgcn_sched_barrier(0)
+    auto body = [&](auto P_, int t) {              // k-tile t in buffer P = t & 1; stages k-tile t + 1, fetches k-tile t + 3
+      constexpr int P = decltype(P_)::value;
+      using SS = std::integral_constant<int, P ^ 1>;                // the register set that holds k-tile t + 1
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(ABL & 16)) frag(I1{}, P, 1);
+      if constexpr (!(ABL & 8)) { lstore_a(SS{}, P ^ 1); lstore_b(SS{}, P ^ 1, 0, 2); }
+      mma8(I0{});
+      CREID_SQ_PHASE(0, 5, 0x100, 3, 0x200, 2);
+      if constexpr (!(ABL & 16)) frag(I0{}, P, 2);
+      if constexpr (!(ABL & 8)) lstore_b(SS{}, P ^ 1, 2, 4);
+      mma8(I1{});
+      CREID_SQ_PHASE(1, 5, 0x100, 2, 0x200, 2);
+      if constexpr (!(ABL & 16)) frag(I1{}, P, 3);
+      if constexpr (!(ABL & 2)) gload(SS{}, (ABL & 64) ? (t & 1) * SQ_BK : (t + 3) * SQ_BK, 0);
+      mma8(I0{});
+      CREID_SQ_PHASE(2, 5, 0x100, 3, 0x020, 1);    // one global load per MFMA gap: a VMEM issue is ~40-60 cycles of the SIMD's issue
+      if constexpr (!(ABL & 4)) __syncthreads();   // port, hidden only under the 64 cycles of the wave's own MFMA just before it
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(ABL & 16)) frag(I0{}, P ^ 1, 0);
+      if constexpr (!(ABL & 2)) gload(SS{}, (ABL & 64) ? (t & 1) * SQ_BK : (t + 3) * SQ_BK, 1);
+      mma8(I1{});
+      CREID_SQ_PHASE(3, 5, 0x100, 2, 0x020, 1);
+    };
+#undef CREID_SQ_PHASE
+    auto last = [&](int buf) {                     // the tile's last k-tile: nothing left to stage
+      frag(I1{}, buf, 1); mma8(I0{});
+      frag(I0{}, buf, 2); mma8(I1{});
+      frag(I1{}, buf, 3); mma8(I0{});
+      mma8(I1{});
     };
     __syncthreads();                               // previous tile's readers are done with both LDS buffers
-    lstore(0);                                     // k-tile 0 was fetched during the previous tile's epilogue
+    lstore_a(I0{}, 0); lstore_b(I0{}, 0, 0, 4);    // k-tile 0 was fetched during the previous tile's epilogue
     __syncthreads();
-    gload(SQ_BK);                                  // k-tile 1 (zeros when there is none)
-    frag(0, 0, a0, b0);
-    for (int t = 0; t + 1 < nk; ++t) {
-      const int buf = t & 1;
-      __builtin_amdgcn_sched_barrier(0);
-      frag(buf, 1, a1, b1);
-      lstore(buf ^ 1);
-      mma16(a0, b0);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-#pragma unroll
-      for (int i = 0; i < 10; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      gload((t + 2) * SQ_BK);
-      frag(buf ^ 1, 0, a0, b0);
-      mma16(a1, b1);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x020, 1, 1); }
-#pragma unroll
-      for (int i = 0; i < 5; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    {                                              // last k-tile: nothing left to stage
-      frag((nk - 1) & 1, 1, a1, b1);
-      mma16(a0, b0);
-      mma16(a1, b1);
-    }
-    if (tn + 1 < t1) { set_tile(tn + 1); gload(0); }               // flies while the epilogue runs
+    gload(I1{}, SQ_BK, 2);                         // k-tiles 1 and 2 (zeros when there are none)
+    gload(I0{}, 2 * SQ_BK, 2);
+    frag(I0{}, 0, 0);
+    int t = 0;
+    for (; t + 2 < nk; t += 2) { body(I0{}, t); body(I1{}, t + 1); }
+    if (t + 2 == nk) { body(I0{}, t); last(1); } else last(0);
+    if (tn + 1 < t1) { set_tile(tn + 1); gload(I0{}, 0, 2); }               // flies while the epilogue runs
     // ---- epilogue: the tile is consumed here (row-major walk: the row's metadata is read once per 4 columns)
+    int rbase = wm * 32 + 4 * kh;                  // opaque per tile: the 16 rows' LDS addresses derived from it are recomputed here
+    asm volatile("" : "+v"(rbase));                // instead of living in registers (or scratch) across the k-loop
     float gv[4];
     long long gp[4];
     bool okc[4];
@@ -293,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
       const unsigned* K[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        rl[h] = wm * 32 + ((r + h) & 3) + 8 * ((r + h) >> 2) + 4 * kh;
-        np[h] = skip_count ? 0 : s_np[rl[h]];
+        rl[h] = rbase + ((r + h) & 3) + 8 * ((r + h) >> 2);
+        np[h] = (skip_count & 1) ? 0 : s_np[rl[h]];
         const long long qp = s_qpid[rl[h]];
         const float qv = s_qq[rl[h]];
         const unsigned kmax = s_kmax[rl[h]];
@@ -323,7 +371,9 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
           if (live[h][j]) {
             if (l < np[h] && K[h][l] == key[h][j]) {               // ties: by gallery index (rare)
               const int c = col0 + wn * 128 + j * 32 + l31;
-              while (l < np[h] && K[h][l] == key[h][j] && pos_idx[(int64_t)(row0 + rl[h]) * cap + l] < c) ++l;
+              int rr_ = row0 + rl[h];
+              asm volatile("" : "+v"(rr_));                        // keeps 16 rows' index pointers out of the k-loop's registers
+              while (l < np[h] && K[h][l] == key[h][j] && pos_idx[(int64_t)rr_ * cap + l] < c) ++l;
             }
             if (l < np[h]) atomicAdd(&s_hist[(rl[h] << log2cap) + l], 1u);
           }
@@ -509,13 +559,36 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
   const int t_per = (tiles_n + nsplit - 1) / nsplit;
   nsplit = (tiles_n + t_per - 1) / t_per;                       // drop empty slices
   const size_t dyn = (size_t)2 * SQ_TM * cap * sizeof(unsigned);
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sqdist_count_f32_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        2 * SQ_TM * PL_MAXC * (int)sizeof(unsigned));
-  if (attr_rc != hipSuccess) return (int)attr_rc;
-  hipLaunchKernelGGL(sqdist_count_f32_kernel, dim3((unsigned)(tiles_m * nsplit)), dim3(256), dyn, as_stream(stream), q, g, qq,
-                     gg, (int)m, (int)n, (int)D, q_pids, g_pids, (int)cap, log2cap, pos_key, pos_idx, npos, hist, tiles_m,
-                     tiles_n, nsplit, skip_count);
+#define CREID_COUNT_LAUNCH_(A, F)                                                                                     \
+  do {                                                                                                                 \
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sqdist_count_f32_kernel<A, F>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                                                          2 * SQ_TM * PL_MAXC * (int)sizeof(unsigned));                \
+    if (attr_rc != hipSuccess) return (int)attr_rc;                                                                    \
+    hipLaunchKernelGGL((sqdist_count_f32_kernel<A, F>), dim3((unsigned)(tiles_m * nsplit)), dim3(256), dyn, as_stream(stream), \
+                       q, g, qq, gg, (int)m, (int)n, (int)D, q_pids, g_pids, (int)cap, log2cap, pos_key, pos_idx, npos, hist,  \
+                       tiles_m, tiles_n, nsplit, skip_count & 1);                                                      \
+  } while (0)
+#define CREID_COUNT_LAUNCH(A)                                                                                          \
+  do { if (D % SQ_BK == 0) CREID_COUNT_LAUNCH_(A, true); else CREID_COUNT_LAUNCH_(0, false); } while (0)
+#ifdef CREID_ABL_BUILD
+  switch (skip_count >> 1) {
+    case 1: CREID_COUNT_LAUNCH(2); break;
+    case 2: CREID_COUNT_LAUNCH(4); break;
+    case 3: CREID_COUNT_LAUNCH(6); break;
+    case 4: CREID_COUNT_LAUNCH(8); break;
+    case 7: CREID_COUNT_LAUNCH(14); break;
+    case 8: CREID_COUNT_LAUNCH(16); break;
+    case 15: CREID_COUNT_LAUNCH(30); break;
+    case 16: CREID_COUNT_LAUNCH(32); break;
+    case 32: CREID_COUNT_LAUNCH(64); break;
+    default: CREID_COUNT_LAUNCH(0); break;
+  }
+#else
+  CREID_COUNT_LAUNCH(0);
+#endif
+#undef CREID_COUNT_LAUNCH
+#undef CREID_COUNT_LAUNCH_
   CREID_LAUNCH_RET();
 }
 

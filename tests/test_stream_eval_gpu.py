@@ -50,7 +50,8 @@ def test_streamed_matches_reference_goldens(golden, name):
 
 
 @pytest.mark.parametrize("nq,ng,D,npid,ncam,dup", [(300, 3000, 256, 60, 3, True), (70, 513, 100, 9, 2, False),
-                                                    (129, 1000, 2048, 400, 5, True), (5, 40, 32, 3, 2, False)])
+                                                    (129, 1000, 2048, 400, 5, True), (5, 40, 32, 3, 2, False),
+                                                    (33, 300, 8, 5, 2, False), (33, 700, 20, 7, 3, True), (64, 512, 48, 9, 2, False)])
 def test_streamed_equals_materialised_random(nq, ng, D, npid, ncam, dup):
     """N(0,1) features (dense near-ties in fp32), duplicated gallery rows (exact ties -> order by gallery index),
     queries whose pid is absent from the gallery or whose positives all share their camera."""
