@@ -134,12 +134,25 @@ __global__ __launch_bounds__(PL_MAXC) void stream_poslist_kernel(
 // ----------------------------------------------------------------------------------------
 // ABL: timing ablations of the k-loop (ablation build only; results wrong): 2 no global loads, 4 no barrier, 8 no LDS writes,
 // 16 no fragment reads, 32 no MFMAs inside the loop, 64 global loads always from k-tiles 0 / 1 (cache-hot).
+//
+// Work split.  A row of the problem is one 64-query tile against the whole gallery, measured in UNITS of 64 gallery columns
+// (U per row).  A workgroup owns a contiguous run of units and walks it in tiles of four units (256 columns); the last tile of a
+// run may be 1-3 units wide (NJ < 4: each wave then multiplies NJ of its four 32-column blocks -- the blocks are dealt to the
+// two column waves alternately, so a narrow tile costs NJ / 4 of a full one).
+//   mode 0 (galleries beyond the Infinity Cache): per row `nsplit` runs of `upw` units, ids split-major, so the workgroups that
+//          share an L2 walk the SAME gallery tiles at the same time (6250 x 200 000: 0.80 of the MFMA peak against 0.68 with
+//          every workgroup streaming its own gallery range);
+//   mode 1 (the gallery fits the Infinity Cache -- DukeMTMC 145 MB, 3000 x 15000 123 MB): the rows' units laid end to end and cut
+//          into gridDim.x EQUAL runs (a run may end one row and begin the next): every resident slot gets the same number of
+//          units, where per-row splitting left 2228 x 17661 at 5 tile-times for 4.72 tiles of work per slot (and 3000 x 15000 at
+//          6 for 5.42).  Measured without the gallery sharing of mode 0: no loss at these sizes (profiles/r06_eval_kloop.md).
+// (!FULLK -- a feature width that is not a multiple of 16 -- carries the zero-fill masks on top and runs one workgroup per CU.)
 template <int ABL, bool FULLK>
-__global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
+__global__ __launch_bounds__(256, FULLK ? 2 : 1) void sqdist_count_f32_kernel(
     const float* __restrict__ q, const float* __restrict__ g, const float* __restrict__ qq, const float* __restrict__ gg,
     int m, int n, int D, const int64_t* __restrict__ q_pids, const int64_t* __restrict__ g_pids, int cap, int log2cap,
     const unsigned* __restrict__ pos_key, const int32_t* __restrict__ pos_idx, const int32_t* __restrict__ npos,
-    unsigned* __restrict__ hist_out, int tiles_m, int tiles_n, int nsplit, int skip_count) {
+    unsigned* __restrict__ hist_out, int tiles_m, int U, int upw, int mode, int skip_count) {
   __shared__ __attribute__((aligned(16))) float As[2][2][4][SQ_PA];
   __shared__ __attribute__((aligned(16))) float Bs[2][2][4][SQ_PB];
   __shared__ float s_qq[SQ_TM];
@@ -152,51 +165,44 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, kh = lane >> 5;
-  // XCD-aware order: consecutive ids land on different XCDs; give every XCD a contiguous run of (split, tile_m)
-  // pairs with the split major, so the workgroups sharing an L2 walk the SAME gallery tiles at the same time.
+  // XCD-aware order: consecutive ids land on different XCDs; every XCD gets a contiguous run of ids
   int bid = blockIdx.x;
   {
     const int nwg = gridDim.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     bid = base + (bid >> 3);
   }
-  const int split = bid / tiles_m, tile_m = bid - split * tiles_m;
-  const int row0 = tile_m * SQ_TM;
-  const int t_per = (tiles_n + nsplit - 1) / nsplit;
-  const int t0 = split * t_per, t1 = min(t0 + t_per, tiles_n);
-
-  for (int i = tid; i < SQ_TM * cap; i += 256) {
-    const int r = i >> log2cap, rr = row0 + r;
-    s_keys[i] = rr < m ? pos_key[(int64_t)rr * cap + (i & (cap - 1))] : 0xffffffffu;
-    s_hist[i] = 0u;
-  }
-  if (tid < SQ_TM) {
-    const int rr = row0 + tid;
-    const int np = rr < m ? npos[rr] : 0;
-    s_np[tid] = np > 0 ? np : 0;
-    s_qq[tid] = rr < m ? qq[rr] : 0.f;
-    s_qpid[tid] = rr < m ? (long long)q_pids[rr] : 0;
-    s_kmax[tid] = np > 0 ? pos_key[(int64_t)rr * cap + np - 1] : 0u;
+  long long g0, g1;                              // this workgroup's run, in units of the rows laid end to end
+  if (mode == 0) {
+    const int split = bid / tiles_m, tile_m = bid - split * tiles_m;
+    const int u0 = split * upw;
+    g0 = (long long)tile_m * U + u0;
+    g1 = (long long)tile_m * U + min(U, u0 + upw);
+  } else {
+    const long long T = (long long)tiles_m * U;
+    g0 = bid * T / gridDim.x;
+    g1 = (bid + 1) * T / gridDim.x;
   }
 
   const int lrow = tid >> 2, lkc = tid & 3;
   // Staging addresses: one wave-uniform base per operand (SGPRs; the k advance is scalar arithmetic) + a 32-bit byte offset per
   // lane and row (clamped rows: at most 256 rows x D floats from the base), so a k-tile's fetch costs no vector ALU work.
-  const char* abase = reinterpret_cast<const char*>(q + (int64_t)min(row0, m - 1) * D);
-  const unsigned aoff = (unsigned)(min(row0 + lrow, m - 1) - min(row0, m - 1)) * (unsigned)D * 4u + 16u * lkc;
+  const char* abase = nullptr;
+  unsigned aoff = 0u;
   const char* bbase = nullptr;
   unsigned boff[4];
   // Two register sets of staged k-tiles: a k-tile is fetched ~1.5 k-tiles before it is written to LDS.
   float4 ra[2], rb[2][4];
   unsigned rmask[2] = {0u, 0u};                    // !FULLK: all ones while the staged k-tile lies inside D
-  auto set_tile = [&](int tn) {
-    const int c0 = min(tn * SQ_TN, n - 1);
+  auto set_tile = [&](int col0) {
+    const int c0 = min(col0, n - 1);
     bbase = reinterpret_cast<const char*>(g + (int64_t)c0 * D);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) boff[i] = (unsigned)(min(tn * SQ_TN + lrow + 64 * i, n - 1) - c0) * (unsigned)D * 4u + 16u * lkc;
+    for (int i = 0; i < 4; ++i) boff[i] = (unsigned)(min(col0 + lrow + 64 * i, n - 1) - c0) * (unsigned)D * 4u + 16u * lkc;
   };
-  // part 0: the query row and gallery rows 0 / 1; part 1: gallery rows 2 / 3; part 2: all five (k0 is wave-uniform; branch-free)
-  auto gload = [&](auto S_, int k0, int part) {
+  // part 0: the query row and gallery row groups 0 / 1; part 1: groups 2 / 3; part 2: all five; groups >= nj are not fetched
+  // (k0 is wave-uniform; branch-free)
+  auto gload = [&](auto S_, int k0, int part, int nj) {
     constexpr int S = decltype(S_)::value;
     const int ko = k0 < D ? k0 : 0;                // a k-tile beyond D (the pipeline fetches up to three ahead) reads k-tile 0
     if constexpr (FULLK) {
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
       if (part != 1) ra[S] = *reinterpret_cast<const float4*>(ab + aoff);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (part == 2 || (i >> 1) == part) rb[S][i] = *reinterpret_cast<const float4*>(bb + boff[i]);
+        if (i < nj && (part == 2 || (i >> 1) == part)) rb[S][i] = *reinterpret_cast<const float4*>(bb + boff[i]);
     } else {                                       // ... and a lane whose 16 bytes lie beyond D reads its row's first 16 bytes;
       const bool in = k0 + 4 * lkc < D;            // lstore writes zeros for both
       rmask[S] = in ? 0xffffffffu : 0u;
@@ -213,13 +219,11 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
       if (part != 1) ra[S] = *reinterpret_cast<const float4*>(abase + (aoff + lo));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (part == 2 || (i >> 1) == part) rb[S][i] = *reinterpret_cast<const float4*>(bbase + (boff[i] + lo));
+        if (i < nj && (part == 2 || (i >> 1) == part)) rb[S][i] = *reinterpret_cast<const float4*>(bbase + (boff[i] + lo));
     }
   };
   const int so = lrow * 2;                         // global k = 4 lkc + {0..3}: quarter lkc, steps 2 lkc and 2 lkc + 1
-  // (x, z) -> kh 0 and (y, w) -> kh 1 as two 4-byte stores each: the compiler emits ds_write2_b32 straight from the load's
-  // registers (an 8-byte store would need the pair copied into adjacent registers first)
-  auto st2 = [&](float* p, float v0, float v1, unsigned mask) {
+  auto st2 = [&](float* p, float v0, float v1, unsigned mask) {    // (x, z) -> kh 0, (y, w) -> kh 1
     if constexpr (FULLK) { p[0] = v0; p[1] = v1; }
     else { p[0] = __uint_as_float(__float_as_uint(v0) & mask); p[1] = __uint_as_float(__float_as_uint(v1) & mask); }
   };
@@ -237,107 +241,125 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
         st2(&Bs[buf][1][lkc][so + 128 * i], rb[S][i].y, rb[S][i].w, rmask[S]);
       }
   };
-  const int fa = (wm * 32 + l31) * 2, fb = (wn * 128 + l31) * 2;
+  // wave wn multiplies the 32-column blocks wn, wn + 2, wn + 4, wn + 6 of the tile (block b = gallery rows 32 b .. 32 b + 31)
+  const int fa = (wm * 32 + l31) * 2, fb = (wn * 32 + l31) * 2;
   const int nk = (D + SQ_BK - 1) / SQ_BK;
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  if (t0 < t1) { set_tile(t0); gload(I0{}, 0, 2); }
-  for (int tn = t0; tn < t1; ++tn) {
-    const int col0 = tn * SQ_TN;
-    f32x16 acc[4];
+  int row0 = 0;
+
+  // ---- one tile of NJ units at column col0; `next` >= 0: the following tile's column (its k-tile 0 is fetched under the epilogue)
+  auto tile = [&](auto NJ_, int col0, int next) {
+    constexpr int NJ = decltype(NJ_)::value;
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // The k-loop keeps the matrix pipe fed from ONE wave: a k-tile is four phases of 8 MFMAs (64 cycles each), and everything
+    // The k-loop keeps the matrix pipe fed from ONE wave: a k-tile is four phases of 2 NJ MFMAs (64 cycles each), and everything
     // else is issued in their shadow.  Phase q multiplies quarter q while quarter q + 1's fragments are read (phase 3: the
     // next k-tile's quarter 0 from the other buffer); phases 0 / 1 write the NEXT k-tile (staged in registers since the
-    // iteration before last) to the other buffer, phase 2 refills those registers with the k-tile three ahead; the one
-    // barrier per k-tile sits between phases 2 and 3, where phase 3's operands are already on their way.
-    // (Before round 6: reads, 32 MFMAs, writes, barrier in sequence -- the two waves of a SIMD fell into step and idled together.)
-    float2 fa_[2], fb_[2][4];                      // fragment double buffer: [phase parity]
+    // iteration before last) to the other buffer, phases 2 / 3 refill those registers with the k-tile three ahead -- one global
+    // load per MFMA gap: a VMEM issue holds the SIMD's issue port for ~40-60 cycles, hidden only under the 64 cycles of the
+    // wave's own MFMA just before it; the one barrier per k-tile sits between phases 2 and 3, where phase 3's operands are
+    // already on their way.  (Before round 6: reads, 32 MFMAs, writes, barrier in sequence -- the two waves of a SIMD fell into
+    // step and idled together: 0.667 of the MFMA peak on 2228 x 17661, 0.708 on 6250 x 200 000.)
+    float2 fa_[2], fb_[2][NJ];                     // fragment double buffer: [phase parity]
     auto frag = [&](auto F_, int buf, int qd) {
       constexpr int F = decltype(F_)::value;
       fa_[F] = *reinterpret_cast<const float2*>(&As[buf][kh][qd][fa]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb_[F][j] = *reinterpret_cast<const float2*>(&Bs[buf][kh][qd][fb + 64 * j]);
+      for (int j = 0; j < NJ; ++j) fb_[F][j] = *reinterpret_cast<const float2*>(&Bs[buf][kh][qd][fb + 128 * j]);
     };
-    auto mma8 = [&](auto F_) {                     // steps in k order: step 2 q + e multiplies k = 2 step + kh
+    auto mma = [&](auto F_) {                      // steps in k order: step 2 q + e multiplies k = 2 step + kh
       constexpr int F = decltype(F_)::value;
       if constexpr (ABL & 32) return;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[F].x, fb_[F][j].x, acc[j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[F].x, fb_[F][j].x, acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[F].y, fb_[F][j].y, acc[j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[F].y, fb_[F][j].y, acc[j], 0, 0, 0);
     };
-    // one MFMA, then up to `n` instructions of class `mask` (0x100 DS read, 0x200 DS write, 0x020 VMEM read), 8 MFMAs in all
-#define CREID_SQ_PHASE(sync, n1, m1, n2, m2, c2)                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < n1; ++i_) {                                                     \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, sync); __builtin_amdgcn_sched_group_barrier(m1, 1, sync); }  \
-    _Pragma("unroll") for (int i_ = 0; i_ < n2; ++i_) {                                                     \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, sync); __builtin_amdgcn_sched_group_barrier(m2, c2, sync); } \
-    __builtin_amdgcn_sched_group_barrier(0x008, 8 - n1 - n2, sync);                                          \
+    // Issue order inside a phase: nA MFMA gaps with cA instructions of class mA each, nB gaps with cB of class mB, the remaining
+    // MFMAs bare (0x100 DS read, 0x200 DS write, 0x020 VMEM read; a phase has 2 NJ MFMAs, 1 + NJ fragment reads).
+#define CREID_SQ_PHASE(sync, nA, mA, cA, nB, mB, cB)                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < nA; ++i_) {                                                         \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, sync); __builtin_amdgcn_sched_group_barrier(mA, cA, sync); }     \
+    _Pragma("unroll") for (int i_ = 0; i_ < nB; ++i_) {                                                         \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, sync); __builtin_amdgcn_sched_group_barrier(mB, cB, sync); }     \
+    if constexpr (2 * NJ - (nA) - (nB) > 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - (nA) - (nB), sync);   \
     __builtin_amdgcn_sched_barrier(0)
     auto body = [&](auto P_, int t) {              // k-tile t in buffer P = t & 1; stages k-tile t + 1, fetches k-tile t + 3
       constexpr int P = decltype(P_)::value;
       using SS = std::integral_constant<int, P ^ 1>;                // the register set that holds k-tile t + 1
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(ABL & 16)) frag(I1{}, P, 1);
-      if constexpr (!(ABL & 8)) { lstore_a(SS{}, P ^ 1); lstore_b(SS{}, P ^ 1, 0, 2); }
-      mma8(I0{});
-      CREID_SQ_PHASE(0, 5, 0x100, 3, 0x200, 2);
+      if constexpr (!(ABL & 8)) { lstore_a(SS{}, P ^ 1); lstore_b(SS{}, P ^ 1, 0, NJ < 2 ? NJ : 2); }
+      mma(I0{});
+      if constexpr (NJ == 4) { CREID_SQ_PHASE(0, 5, 0x100, 1, 3, 0x200, 2); }
+      else if constexpr (NJ == 3) { CREID_SQ_PHASE(0, 4, 0x100, 1, 2, 0x200, 3); }
+      else if constexpr (NJ == 2) { CREID_SQ_PHASE(0, 3, 0x100, 1, 1, 0x200, 6); }
+      else { CREID_SQ_PHASE(0, 1, 0x100, 2, 1, 0x200, 4); }
       if constexpr (!(ABL & 16)) frag(I0{}, P, 2);
-      if constexpr (!(ABL & 8)) lstore_b(SS{}, P ^ 1, 2, 4);
-      mma8(I1{});
-      CREID_SQ_PHASE(1, 5, 0x100, 2, 0x200, 2);
+      if constexpr (!(ABL & 8)) lstore_b(SS{}, P ^ 1, 2, NJ);
+      mma(I1{});
+      if constexpr (NJ == 4) { CREID_SQ_PHASE(1, 5, 0x100, 1, 2, 0x200, 2); }
+      else if constexpr (NJ == 3) { CREID_SQ_PHASE(1, 4, 0x100, 1, 1, 0x200, 2); }
+      else if constexpr (NJ == 2) { CREID_SQ_PHASE(1, 3, 0x100, 1, 0, 0x200, 1); }
+      else { CREID_SQ_PHASE(1, 2, 0x100, 1, 0, 0x200, 1); }
       if constexpr (!(ABL & 16)) frag(I1{}, P, 3);
-      if constexpr (!(ABL & 2)) gload(SS{}, (ABL & 64) ? (t & 1) * SQ_BK : (t + 3) * SQ_BK, 0);
-      mma8(I0{});
-      CREID_SQ_PHASE(2, 5, 0x100, 3, 0x020, 1);    // one global load per MFMA gap: a VMEM issue is ~40-60 cycles of the SIMD's issue
-      if constexpr (!(ABL & 4)) __syncthreads();   // port, hidden only under the 64 cycles of the wave's own MFMA just before it
+      if constexpr (!(ABL & 2)) gload(SS{}, (ABL & 64) ? (t & 1) * SQ_BK : (t + 3) * SQ_BK, 0, NJ);
+      mma(I0{});
+      if constexpr (NJ == 4) { CREID_SQ_PHASE(2, 5, 0x100, 1, 3, 0x020, 1); }
+      else if constexpr (NJ == 3) { CREID_SQ_PHASE(2, 2, 0x100, 2, 3, 0x020, 1); }
+      else if constexpr (NJ == 2) { CREID_SQ_PHASE(2, 1, 0x100, 3, 3, 0x020, 1); }
+      else { CREID_SQ_PHASE(2, 1, 0x100, 2, 1, 0x020, 2); }
+      if constexpr (!(ABL & 4)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(ABL & 16)) frag(I0{}, P ^ 1, 0);
-      if constexpr (!(ABL & 2)) gload(SS{}, (ABL & 64) ? (t & 1) * SQ_BK : (t + 3) * SQ_BK, 1);
-      mma8(I1{});
-      CREID_SQ_PHASE(3, 5, 0x100, 2, 0x020, 1);
+      if constexpr (!(ABL & 2)) gload(SS{}, (ABL & 64) ? (t & 1) * SQ_BK : (t + 3) * SQ_BK, 1, NJ);
+      mma(I1{});
+      if constexpr (NJ == 4) { CREID_SQ_PHASE(3, 5, 0x100, 1, 2, 0x020, 1); }
+      else if constexpr (NJ == 3) { CREID_SQ_PHASE(3, 4, 0x100, 1, 1, 0x020, 1); }
+      else if constexpr (NJ == 2) { CREID_SQ_PHASE(3, 3, 0x100, 1, 0, 0x020, 1); }
+      else { CREID_SQ_PHASE(3, 2, 0x100, 1, 0, 0x020, 1); }
     };
 #undef CREID_SQ_PHASE
     auto last = [&](int buf) {                     // the tile's last k-tile: nothing left to stage
-      frag(I1{}, buf, 1); mma8(I0{});
-      frag(I0{}, buf, 2); mma8(I1{});
-      frag(I1{}, buf, 3); mma8(I0{});
-      mma8(I1{});
+      frag(I1{}, buf, 1); mma(I0{});
+      frag(I0{}, buf, 2); mma(I1{});
+      frag(I1{}, buf, 3); mma(I0{});
+      mma(I1{});
     };
     __syncthreads();                               // previous tile's readers are done with both LDS buffers
-    lstore_a(I0{}, 0); lstore_b(I0{}, 0, 0, 4);    // k-tile 0 was fetched during the previous tile's epilogue
+    lstore_a(I0{}, 0); lstore_b(I0{}, 0, 0, NJ);   // k-tile 0 was fetched during the previous tile's epilogue
     __syncthreads();
-    gload(I1{}, SQ_BK, 2);                         // k-tiles 1 and 2 (zeros when there are none)
-    gload(I0{}, 2 * SQ_BK, 2);
+    gload(I1{}, SQ_BK, 2, NJ);                     // k-tiles 1 and 2 (zeros when there are none)
+    gload(I0{}, 2 * SQ_BK, 2, NJ);
     frag(I0{}, 0, 0);
     int t = 0;
     for (; t + 2 < nk; t += 2) { body(I0{}, t); body(I1{}, t + 1); }
     if (t + 2 == nk) { body(I0{}, t); last(1); } else last(0);
-    if (tn + 1 < t1) { set_tile(tn + 1); gload(I0{}, 0, 2); }               // flies while the epilogue runs
-    // ---- epilogue: the tile is consumed here (row-major walk: the row's metadata is read once per 4 columns)
+    if (next >= 0) { set_tile(next); gload(I0{}, 0, 2, 4); }        // flies while the epilogue runs
+    // ---- epilogue: the tile is consumed here (row-major walk: the row's metadata is read once per NJ columns)
     int rbase = wm * 32 + 4 * kh;                  // opaque per tile: the 16 rows' LDS addresses derived from it are recomputed here
     asm volatile("" : "+v"(rbase));                // instead of living in registers (or scratch) across the k-loop
-    float gv[4];
-    long long gp[4];
-    bool okc[4];
+    float gv[NJ];
+    long long gp[NJ];
+    bool okc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = col0 + wn * 128 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+      const int c = col0 + (wn + 2 * j) * 32 + l31;
       okc[j] = c < n;
       gv[j] = okc[j] ? gg[c] : 0.f;
       gp[j] = okc[j] ? (long long)g_pids[c] : 0;
     }
-    // Two accumulator rows x four column blocks = 8 binary searches in flight per lane: the search is a chain of
+    // Two accumulator rows x NJ column blocks = 2 NJ binary searches in flight per lane: the search is a chain of
     // dependent LDS reads (~100 cycles each), so it is the number of INDEPENDENT chains that sets the epilogue time.
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      int rl[2], np[2], lo[2][4];
-      unsigned key[2][4];
-      bool live[2][4];
+      int rl[2], np[2], lo[2][NJ];
+      unsigned key[2][NJ];
+      bool live[2][NJ];
       const unsigned* K[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -348,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
         const unsigned kmax = s_kmax[rl[h]];
         K[h] = s_keys + (rl[h] << log2cap);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           key[h][j] = mono_key(fmaf(-2.0f, acc[j][r + h], qv + gv[j]));
           // positives / removed entries (same pid) are not counted; behind every positive: affects no rank
           live[h][j] = np[h] > 0 && okc[j] && gp[j] != qp && key[h][j] <= kmax;
@@ -360,17 +382,17 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) lo[h][j] += (K[h][lo[h][j] + step - 1] < key[h][j]) ? step : 0;
+          for (int j = 0; j < NJ; ++j) lo[h][j] += (K[h][lo[h][j] + step - 1] < key[h][j]) ? step : 0;
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           int l = lo[h][j];
           l += (K[h][l] < key[h][j]) ? 1 : 0;                      // l = #positives with key strictly below
           if (live[h][j]) {
             if (l < np[h] && K[h][l] == key[h][j]) {               // ties: by gallery index (rare)
-              const int c = col0 + wn * 128 + j * 32 + l31;
+              const int c = col0 + (wn + 2 * j) * 32 + l31;
               int rr_ = row0 + rl[h];
               asm volatile("" : "+v"(rr_));                        // keeps 16 rows' index pointers out of the k-loop's registers
               while (l < np[h] && K[h][l] == key[h][j] && pos_idx[(int64_t)rr_ * cap + l] < c) ++l;
@@ -379,12 +401,49 @@ __global__ __launch_bounds__(256, 2) void sqdist_count_f32_kernel(
           }
         }
     }
-  }
-  __syncthreads();
-  for (int i = tid; i < SQ_TM * cap; i += 256) {
-    const unsigned v = s_hist[i];
-    const int rr = row0 + (i >> log2cap);
-    if (v && rr < m) atomicAdd(&hist_out[(int64_t)rr * cap + (i & (cap - 1))], v);      // integer: order-independent
+  };
+
+  while (g0 < g1) {                               // the run's segments: one per row it touches
+    const int row = (int)(g0 / U), u0 = (int)(g0 - (long long)row * U);
+    const int u1 = (int)min((long long)U, u0 + (g1 - g0));
+    g0 += u1 - u0;
+    row0 = row * SQ_TM;
+    __syncthreads();                               // the previous segment's histogram has been flushed
+    int ts = tid;                                  // opaque: the set-up's LDS addresses are recomputed per segment instead of
+    asm volatile("" : "+v"(ts));                   // occupying registers (or scratch) across the k-loops
+    for (int i = ts; i < SQ_TM * cap; i += 256) {
+      const int r = i >> log2cap, rr = row0 + r;
+      s_keys[i] = rr < m ? pos_key[(int64_t)rr * cap + (i & (cap - 1))] : 0xffffffffu;
+      s_hist[i] = 0u;
+    }
+    if (ts < SQ_TM) {
+      const int rr = row0 + ts;
+      const int np = rr < m ? npos[rr] : 0;
+      s_np[ts] = np > 0 ? np : 0;
+      s_qq[ts] = rr < m ? qq[rr] : 0.f;
+      s_qpid[ts] = rr < m ? (long long)q_pids[rr] : 0;
+      s_kmax[ts] = np > 0 ? pos_key[(int64_t)rr * cap + np - 1] : 0u;
+    }
+    abase = reinterpret_cast<const char*>(q + (int64_t)min(row0, m - 1) * D);
+    aoff = (unsigned)(min(row0 + lrow, m - 1) - min(row0, m - 1)) * (unsigned)D * 4u + 16u * lkc;
+    const int cend = u1 * 64;
+    int col = u0 * 64;
+    set_tile(col);
+    gload(I0{}, 0, 2, 4);
+    while (col < cend) {
+      const int nj = min(4, (cend - col) >> 6), next = col + 256 < cend ? col + 256 : -1;
+      if (nj == 4) tile(std::integral_constant<int, 4>{}, col, next);
+      else if (nj == 3) tile(std::integral_constant<int, 3>{}, col, next);
+      else if (nj == 2) tile(std::integral_constant<int, 2>{}, col, next);
+      else tile(std::integral_constant<int, 1>{}, col, next);
+      col += 256;
+    }
+    __syncthreads();
+    for (int i = ts; i < SQ_TM * cap; i += 256) {
+      const unsigned v = s_hist[i];
+      const int rr = row0 + (i >> log2cap);
+      if (v && rr < m) atomicAdd(&hist_out[(int64_t)rr * cap + (i & (cap - 1))], v);      // integer: order-independent
+    }
   }
 }
 
@@ -543,11 +602,12 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
   int log2cap = 0;
   while ((1 << log2cap) < cap) ++log2cap;
   const int tiles_m = (int)((m + SQ_TM - 1) / SQ_TM), tiles_n = (int)((n + SQ_TN - 1) / SQ_TN);
+  const int U = (int)((n + 63) / 64);                           // units of 64 gallery columns per row of query tiles
   // enough workgroups for two per CU, but never fewer than ~4 gallery tiles per workgroup (per-tile restart cost)
   static const int target = [] { const char* e = getenv("CREID_STREAM_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   // timing ablation only (CREID_STREAM_NOEPI=1: contraction without the count epilogue -- results are then wrong)
   static const int skip_count = creid_ablation_env("CREID_STREAM_NOEPI");
-  // ... and never MORE than `tper_max` gallery tiles per workgroup: the grid overshoots the 512 slots by up to tiles_m - 1
+  // mode 0: never MORE than `tper_max` gallery tiles per workgroup: the grid overshoots the 512 slots by up to tiles_m - 1
   // workgroups, which start when the first ones finish -- harmless when a workgroup is 5 tiles long, a whole second round on an
   // idle chip when it is 131 (6250 x 200 000: 588 workgroups, 66.0 ms; with <= 8 tiles per workgroup 46.1 ms; HBM-side traffic by
   // the counters the same under both rules -- profiles/r05_stream_grid.md)
@@ -558,6 +618,20 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
   if (nsplit < 1) nsplit = 1;
   const int t_per = (tiles_n + nsplit - 1) / nsplit;
   nsplit = (tiles_n + t_per - 1) / t_per;                       // drop empty slices
+  // mode 1 (equal runs of units over the resident slots): only while the gallery fits the Infinity Cache beside the queries, the
+  // grid of mode 0 is a single round, and the equal run is shorter than mode 0's longest workgroup by more than the narrow tile
+  // and the second segment cost (~a quarter tile: 2228 x 17661 -- 4.75 tiles against 5 -- measured EQUAL in both modes,
+  // 3000 x 15000 -- 5.5 against 6 -- 5.6 % faster in mode 1; profiles/r06_eval_kloop.md).  CREID_STREAM_BALANCE=0 / 1 forces a
+  // mode (the tests run both).
+  const long long T = (long long)tiles_m * U;
+  const long long wg1 = T / 4 < target ? (T / 4 > 0 ? T / 4 : 1) : target;
+  const char* bal_e = CREID_KNOB_ENV("CREID_STREAM_BALANCE");
+  const int bal = (bal_e && *bal_e) ? atoi(bal_e) : -1;
+  const double run1 = (double)((T + wg1 - 1) / wg1) / 4.0 + 0.3;
+  const int mode = bal >= 0 ? (bal != 0)
+                            : ((double)n * (double)D * 4.0 <= 192e6 && (long long)tiles_m * nsplit <= target && run1 < (double)t_per);
+  const int upw = 4 * t_per;
+  const unsigned grid = mode == 0 ? (unsigned)(tiles_m * nsplit) : (unsigned)wg1;
   const size_t dyn = (size_t)2 * SQ_TM * cap * sizeof(unsigned);
 #define CREID_COUNT_LAUNCH_(A, F)                                                                                     \
   do {                                                                                                                 \
@@ -565,9 +639,9 @@ int creid_stream_count(const float* q, const float* g, const float* qq, const fl
                                                           hipFuncAttributeMaxDynamicSharedMemorySize,                  \
                                                           2 * SQ_TM * PL_MAXC * (int)sizeof(unsigned));                \
     if (attr_rc != hipSuccess) return (int)attr_rc;                                                                    \
-    hipLaunchKernelGGL((sqdist_count_f32_kernel<A, F>), dim3((unsigned)(tiles_m * nsplit)), dim3(256), dyn, as_stream(stream), \
+    hipLaunchKernelGGL((sqdist_count_f32_kernel<A, F>), dim3(grid), dim3(256), dyn, as_stream(stream),                 \
                        q, g, qq, gg, (int)m, (int)n, (int)D, q_pids, g_pids, (int)cap, log2cap, pos_key, pos_idx, npos, hist,  \
-                       tiles_m, tiles_n, nsplit, skip_count & 1);                                                      \
+                       tiles_m, U, upw, mode, skip_count & 1);                                                         \
   } while (0)
 #define CREID_COUNT_LAUNCH(A)                                                                                          \
   do { if (D % SQ_BK == 0) CREID_COUNT_LAUNCH_(A, true); else CREID_COUNT_LAUNCH_(0, false); } while (0)

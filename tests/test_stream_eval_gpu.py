@@ -36,8 +36,16 @@ def _assert_same(a, ra, b, rb, pids, cams, nq):
     np.testing.assert_allclose(b.last["single_performance"], a.last["single_performance"], rtol=0, atol=1e-12)
 
 
+@pytest.fixture(params=["0", "1"], ids=["split-major", "equal-runs"])
+def work_split(monkeypatch, request):
+    """Both work splits of the counting contraction (csrc/stream_eval.hip: mode 0 = per-row slices for galleries beyond the
+    Infinity Cache, mode 1 = equal runs of 64-column units that may cross query tiles); the default picks by gallery size."""
+    monkeypatch.setenv("CREID_STREAM_BALANCE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["eval_small", "eval_d2048", "eval_tiny_gallery"])
-def test_streamed_matches_reference_goldens(golden, name):
+def test_streamed_matches_reference_goldens(golden, name, work_split):
     g = golden(name)
     nq = int(g["num_query"])
     feats = torch.from_numpy(g["feats"])
@@ -52,7 +60,7 @@ def test_streamed_matches_reference_goldens(golden, name):
 @pytest.mark.parametrize("nq,ng,D,npid,ncam,dup", [(300, 3000, 256, 60, 3, True), (70, 513, 100, 9, 2, False),
                                                     (129, 1000, 2048, 400, 5, True), (5, 40, 32, 3, 2, False),
                                                     (33, 300, 8, 5, 2, False), (33, 700, 20, 7, 3, True), (64, 512, 48, 9, 2, False)])
-def test_streamed_equals_materialised_random(nq, ng, D, npid, ncam, dup):
+def test_streamed_equals_materialised_random(nq, ng, D, npid, ncam, dup, work_split):
     """N(0,1) features (dense near-ties in fp32), duplicated gallery rows (exact ties -> order by gallery index),
     queries whose pid is absent from the gallery or whose positives all share their camera."""
     rng = np.random.default_rng(nq * 7 + ng)
@@ -72,7 +80,7 @@ def test_streamed_equals_materialised_random(nq, ng, D, npid, ncam, dup):
         assert b.last["valid"][0].item() == 0 and b.last["valid"][1].item() == 0
 
 
-def test_streamed_overflow_rows_take_general_path():
+def test_streamed_overflow_rows_take_general_path(work_split):
     """A pid with more than 128 positives does not fit the LDS list: those queries are routed through the
     materialised kernels and merged; the rest stay streamed."""
     from centroids_reid_amd import reid_metric as rm
@@ -89,7 +97,7 @@ def test_streamed_overflow_rows_take_general_path():
     _assert_same(a, ra, b, rb, pids, cams, nq)
 
 
-def test_streamed_duke_shape_equals_materialised():
+def test_streamed_duke_shape_equals_materialised(work_split):
     """BASELINE configs[4] shape (2228 x 17661 x 2048, the bench generator): whole-job equality of the two paths."""
     gen = torch.Generator(device="cuda").manual_seed(0)
     nq, ng, D = 2228, 17661, 2048
@@ -101,7 +109,7 @@ def test_streamed_duke_shape_equals_materialised():
     assert 0 < rb[1] < 1
 
 
-def test_north_star_3000x15000_streamed_materialised_oracle():
+def test_north_star_3000x15000_streamed_materialised_oracle(work_split):
     """north_star's own target shape (3000 queries x 15000 gallery x 2048 fp32; utils/reid_metric.py:112-151): the streamed
     path equals the materialised one, the ranking has the size-independent properties, the integer stage equals the oracle on
     the device's ranking and a 64-query slice of the distance matrix matches float64 CPU arithmetic."""
@@ -256,8 +264,9 @@ def test_streamed_speculative_capacity_is_verified():
 
 
 def test_streamed_results_do_not_depend_on_the_gallery_slicing():
-    """The grid rule of the streamed contraction (round 5: at most CREID_STREAM_TPER gallery tiles per workgroup) only changes how
-    the gallery is cut into slices; a query's histogram is summed over the slices with integer atomics, so valid / first / AP must be
+    """The grid rules of the streamed contraction (per-row slices of at most CREID_STREAM_TPER gallery tiles; equal runs of 64-column
+    units over CREID_STREAM_WGS workgroups, which may end inside one query tile and continue in the next) only change how the work
+    is cut; a query's histogram is summed over the slices with integer atomics, so valid / first / AP must be
     IDENTICAL for every slicing.  The rule is read once per process: one subprocess per value, same seeded inputs."""
     import os
     import subprocess
@@ -279,9 +288,11 @@ def test_streamed_results_do_not_depend_on_the_gallery_slicing():
         "    h.update(m.last[k].cpu().numpy().tobytes())\n"
         "print('RESULT', repr(mAP), h.hexdigest())\n" % root)
     outs = []
-    for tper in ("1", "3", "1000"):
-        env = dict(os.environ, CREID_STREAM_TPER=tper)
+    for extra in ({"CREID_STREAM_BALANCE": "0", "CREID_STREAM_TPER": "1"}, {"CREID_STREAM_BALANCE": "0", "CREID_STREAM_TPER": "3"},
+                  {"CREID_STREAM_BALANCE": "0", "CREID_STREAM_TPER": "1000"}, {"CREID_STREAM_BALANCE": "1"},
+                  {"CREID_STREAM_BALANCE": "1", "CREID_STREAM_WGS": "37"}, {"CREID_STREAM_BALANCE": "1", "CREID_STREAM_WGS": "4000"}, {}):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1])
-    assert outs[0] == outs[1] == outs[2], outs
+    assert all(o == outs[0] for o in outs), outs
