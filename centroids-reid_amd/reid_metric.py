@@ -202,6 +202,33 @@ _CAP_HINT = {}      # (queries, gallery) -> positive-list capacity of the last s
                     # that R1_mAP._compute_streamed verifies; never trusted)
 
 
+_LABEL_STAGE = {}   # (device, length) -> (pinned [2, length] int64 staging tensor, event of its last upload)
+
+
+def _upload_labels(p, c, device):
+    """[2, len] int64 device tensor of (pids, camids) through a reused page-locked staging buffer: the copy is enqueued on the
+    current stream instead of blocking the host the way a pageable upload does (the evaluation's clock includes this upload;
+    the device is still normalising the features while it runs).  The buffer is reused only after its previous upload has
+    completed (event), whatever the caller did in between."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return torch.from_numpy(np.stack([p, c])).to(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), len(p))
+    ent = _LABEL_STAGE.get(key)
+    if ent is None:
+        if len(_LABEL_STAGE) > 8:
+            _LABEL_STAGE.clear()
+        ent = _LABEL_STAGE[key] = (torch.empty((2, len(p)), dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+    else:
+        ent[1].synchronize()
+    stage, ev = ent
+    h = stage.numpy()
+    np.copyto(h[0], p); np.copyto(h[1], c)
+    lab = stage.to(dev, non_blocking=True)
+    ev.record(torch.cuda.current_stream(dev))
+    return lab
+
+
 class StreamPlan:
     """Index for the streamed evaluation (csrc/stream_eval.hip): the gallery grouped by pid (CSR), every query's slot in
     it, and the per-query number of positives (same pid, different camera) which fixes the LDS list capacity `cap`.
@@ -231,15 +258,18 @@ class StreamPlan:
             return cls(p[:nq], p[nq:], c[:nq], c[nq:], device)
         self = cls.__new__(cls)
         self.m, self.n = m, n
-        lab = torch.from_numpy(np.stack([p, c])).to(device)                       # ONE upload: [2, nq + ng] int64
+        lab = _upload_labels(p, c, device)                                        # ONE upload: [2, nq + ng] int64
         self.q_pids, self.g_pids, self.q_cams, self.g_cams = lab[0, :nq], lab[0, nq:], lab[1, :nq], lab[1, nq:]
-        i32 = dict(dtype=torch.int32, device=device)
-        self.csr_off = torch.empty(R + 1, dtype=torch.int64, device=device)
-        self.g_order = torch.empty(n, **i32)
-        self.q_slot = torch.empty(max(m, 1), **i32)
-        self._n_pos_dev = torch.empty(max(m, 1), **i32)
-        self._stats = torch.empty(2, **i32)
-        scratch = torch.empty(2 * R, **i32)
+        # one allocation for the index: [csr_off int64 (R + 1) | g_order | q_slot | n_pos | stats | scratch (2 R)] int32
+        mm = max(m, 1)
+        ws = torch.empty(2 * (R + 1) + n + 2 * mm + 2 + 2 * R, dtype=torch.int32, device=device)
+        self.csr_off = ws[:2 * (R + 1)].view(torch.int64)
+        o = 2 * (R + 1)
+        self.g_order = ws[o:o + n]; o += n
+        self.q_slot = ws[o:o + mm]; o += mm
+        self._n_pos_dev = ws[o:o + mm]; o += mm
+        self._stats = ws[o:o + 2]; o += 2
+        scratch = ws[o:o + 2 * R]
         L.check(L.lib().creid_stream_plan(L.ptr(self.q_pids), L.ptr(self.g_pids), L.ptr(self.q_cams), L.ptr(self.g_cams), m, n,
                                           pmin, R, L.ptr(self.csr_off), L.ptr(self.g_order), L.ptr(self.q_slot),
                                           L.ptr(self._n_pos_dev), L.ptr(self._stats), L.ptr(scratch), L.stream()),
