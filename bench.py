@@ -129,6 +129,92 @@ def pmc_field(key, field):
     return None
 
 
+def inner_eval_trace():
+    """Child of pmc_eval_insitu: the two fp32 contraction kernels of the evaluation on the configs[4] shape, a few launches each."""
+    import torch
+    from centroids_reid_amd import reid_metric as rm
+    nq, ng, D = 2228, 17661, 2048
+    feats, pids, cams = eval_inputs(nq, ng, D, 0, 1)
+    plan = rm.StreamPlan.on_device(pids, cams, nq, "cuda").finish()
+    fn, sq = rm.l2_normalize(feats, return_sqnorm=True)
+    q, g = fn[:nq], fn[nq:]
+    qq, gg = sq[:nq].contiguous(), sq[nq:].contiguous()
+    L = rm.L
+    lib = L.lib()
+    cap = plan.cap
+    pos_key = torch.empty((nq, cap), dtype=torch.int32, device="cuda"); pos_idx = torch.empty_like(pos_key)
+    npos = torch.empty(nq, dtype=torch.int32, device="cuda"); hist = torch.zeros((nq, cap), dtype=torch.int32, device="cuda")
+    L.check(lib.creid_stream_poslist(L.ptr(q), L.ptr(g), L.ptr(qq), L.ptr(gg), nq, ng, D, L.ptr(plan.q_slot), L.ptr(plan.csr_off),
+                                     L.ptr(plan.g_order), L.ptr(plan.q_cams), L.ptr(plan.g_cams), cap, L.ptr(pos_key), L.ptr(pos_idx),
+                                     L.ptr(npos), L.stream()), "poslist")
+    for _ in range(4):
+        L.check(lib.creid_stream_count(L.ptr(q), L.ptr(g), L.ptr(qq), L.ptr(gg), nq, ng, D, L.ptr(plan.q_pids), L.ptr(plan.g_pids),
+                                       cap, L.ptr(pos_key), L.ptr(pos_idx), L.ptr(npos), L.ptr(hist), L.stream()), "count")
+        rm.get_euclidean(q, g, qq, gg)
+    torch.cuda.synchronize()
+
+
+def pmc_eval_insitu(timeout_s=120):
+    """HBM-side traffic and matrix-pipe occupancy of sqdist_count_f32_kernel / sqdist_f32_kernel measured in THIS run: three
+    `rocprofv3 --kernel-trace --pmc` child runs of `bench.py --inner-eval-trace` (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES
+    + GRBM_GUI_ACTIVE, each in a pass of its own; counters only).  Per kernel and LAUNCH (first launch dropped): fetch_bytes =
+    2 x FETCH_SIZE KiB (gfx950: the counter tallies 128-byte requests at 64), write_bytes = WRITE_SIZE KiB, mfma_busy = busy
+    cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).  None when rocprofv3 or a pass is unavailable."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or os.environ.get("CREID_BENCH_NO_PMC", "0") == "1":
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CREID_FORCE_DIST"):
+        env.pop(k, None)
+
+    def one_pass(counters):
+        tmp = tempfile.mkdtemp(prefix="creid_pmc_ev_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", *counters, "-d", tmp, "-o", "pmc", "--", sys.executable,
+                   os.path.join(here, "bench.py"), "--inner-eval-trace"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                print(f"[bench] eval counter pass {counters} failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+                return None
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, counter_name, value, dispatch_id, start from counters_collection").fetchall()
+            disp = {}
+            for kn, cn, v, did, st in rows:
+                d = disp.setdefault(did, {"name": kn, "start": st})
+                d[cn] = d.get(cn, 0.0) + float(v)
+            out = {}
+            for key in ("sqdist_count_f32_kernel", "sqdist_f32_kernel"):
+                ds = sorted((d for d in disp.values() if key in d["name"]), key=lambda d: d["start"])[1:]
+                if ds:
+                    out[key] = {c: sum(d.get(c, 0.0) for d in ds) / len(ds) for c in counters}
+            return out or None
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] eval counter pass {counters} unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+    F = one_pass(["FETCH_SIZE"])
+    Wr = one_pass(["WRITE_SIZE"]) if F else None
+    S = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]) if Wr else None
+    if not (F and Wr):
+        return None
+    out = {}
+    for key in F:
+        e = {"fetch_bytes": 2.0 * F[key]["FETCH_SIZE"] * 1024.0, "write_bytes": Wr.get(key, {}).get("WRITE_SIZE", 0.0) * 1024.0}
+        if S and key in S and S[key].get("GRBM_GUI_ACTIVE"):
+            e["mfma_busy"] = S[key]["SQ_VALU_MFMA_BUSY_CYCLES"] / (S[key]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        out[key] = e
+    return out
+
+
 def run_eval(args, rank, world, steps=None, warmup=None, shape=None, extras=True):
     """BASELINE configs[4]: normalise + squared-L2 + rank + CMC/mAP over 2228 x 17661 x 2048 fp32.  Timed twice:
     the METRIC-ONLY path the validation hook uses (streamed: the m x n matrix is never written; `value`) and the
@@ -235,17 +321,26 @@ def run_eval(args, rank, world, steps=None, warmup=None, shape=None, extras=True
         t_cmc = time_kernel(lambda: rm.eval_func_device(idx, q_pids, g_pids, q_cams, g_cams, 50), 10)
         t_rank_eval = time_kernel(lambda: rm.rank_rows_eval(d, q_pids, g_pids, q_cams, g_cams), 5)
         flops = 2.0 * nq * ng * D
+        live = pmc_eval_insitu() if (extras and world == 1 and shape is None) else None
+
+        def traffic_of(key):
+            if live and key in live:
+                return live[key]["fetch_bytes"] + live[key]["write_bytes"]
+            return pmc_traffic(key)
+        src = ("THIS run: rocprofv3 --kernel-trace --pmc child passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE, "
+               "one pass each) over the same kernels on the same inputs; fetch = 2 x FETCH_SIZE (gfx950)") if live else \
+            "profiles/r0x_pmc_traffic.json: committed rocprofv3 --pmc passes, NOT measured in this run"
         res["roofline"] = {"kernel": "sqdist_count_f32_kernel (contraction + in-register rank-by-counting epilogue)",
                            "bound": "mfma", "achieved": flops / (t_count * 1e-3) / 1e12, "peak": MFMA_F32_TFLOPS,
                            "unit": "TFLOP/s", "frac": flops / (t_count * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
-                           "traffic": pmc_traffic("sqdist_count_f32_kernel"), "ms": t_count,
-                           "traffic_source": "profiles/r0x_pmc_traffic.json: committed rocprofv3 --pmc passes, NOT measured in this run",
-                           "mfma_busy_by_counter": pmc_field("sqdist_count_f32_kernel", "mfma_busy")}
+                           "traffic": traffic_of("sqdist_count_f32_kernel"), "ms": t_count, "traffic_source": src,
+                           "mfma_busy_by_counter": (live or {}).get("sqdist_count_f32_kernel", {}).get("mfma_busy")
+                           if live else pmc_field("sqdist_count_f32_kernel", "mfma_busy")}
         res["materialised"] = {
             "value": float(nq) * ng * world * steps / dt_m, "unit": "pairs/s", "ms_per_step": dt_m / steps * 1e3,
             "roofline": {"kernel": "sqdist_f32_kernel", "bound": "mfma", "achieved": flops / (t_dist * 1e-3) / 1e12,
                          "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": flops / (t_dist * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
-                         "traffic": pmc_traffic("sqdist_f32_kernel"), "ms": t_dist},
+                         "traffic": traffic_of("sqdist_f32_kernel"), "ms": t_dist},
             "stages_ms": {"l2norm": t_norm, "sqdist": t_dist, "rank_rows_eval": t_rank_eval,
                           "separately": {"rank_rows": t_rank, "cmc_ap": t_cmc}},
             "rank_rows_GBs": nq * ng * (4 + 8) / (t_rank * 1e-3) / 1e9}
@@ -482,7 +577,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU leg (profiling runs; the default run always reports it)")
     ap.add_argument("--inner-trace", action="store_true", help=argparse.SUPPRESS)   # child of bench_train.insitu_trace
+    ap.add_argument("--inner-eval-trace", action="store_true", help=argparse.SUPPRESS)   # child of pmc_eval_insitu
     args = ap.parse_args()
+    if args.inner_eval_trace:
+        inner_eval_trace()
+        return
     rank, world = ddp_setup(args.gpus)
     if args.inner_trace:
         from centroids_reid_amd import bench_train
