@@ -16,7 +16,7 @@ python tools/train_layers.py $db > $o/train_layers.md 2>&1; tail -16 $o/train_la
 python tools/step_sequence.py $db > $o/step_sequence.txt 2>&1
 cp gpurun_out/prof_r6f.md $o/train_kernel_stats.md 2>/dev/null
 bash tools/prof_embed.sh r6fe > $o/embed_anatomy.md 2>&1; tail -4 $o/embed_anatomy.md
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $repo/gpurun_out/prof_r6fev -o ev -- \
+(cd /tmp && export TMPDIR=/tmp && CREID_BENCH_NO_PMC=1 rocprofv3 --kernel-trace --stats -d $repo/gpurun_out/prof_r6fev -o ev -- \
    python $repo/bench.py --workload eval --steps 5 --warmup 2 --no-cpu-baseline > $repo/gpurun_out/prof_r6fev.log 2>&1)
 python tools/prof_summary.py $(find gpurun_out/prof_r6fev -name "*.db" | head -1) $o/eval_kernel_stats.md > /dev/null; head -14 $o/eval_kernel_stats.md
 # the exact-f32 parity mode of the step: where its time goes

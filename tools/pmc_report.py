@@ -58,9 +58,16 @@ for key, prefix in (("igemm_family", "igemm_bf16_"), ("wgrad_family", "wgrad_bf1
     out[key] = {"launches": n, "fetch_bytes": 2 * f, "write_bytes": w, "fetch_size_raw_bytes": f,
                 "algorithmic_bytes": meta[key]["algorithmic_bytes"],
                 "traffic_over_algorithmic": (2 * f + w) / meta[key]["algorithmic_bytes"]}
+def by_prefix(db, key):
+    """The entry of a kernel whose template argument list is not part of the key (sqdist_count_f32_kernel<0, true> since round 6)."""
+    if key in db:
+        return db[key]
+    return next(v for k, v in db.items() if k.startswith(key + "<"))
+
+
 for key in ("sqdist_f32_kernel", "sqdist_count_f32_kernel", "rank_rows_lds_kernel", "stream_poslist_kernel", "cmc_ap_ranked_wide_kernel<false>"):
-    f = F[key]["FETCH_SIZE"]["sum"] * 1024; w = W[key]["WRITE_SIZE"]["sum"] * 1024
-    e = {"launches": F[key]["FETCH_SIZE"]["dispatches"], "fetch_bytes": 2 * f, "write_bytes": w, "fetch_size_raw_bytes": f}
+    f = by_prefix(F, key)["FETCH_SIZE"]["sum"] * 1024; w = by_prefix(W, key)["WRITE_SIZE"]["sum"] * 1024
+    e = {"launches": by_prefix(F, key)["FETCH_SIZE"]["dispatches"], "fetch_bytes": 2 * f, "write_bytes": w, "fetch_size_raw_bytes": f}
     if key in meta:
         e["algorithmic_bytes"] = meta[key]["algorithmic_bytes"]
         e["traffic_over_algorithmic"] = (2 * f + w) / meta[key]["algorithmic_bytes"]
