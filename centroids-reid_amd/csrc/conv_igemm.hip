@@ -1051,9 +1051,13 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IGemmGeom g, const float
                                                         const float* __restrict__ wgt, float* __restrict__ out,
                                                         const float* __restrict__ add_src,
                                                         float* __restrict__ bn_part, int tiles_n) {
-  constexpr int BK = 16, LDA = 129, LDB = BN + 1, TNW = BN / 64, NB = BN / 64;
-  __shared__ float As[2][BK][LDA];
-  __shared__ float Bs[2][BK][LDB];
+  // LDS operand image of a 16-deep k-tile (the same as dist.hip's fp32 distance kernel): [kh = k & 1][half = k >> 3][row][4] -- the
+  // per-lane MFMA operand is A[i = lane & 31][k = 2 step + (lane >> 5)], so four consecutive steps' values are one 16-byte unit
+  // (ds_read_b128) and a staged float4 is two 8-byte writes ((x, z) -> kh 0, (y, w) -> kh 1).  The k order of the accumulation is
+  // the sequential one of rounds 1-5: results unchanged.
+  constexpr int BK = 16, PA = 128 * 4 + 16, PB = BN * 4 + 16, TNW = BN / 64, NB = BN / 64;
+  __shared__ __attribute__((aligned(16))) float As[2][2][2][PA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][2][2][PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1077,33 +1081,34 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IGemmGeom g, const float
 #pragma unroll
   for (int i = 0; i < NB; ++i) wp[i] = wgt + (int64_t)(col0 + lrow + 64 * i) * g.K + 4 * lkc;
   float4 ra[2], rb[NB];
-  auto gload = [&](int t) {
+  unsigned amask[2] = {0u, 0u};                    // all ones where the staged tap is a real pixel (else the tile gets zeros)
+  auto gload = [&](int t) {                        // branch-free: an absent tap reads the tensor's first element and is masked in lstore
     const int kk = t * BK + 4 * lkc;
     const int tap = kk >> g.log2span, c = kk & span_mask;
     const int r = tap / g.kw, s = tap - r * g.kw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int iy, ix;
-      if (vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix))
-        ra[i] = *reinterpret_cast<const float4*>(src + (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + c);
-      else
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = vm[i] && igemm_src_pixel(g, oy[i], ox[i], r, s, iy, ix);
+      amask[i] = ok ? 0xffffffffu : 0u;
+      const int64_t off = ok ? (int64_t)(bpix[i] + iy * g.SW + ix) * g.pitch + c : 0;
+      ra[i] = *reinterpret_cast<const float4*>(src + off);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4*>(wp[i] + t * BK);
   };
+  const int sh = lkc >> 1, so = lrow * 4 + 2 * (lkc & 1);          // global k = 4 lkc + {0..3}: steps 2 lkc, 2 lkc + 1
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = lrow + 64 * i;
-      As[buf][4 * lkc + 0][r] = ra[i].x; As[buf][4 * lkc + 1][r] = ra[i].y;
-      As[buf][4 * lkc + 2][r] = ra[i].z; As[buf][4 * lkc + 3][r] = ra[i].w;
+      auto mk = [&](float v) { return __uint_as_float(__float_as_uint(v) & amask[i]); };
+      *reinterpret_cast<float2*>(&As[buf][0][sh][so + 256 * i]) = make_float2(mk(ra[i].x), mk(ra[i].z));
+      *reinterpret_cast<float2*>(&As[buf][1][sh][so + 256 * i]) = make_float2(mk(ra[i].y), mk(ra[i].w));
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int r = lrow + 64 * i;
-      Bs[buf][4 * lkc + 0][r] = rb[i].x; Bs[buf][4 * lkc + 1][r] = rb[i].y;
-      Bs[buf][4 * lkc + 2][r] = rb[i].z; Bs[buf][4 * lkc + 3][r] = rb[i].w;
+      *reinterpret_cast<float2*>(&Bs[buf][0][sh][so + 256 * i]) = make_float2(rb[i].x, rb[i].z);
+      *reinterpret_cast<float2*>(&Bs[buf][1][sh][so + 256 * i]) = make_float2(rb[i].y, rb[i].w);
     }
   };
   f32x16 acc[2][TNW];
@@ -1114,29 +1119,67 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(IGemmGeom g, const float
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int nk = g.K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
   const int l31 = lane & 31, kh = lane >> 5;
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nk) gload(t + 1);
+  const int fa = (wm * 64 + l31) * 4, fb = (wn * (BN / 2) + l31) * 4;
+  // Two-phase k-loop (round 6, from the evaluation's distance kernels): 8 TNW MFMAs (64 cycles each) per phase with everything
+  // else issued in their shadow -- phase 1: the second half's fragment reads + the LDS writes of the next k-tile, barrier,
+  // phase 2: the global loads of the k-tile after that + the next k-tile's first-half fragment reads.  (Before: reads, MFMAs,
+  // writes, barrier in sequence per k-tile; the two waves a SIMD holds fell into step and the matrix pipe idled with them.)
+  float4 a0[2], b0[TNW], a1[2], b1[TNW];
+  auto frag = [&](int buf, int half, float4 (&a)[2], float4 (&b)[TNW]) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[2], b[TNW];
+    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][kh][half][fa + 128 * i]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[buf][kk + kh][wm * 64 + i * 32 + l31];
+    for (int j = 0; j < TNW; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[buf][kh][half][fb + 128 * j]);
+  };
+  auto mma = [&](const float4 (&a)[2], const float4 (&b)[TNW]) {   // steps in k order: 4 half + s4 multiplies k = 2 step + kh
 #pragma unroll
-      for (int j = 0; j < TNW; ++j) b[j] = Bs[buf][kk + kh][wn * (BN / 2) + j * 32 + l31];
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float av[2], bv[TNW];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const float c4[4] = {a[i].x, a[i].y, a[i].z, a[i].w}; av[i] = c4[s4]; }
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) { const float c4[4] = {b[j].x, b[j].y, b[j].z, b[j].w}; bv[j] = c4[s4]; }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < nk) lstore(buf ^ 1);
+  };
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  gload(nk > 1 ? 1 : 0);
+  frag(0, 0, a0, b0);
+  for (int t = 0; t + 1 < nk; ++t) {
+    const int buf = t & 1;
+    __builtin_amdgcn_sched_barrier(0);
+    frag(buf, 1, a1, b1);
+    lstore(buf ^ 1);
+    mma(a0, b0);
+#pragma unroll
+    for (int i = 0; i < 2 + TNW; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+    for (int i = 0; i < 2 + NB; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * TNW - (2 + TNW) - (2 + NB), 0);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    gload(t + 2 < nk ? t + 2 : nk - 1);
+    frag(buf ^ 1, 0, a0, b0);
+    mma(a1, b1);
+#pragma unroll
+    for (int i = 0; i < 2 + NB; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x020, 1, 1); }
+#pragma unroll
+    for (int i = 0; i < 2 + TNW; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * TNW - (2 + NB) - (2 + TNW), 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  float* red = &As[0][0][0];
+  frag((nk - 1) & 1, 1, a1, b1);                   // last k-tile: nothing left to stage
+  mma(a0, b0);
+  mma(a1, b1);
+  __syncthreads();                                 // the reduction scratch below aliases the operand image
+  float* red = &As[0][0][0][0];
 #pragma unroll
   for (int j = 0; j < TNW; ++j) {
     const int cl = wn * (BN / 2) + j * 32 + l31;
