@@ -154,7 +154,7 @@ def inner_eval_trace():
     torch.cuda.synchronize()
 
 
-def pmc_eval_insitu(timeout_s=120):
+def pmc_eval_insitu(timeout_s=75):
     """HBM-side traffic and matrix-pipe occupancy of sqdist_count_f32_kernel / sqdist_f32_kernel measured in THIS run: three
     `rocprofv3 --kernel-trace --pmc` child runs of `bench.py --inner-eval-trace` (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES
     + GRBM_GUI_ACTIVE, each in a pass of its own; counters only).  Per kernel and LAUNCH (first launch dropped): fetch_bytes =
@@ -166,7 +166,7 @@ def pmc_eval_insitu(timeout_s=120):
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe) or os.environ.get("CREID_BENCH_NO_PMC", "0") == "1":
+    if not os.path.exists(exe) or os.environ.get("CREID_BENCH_NO_PMC", "0") == "1" or os.environ.get("CREID_BENCH_PMC_FAILED") == "1":
         return None
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, TMPDIR="/tmp")

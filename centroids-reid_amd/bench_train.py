@@ -322,6 +322,7 @@ def pmc_insitu(timeout_s=150):
     Wr = one_pass(["WRITE_SIZE"]) if F else None
     S = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]) if Wr else None
     if not (F and Wr):
+        os.environ["CREID_BENCH_PMC_FAILED"] = "1"          # the evaluation's counter passes (bench.pmc_eval_insitu) are not tried either
         return None
     out = {}
     for key, pat in (("igemm", _IGEMM_PAT), ("wgrad", _WGRAD_PAT)):
