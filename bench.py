@@ -622,6 +622,10 @@ def main():
                     ev["north_star_3000x15000"] = ns
                 if c3 is not None:
                     ev["configs3_shard"] = c3
+                vy = out.get("extra", {}).get("vendor_yardstick")
+                if vy and "eval" in vy:                      # stock torch to RANKED INDICES vs the product's materialised path (adds CMC / AP)
+                    vy["eval"]["product_materialised_over_vendor"] = ev["materialised"]["value"] / vy["eval"]["pairs_per_s_to_ranked_indices"]
+                    vy["eval"]["product_streamed_over_vendor"] = ev["value"] / vy["eval"]["pairs_per_s_to_ranked_indices"]
                 out["eval"] = ev
     else:
         args.steps = args.steps or 5

@@ -6,6 +6,9 @@ child process and prints the result as `extra.vendor_yardstick` when it finishes
   step : ResNet50 (last_stride 1, no stem ReLU: modelling/backbones/resnet.py) 256 x 128, B = 64, forward + backward of
          sum(GAP features^2) stand-in head (the heads are ~2 % of the step), Adam over all parameters      -> images/s
   embed: the same backbone in eval mode, B = 128, forward only                                             -> images/s
+  eval : the reference's distance stage as it is written (utils/reid_metric.py:25-33: pow-sum + addmm_, fp32) on
+         2228 x 17661 x 2048 device features, plus torch.argsort of the matrix (what utils/eval_reid.py:36 does in
+         numpy on the host) -- the stock-GPU route to ranked indices; no CMC / AP                           -> pairs/s
 
     python tools/vendor_step.py [--steps 20] [--no-graph]        -> one JSON line
 """
@@ -119,6 +122,27 @@ def main():
         except Exception as e:  # noqa: BLE001  (a capture problem of the stock stack: fall back to eager launches)
             out.setdefault("errors", []).append(f"graph={graph}: {type(e).__name__}: {str(e)[:200]}")
             torch.cuda.synchronize()
+    try:
+        nq, ng, D = 2228, 17661, 2048
+        gen = torch.Generator(device=dev).manual_seed(0)
+        feats = torch.randn((nq + ng, D), generator=gen, device=dev)
+
+        def dist_only():
+            f = torch.nn.functional.normalize(feats, dim=1, p=2)
+            qf, gf = f[:nq], f[nq:]
+            d = torch.pow(qf, 2).sum(dim=1, keepdim=True).expand(nq, ng) + torch.pow(gf, 2).sum(dim=1, keepdim=True).expand(ng, nq).t()
+            d.addmm_(qf, gf.t(), beta=1, alpha=-2)
+            return d
+
+        def dist_rank():
+            return torch.argsort(dist_only(), dim=1)
+        td = timed(dist_only, 10, 3, False)
+        tr = timed(dist_rank, 5, 2, False)
+        out["eval"] = {"pairs_per_s_to_ranked_indices": nq * ng / tr, "ms_normalise_and_distance_matrix": td * 1e3,
+                       "ms_to_ranked_indices": tr * 1e3, "shape": [nq, ng, D],
+                       "note": "normalize + pow-sum + addmm_ (hipBLASLt fp32) + torch.argsort; the reference ranks on the host in numpy"}
+    except Exception as e:  # noqa: BLE001
+        out.setdefault("errors", []).append(f"eval: {type(e).__name__}: {str(e)[:200]}")
     print(json.dumps(out))
     return 0 if "step" in out else 1
 
