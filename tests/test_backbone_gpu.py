@@ -225,6 +225,35 @@ def test_resnet50_fp32_golden(golden):
     assert abs(gsum - float(g["grad_abs_sum"])) < 2e-2 * float(g["grad_abs_sum"])
 
 
+@pytest.mark.parametrize("arch,base,ac,H,W", [("resnet50", "backbone_r50_2x256x128", "backbone_r50_autocast_2x256x128", 256, 128),
+                                              ("resnet50_ibn_a", "backbone_r50ibn_2x64x64", "backbone_r50ibn_autocast_2x64x64", 64, 64)])
+@pytest.mark.parametrize("tag,dtype", [("f16", torch.float16), ("bf16", torch.bfloat16)])
+def test_16bit_modes_vs_the_reference_under_autocast(golden, arch, base, ac, H, W, tag, dtype):
+    """The reference's `precision=16` is torch autocast around its own modules (utils/misc.py:111).  `tools/gen_golden.py autocast`
+    ran exactly those modules under torch.autocast (CPU build: the same op-level policy -- convolutions in the 16-bit type,
+    BatchNorm / ReLU / pooling / residual adds by type promotion) on the weights and images of the fp32 recording.  The 16-bit
+    modes here round differently (fp32 accumulation and BatchNorm statistics inside the kernels, one rounding per layer output),
+    so they are compared through the fp32 recording: their error against it must not exceed the reference-under-autocast's own
+    error by more than 1.2 x (measured: 0.88-0.99 x), and the two 16-bit results must agree with each other to within the sum of both errors."""
+    from oracle import backbone_oracle as bo
+    g, a = golden(base), golden(ac)
+    net, eng, sd = _build(arch, dtype)
+    x = bo.synthetic_images(2, H, W, seed=7).cuda()
+
+    def rel(u, v):
+        u = np.asarray(u, np.float64).ravel(); v = np.asarray(v, np.float64).ravel()
+        return np.linalg.norm(u - v) / np.linalg.norm(v)
+    for mode, training in (("eval", False), ("train", True)):
+        ref32, ref16 = g[f"{mode}_feat"], a[f"{mode}_feat_{tag}"]
+        _, feat = eng.forward(x, training=training)
+        ours = feat.float().cpu().numpy()
+        assert np.isfinite(ours).all()
+        e_ref, e_ours, e_cross = rel(ref16, ref32), rel(ours, ref32), rel(ours, ref16)
+        print(f"{arch} {tag} {mode}: reference under autocast vs its fp32 {e_ref:.3e}, this mode vs fp32 {e_ours:.3e}, mode vs autocast {e_cross:.3e}")
+        assert e_ours <= 1.2 * e_ref + 1e-5, (mode, e_ours, e_ref)
+        assert e_cross <= e_ours + e_ref + 1e-6, (mode, e_cross, e_ours, e_ref)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,C,with_res,relu", [(256, 64, True, True), (1000, 256, False, True), (4096, 2048, True, True),
                                                (300, 128, False, False)])

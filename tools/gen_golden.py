@@ -297,10 +297,40 @@ def gen_backbone(ref, name, arch, B, H, W):
           f"train_feat std={rec['train_feat'].std():.5f} grad_abs_sum={gsum:.4e}")
 
 
+def gen_backbone_autocast(ref, name, arch, B, H, W):
+    """The reference's own modules under torch.autocast -- the op-level dtype policy of its `precision=16` trainer flag
+    (utils/misc.py:111: Lightning native AMP = autocast around the step), executed here on the CPU (autocast(cpu) lowers the
+    same convolutions / linears and leaves BatchNorm, ReLU, pooling and the residual adds to type promotion, like
+    autocast(cuda)).  Same weights and images as gen_backbone(name without the suffix): the fp32 recording there is the anchor
+    the 16-bit errors are measured against."""
+    from oracle import backbone_oracle as bo
+    sd = bo.make_state_dict(arch, 1, seed=1234)
+    if arch.endswith("_ibn_a"):
+        net = getattr(ref.resnet_ibn_a, arch)(1)
+    else:
+        net = ref.resnet.ResNet(last_stride=1, block=ref.resnet.Bottleneck, layers=list(bo.ARCH_LAYERS[arch]))
+    net.load_state_dict(sd, strict=False)
+    x = bo.synthetic_images(B, H, W, seed=7)
+    rec = {}
+    for tag, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        net.load_state_dict(sd, strict=False)                      # running statistics back to the initial ones
+        net.eval()
+        with torch.no_grad(), torch.autocast("cpu", dtype=dt):
+            y = net(x)
+        rec[f"eval_dtype_{tag}"] = np.array(str(y.dtype))
+        rec[f"eval_feat_{tag}"] = y.float().mean(dim=(2, 3)).numpy()
+        net.train()
+        with torch.no_grad(), torch.autocast("cpu", dtype=dt):
+            y = net(x)
+        rec[f"train_feat_{tag}"] = y.float().mean(dim=(2, 3)).numpy()
+        print(f"[{name}] {tag}: out dtype {y.dtype}")
+    np.savez_compressed(os.path.join(OUT, name), arch=np.array(arch), B=np.int64(B), H=np.int64(H), W=np.int64(W), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.load()
-    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed", "transforms", "deep", "config", "basic")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
+    which = [a for a in sys.argv[1:] if a not in ("sampler", "ckpt", "camsets", "inference", "surface_r2", "ibn320", "streamed", "transforms", "deep", "config", "basic", "autocast")] or (["eval", "losses", "heads", "backbone"] if len(sys.argv) == 1 else [])
     if "eval" in which:
         gen_eval(ref, "eval_small", 32, 256, 64, 11, n_pid=24, n_cam=4, min_gap=2e-5, force_invalid=2)
         gen_eval(ref, "eval_d2048", 24, 200, 2048, 12, n_pid=25, n_cam=6, min_gap=1e-5, force_invalid=1, slim=True)
@@ -314,6 +344,9 @@ def main():
         gen_heads(ref, "heads_p16k4_d128_fake1", 16, 4, 128, 60, 32, fakes=(5,))
         gen_heads(ref, "heads_p16k4_d128_fake2", 16, 4, 128, 60, 33, fakes=(8, 9, 30))
         gen_heads(ref, "heads_p8k4_d2048", 8, 4, 2048, 24, 34)
+    if "autocast" in sys.argv[1:]:
+        gen_backbone_autocast(ref, "backbone_r50_autocast_2x256x128", "resnet50", 2, 256, 128)
+        gen_backbone_autocast(ref, "backbone_r50ibn_autocast_2x64x64", "resnet50_ibn_a", 2, 64, 64)
     if "backbone" in which:
         gen_backbone(ref, "backbone_r50_2x256x128", "resnet50", 2, 256, 128)
         gen_backbone(ref, "backbone_r50ibn_2x64x64", "resnet50_ibn_a", 2, 64, 64)
