@@ -297,15 +297,15 @@ def gen_backbone(ref, name, arch, B, H, W):
           f"train_feat std={rec['train_feat'].std():.5f} grad_abs_sum={gsum:.4e}")
 
 
-def gen_full_step(ref, name="full_step_r50_p4k4_64x32"):
+def gen_full_step(ref, name="full_step_r50_p4k4_64x32", arch="resnet50", H=64, W=32, seed=77):
     """The reference's whole training_step (real ResNet50 + BNNeck + the four losses + both optimiser steps) on a small PK batch
     with one isReal = False sample, in fp32.  (Under torch.autocast(cpu) the step does not run: losses/triplet_loss.py:34's in-place
     addmm_ mixes the 16-bit features with fp32 terms, which only the CUDA autocast lists reconcile -- so the precision=16 anchor is
     the backbone recording of gen_backbone_autocast, where the 16-bit arithmetic lives.)  Weights / batch: those of
     tests/test_ctl_step_gpu.py::test_full_model_fp32_vs_oracle."""
     from oracle import backbone_oracle as bo
-    P, K, C, H, W = 4, 4, 20, 64, 32
-    sd = bo.make_state_dict("resnet50", 1, seed=77)
+    P, K, C = 4, 4, 20
+    sd = bo.make_state_dict(arch, 1, seed=seed)
     rng = np.random.default_rng(5)
     centers0 = torch.from_numpy(rng.standard_normal((C, 2048)).astype(np.float32)) * 0.3
     fc0 = torch.from_numpy((rng.standard_normal((C, 2048)) * 0.01).astype(np.float32))
@@ -318,6 +318,7 @@ def gen_full_step(ref, name="full_step_r50_p4k4_64x32"):
         cfg.SOLVER.MARGIN = 0.5
         cfg.DATALOADER.NUM_INSTANCE = K
         cfg.MODEL.BACKBONE_EMB_SIZE = 2048
+        cfg.MODEL.NAME = arch
         model = ref.train_ctl_model.CTLModel(cfg, num_classes=C, num_query=0)
         missing = model.backbone.base.load_state_dict(sd, strict=False)
         assert not missing.unexpected_keys, missing
@@ -339,7 +340,8 @@ def gen_full_step(ref, name="full_step_r50_p4k4_64x32"):
         for n in model.losses_names:
             rec[f"{tag}_{n}"] = np.float32(model.losses_dict[n][-1])
         print(f"[{name}] {tag}: total={rec[tag + '_loss_total']:.6f} " + " ".join(f"{n}={rec[tag + '_' + n]:.6f}" for n in model.losses_names))
-    np.savez_compressed(os.path.join(OUT, name), P=np.int64(P), K=np.int64(K), C=np.int64(C), H=np.int64(H), W=np.int64(W), **rec)
+    np.savez_compressed(os.path.join(OUT, name), arch=np.array(arch), seed=np.int64(seed), P=np.int64(P), K=np.int64(K), C=np.int64(C),
+                        H=np.int64(H), W=np.int64(W), **rec)
 
 
 def gen_backbone_autocast(ref, name, arch, B, H, W):
@@ -393,6 +395,7 @@ def main():
         gen_backbone_autocast(ref, "backbone_r50_autocast_2x256x128", "resnet50", 2, 256, 128)
         gen_backbone_autocast(ref, "backbone_r50ibn_autocast_2x64x64", "resnet50_ibn_a", 2, 64, 64)
         gen_full_step(ref)
+        gen_full_step(ref, "full_step_r50ibn_p4k4_64x64", "resnet50_ibn_a", 64, 64, seed=79)
     if "backbone" in which:
         gen_backbone(ref, "backbone_r50_2x256x128", "resnet50", 2, 256, 128)
         gen_backbone(ref, "backbone_r50ibn_2x64x64", "resnet50_ibn_a", 2, 64, 64)
