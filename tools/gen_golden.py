@@ -331,15 +331,24 @@ def gen_full_step(ref, name="full_step_r50_p4k4_64x32", arch="resnet50", H=64, W
         model.trainer = types.SimpleNamespace(current_epoch=0)
         model.train()
         batch = (x, labels, torch.zeros(P * K, dtype=torch.int64), is_real)
-        if dt is None:
-            out = model.training_step(batch, 0)
-        else:
-            with torch.autocast("cpu", dtype=dt):
-                out = model.training_step(batch, 0)
+        out = model.training_step(batch, 0)
         rec[f"{tag}_loss_total"] = np.float32(float(out["loss"]))
         for n in model.losses_names:
             rec[f"{tag}_{n}"] = np.float32(model.losses_dict[n][-1])
         print(f"[{name}] {tag}: total={rec[tag + '_loss_total']:.6f} " + " ".join(f"{n}={rec[tag + '_' + n]:.6f}" for n in model.losses_names))
+        # three more steps on fresh batches of the same identities (trajectory: Adam + the centers' SGD + BatchNorm running
+        # statistics feed back into the next step's losses)
+        for st in range(1, 4):
+            xs = bo.synthetic_images(P * K, H, W, seed=3 + st)
+            out = model.training_step((xs, labels, torch.zeros(P * K, dtype=torch.int64), torch.ones(P * K, dtype=torch.bool)), st)
+            rec[f"{tag}_s{st}_loss_total"] = np.float32(float(out["loss"]))
+            for n in model.losses_names:
+                rec[f"{tag}_s{st}_{n}"] = np.float32(model.losses_dict[n][-1])
+            print(f"[{name}] step {st}: total={rec[f'{tag}_s{st}_loss_total']:.6f}")
+        rec["l4_bn3_rm_after"] = model.backbone.base.layer4[2].bn3.running_mean.numpy().copy()
+        rec["bn_rv_after"] = model.bn.running_var.numpy().copy()
+        rec["centers_after"] = model.center_loss.centers.detach().numpy().copy()
+        rec["conv1_after_slice"] = model.backbone.base.conv1.weight.detach().numpy()[:8].copy()
     np.savez_compressed(os.path.join(OUT, name), arch=np.array(arch), seed=np.int64(seed), P=np.int64(P), K=np.int64(K), C=np.int64(C),
                         H=np.int64(H), W=np.int64(W), **rec)
 
