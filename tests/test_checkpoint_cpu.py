@@ -175,3 +175,38 @@ def test_config_tree_has_exactly_the_reference_keys_and_defaults():
     assert sorted(own) == sorted(ref), (sorted(set(ref) - set(own)), sorted(set(own) - set(ref)))
     diff = {k: (own[k], ref[k]) for k in ref if own[k] != ref[k]}
     assert not diff, diff
+
+
+def test_learning_rate_schedule_matches_the_reference_recording(golden):
+    """solver/build.py:50-63 + the warm-up of train_ctl_model.py:41-49: the learning rate Adam steps with, epoch by epoch, for both
+    scheduler names with and without warm-up, against `tools/gen_golden.py autocast` -> lr_schedule.npz (the reference's optimiser,
+    scheduler and warm-up lines run for 120 epochs).  Here: this package's FusedAdam / CenterSGD param_groups under the same torch
+    scheduler, the warm-up as CTLModel.forward_backward applies it."""
+    import warnings
+    import torch
+    from centroids_reid_amd.config import get_cfg_defaults
+    from centroids_reid_amd.solver import build_optimizer, build_scheduler
+    g = golden("lr_schedule")
+    for sched in ("multistep_lr", "cosine_annealing"):
+        for warm in (True, False):
+            cfg = get_cfg_defaults()
+            cfg.SOLVER.LR_SCHEDULER_NAME = sched
+            cfg.SOLVER.USE_WARMUP_LR = warm
+            if sched == "cosine_annealing":
+                cfg.SOLVER.MIN_LR = 1e-7
+            w = torch.nn.Parameter(torch.zeros(4)); c = torch.nn.Parameter(torch.zeros(4))
+            opts = build_optimizer([("w", w), ("center_loss.centers", c)], cfg)
+            sch = build_scheduler(opts[0], cfg)
+            used, center = [], []
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                 # "scheduler.step() before optimizer.step()": no device here to step on
+                for epoch in range(int(cfg.SOLVER.MAX_EPOCHS)):
+                    if cfg.SOLVER.USE_WARMUP_LR and epoch < cfg.SOLVER.WARMUP_EPOCHS:
+                        lr_scale = min(1.0, float(epoch + 1) / float(cfg.SOLVER.WARMUP_EPOCHS))
+                        for pg in opts[0].param_groups:
+                            pg["lr"] = lr_scale * cfg.SOLVER.BASE_LR
+                    used.append(opts[0].param_groups[0]["lr"]); center.append(opts[1].param_groups[0]["lr"])
+                    sch.step()
+            key = f"{sched}_{'warm' if warm else 'nowarm'}"
+            np.testing.assert_allclose(np.array(used), g[key], rtol=1e-12, atol=0, err_msg=key)
+            np.testing.assert_allclose(np.array(center), g[key + "_center"], rtol=0, atol=0, err_msg=key)

@@ -353,6 +353,39 @@ def gen_full_step(ref, name="full_step_r50_p4k4_64x32", arch="resnet50", H=64, W
                         H=np.int64(H), W=np.int64(W), **rec)
 
 
+def gen_lr_schedule(ref, name="lr_schedule"):
+    """The learning rate Adam actually steps with, epoch by epoch, under the reference's two mechanisms together: the warm-up
+    written into training_step (train_ctl_model.py:41-49, overwrites every group's lr with lr_scale x BASE_LR) and the epoch
+    scheduler of solver/build.py:50-63 (stepped once per epoch, as the Lightning trainer does), for both scheduler names and the
+    default SOLVER values (BASE_LR, WARMUP_EPOCHS 10, LR_STEPS [40, 70], GAMMA 0.1, MAX_EPOCHS 120; config/defaults.py has no
+    SOLVER.MIN_LR -- the cosine branch reads it from the user's yaml -- so it is set to 1e-7 here)."""
+    rec = {}
+    for sched in ("multistep_lr", "cosine_annealing"):
+        for warm in (True, False):
+            cfg = make_cfg(ref)
+            cfg.SOLVER.LR_SCHEDULER_NAME = sched
+            cfg.SOLVER.USE_WARMUP_LR = warm
+            if sched == "cosine_annealing":
+                cfg.SOLVER.MIN_LR = 1e-7
+            w = torch.nn.Parameter(torch.zeros(4)); c = torch.nn.Parameter(torch.zeros(4))
+            opts = ref.solver.build_optimizer([("w", w), ("center_loss.centers", c)], cfg)
+            sch = ref.solver.build_scheduler(opts[0], cfg)
+            used, center = [], []
+            for epoch in range(int(cfg.SOLVER.MAX_EPOCHS)):
+                if cfg.SOLVER.USE_WARMUP_LR and epoch < cfg.SOLVER.WARMUP_EPOCHS:       # train_ctl_model.py:41-49
+                    lr_scale = min(1.0, float(epoch + 1) / float(cfg.SOLVER.WARMUP_EPOCHS))
+                    for pg in opts[0].param_groups:
+                        pg["lr"] = lr_scale * cfg.SOLVER.BASE_LR
+                used.append(opts[0].param_groups[0]["lr"]); center.append(opts[1].param_groups[0]["lr"])
+                w.grad = torch.ones(4); c.grad = torch.ones(4)
+                opts[0].step(); opts[1].step()
+                sch.step()
+            key = f"{sched}_{'warm' if warm else 'nowarm'}"
+            rec[key] = np.array(used, np.float64); rec[key + "_center"] = np.array(center, np.float64)
+            print(f"[{name}] {key}: lr[0..12] = {np.round(np.array(used[:13]) * 1e4, 3).tolist()} x1e-4, lr[39..42] = {used[39:43]}, last {used[-1]:.3e}")
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+
+
 def gen_backbone_autocast(ref, name, arch, B, H, W):
     """The reference's own modules under torch.autocast -- the op-level dtype policy of its `precision=16` trainer flag
     (utils/misc.py:111: Lightning native AMP = autocast around the step), executed here on the CPU (autocast(cpu) lowers the
@@ -404,6 +437,7 @@ def main():
         gen_backbone_autocast(ref, "backbone_r50_autocast_2x256x128", "resnet50", 2, 256, 128)
         gen_backbone_autocast(ref, "backbone_r50ibn_autocast_2x64x64", "resnet50_ibn_a", 2, 64, 64)
         gen_full_step(ref)
+        gen_lr_schedule(ref)
         gen_full_step(ref, "full_step_r50ibn_p4k4_64x64", "resnet50_ibn_a", 64, 64, seed=79)
     if "backbone" in which:
         gen_backbone(ref, "backbone_r50_2x256x128", "resnet50", 2, 256, 128)
